@@ -1,0 +1,105 @@
+"""ctypes binding of the C ABI declared in include/b2m.h.
+
+There is no CPU fallback: if the shared library is missing the import fails loudly and tells the
+user how to build it.  Device pointers are passed as integers (``tensor.data_ptr()``) and the
+stream is torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libb2m_hip.so')
+
+P = C.c_void_p
+I32 = C.c_int32
+I64 = C.c_int64
+F32 = C.c_float
+F64 = C.c_double
+
+# name -> argument types (return type is always int).  Must list EVERY symbol of include/b2m.h;
+# tests/test_abi.py cross-checks this table against the header.
+PROTOTYPES = {
+    'b2m_coords_build': [P, I64, P, P, I64, P, P],
+    'b2m_coords_stride': [P, I64, I32, P, P, P, P, P, I64, P, C.POINTER(I64), P],
+    'b2m_kernel_map': [P, I64, I32, I32, P, P, I64, P, I64, P],
+    'b2m_stride_tables': [P, P, I64, I64, P, I64, P, I64, P],
+    'b2m_rulebook': [P, I64, I32, I64, P, P, P, P, P],
+    'b2m_conv_fwd': [P, I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, I64, P, I64, I32, I32, P],
+    'b2m_weight_transpose': [P, I64, I32, I32, I32, P, I64, I32, P],
+    'b2m_conv_wgrad': [P, I64, I32, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P],
+    'b2m_bn_stats': [P, I64, I64, I32, P, P, P],
+    'b2m_bn_finalize': [P, F64, I32, P, P, F32, F32, P, P, P, P, P, P, P],
+    'b2m_bn_apply': [P, I64, I64, I32, P, P, P, I64, I32, P, I64, P],
+    'b2m_bn_bwd_reduce': [P, I64, P, I64, P, I64, I64, I32, P, P, I32, P, P, P],
+    'b2m_bn_bwd_apply': [P, I64, P, I64, P, I64, I64, I32, P, P, P, P, F64, I32, P, I64, P, I64, P],
+    'b2m_relu_fwd': [P, I64, P, P],
+    'b2m_relu_bwd': [P, P, I64, P, P],
+    'b2m_add': [P, P, I64, P, P],
+    'b2m_segment_pool_fwd': [P, I64, I64, I32, P, I64, I32, P, P, P, P, P],
+    'b2m_segment_pool_bwd': [P, I64, I32, P, I64, I32, P, P, P, I64, P],
+    'b2m_nmc': [P, I32, F32, I32, P, P, P, P, P, P],
+    'b2m_mask_project': [P, I32, P, I32, P, P, I64, F32, P, I64, P],
+    'b2m_mask_nms': [P, I32, I64, F32, P, P, P, P],
+    'b2m_label_hist': [P, I64, P, I32, P, I64, I32, P, P],
+    'b2m_mask_gather': [P, I64, P, I32, P, I64, P, P],
+    'b2m_mask_pack': [P, I32, I64, P, I64, P],
+    'b2m_set_ious': [P, P, I64, P, P],
+}
+PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_device_ok': (C.c_int, [])}
+
+_lib = None
+
+
+class B2MError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libb2m_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'box2mask_amd: the HIP extension %s is missing. Build it with '
+            '`python -m box2mask_amd.build` (hipcc --offload-arch=gfx950); there is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, (res, args) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, or None."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke a b2m_* entry on the current stream; raise B2MError on a negative return."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise B2MError('%s failed (%d): %s' % (name, rc, lib.b2m_last_error().decode()))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise B2MError('box2mask_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path in the product.')
+    load()

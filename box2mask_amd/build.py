@@ -1,0 +1,57 @@
+"""Build recipe for the HIP extension (one shared library with a C ABI, include/b2m.h).
+
+`python -m box2mask_amd.build` cross-compiles for gfx950 with hipcc; no GPU is needed to build.
+The library is built in-tree (box2mask_amd/libb2m_hip.so) so that it travels with the repository
+snapshot to the GPU box and shows up as loaded native code.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libb2m_hip.so')
+SOURCES = ['coords.hip', 'conv.hip', 'norm.hip', 'nms.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics', '-Wall',
+         '-Wno-unused-function']
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'b2m.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(CSRC, s.replace('.hip', '.o'))
+        objs.append(o)
+        cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode()))
+        if verbose and out.strip():
+            print(out.decode())
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

@@ -1,0 +1,285 @@
+// Coordinate hashing, strided coordinate generation, kernel maps and the tile rulebook.
+// All integer work, HBM/L2-latency bound; results are bit-exact against oracle/sparse_ref.py.
+#include "b2m_common.h"
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+void b2m_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* b2m_last_error(void) { return g_err; }
+extern "C" int b2m_version(void) { return 1; }
+extern "C" int b2m_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ exclusive scan (int32)
+// 1024 items per block of 256 threads; three launches; deterministic.
+#define SCAN_ITEMS 1024
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+// returns exclusive prefix of v within the 256-thread block, *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int* total) {
+    __shared__ int wsum[4];
+    int incl = wave_incl_scan(v);
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 63) wsum[w] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int s = wsum[i]; if (i < w) off += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return off + incl - v;
+}
+__global__ void scan_reduce_kernel(const int* __restrict__ in, int64_t n, int* __restrict__ bsum) {
+    int64_t base = (int64_t)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (base + i < n) s += in[base + i];
+    int tot; block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ void scan_bsum_kernel(int* __restrict__ bsum, int64_t nb, int* __restrict__ total) {
+    int carry = 0;
+    for (int64_t b0 = 0; b0 < nb; b0 += 256) {
+        int64_t i = b0 + threadIdx.x;
+        int v = i < nb ? bsum[i] : 0;
+        int tot; int ex = block_excl_scan(v, &tot);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void scan_apply_kernel(const int* __restrict__ in, int64_t n, const int* __restrict__ bsum,
+                                  int* __restrict__ out) {
+    int64_t base = (int64_t)blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    int v[4]; int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = base + i < n ? in[base + i] : 0; s += v[i]; }
+    int tot; int ex = block_excl_scan(s, &tot) + bsum[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+}
+// out may alias in.  bsum: int32[cdiv(n,1024)+1]; the last element receives the total.
+int b2m_scan_excl(const int* in, int64_t n, int* out, int* bsum, hipStream_t st) {
+    int64_t nb = cdiv64(n, SCAN_ITEMS);
+    if (nb == 0) { return hipMemsetAsync(bsum, 0, sizeof(int), st) == hipSuccess ? 0 : B2M_ERR_HIP; }
+    scan_reduce_kernel<<<dim3((unsigned)nb), 256, 0, st>>>(in, n, bsum);
+    scan_bsum_kernel<<<1, 256, 0, st>>>(bsum, nb, bsum + nb);
+    scan_apply_kernel<<<dim3((unsigned)nb), 256, 0, st>>>(in, n, bsum, out);
+    return 0;
+}
+
+// ------------------------------------------------------------------ hash build
+__global__ void hash_insert_kernel(const int32_t* __restrict__ coords, int64_t n, uint64_t* __restrict__ keys,
+                                   int32_t* __restrict__ vals, int64_t mask, int32_t shift_mask,
+                                   int32_t* __restrict__ slot_of) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    i32x4 c = *(const i32x4*)(coords + i * 4);
+    // shift_mask = ~(2*ts-1) for strided insertion, ~0 for plain insertion
+    uint64_t key = b2m_pack(c.x, c.y & shift_mask, c.z & shift_mask, c.w & shift_mask);
+    int64_t s = (int64_t)(b2m_hash(key) & (uint64_t)mask);
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&keys[s], (unsigned long long)B2M_EMPTY_KEY,
+                                            (unsigned long long)key);
+        if (prev == B2M_EMPTY_KEY || prev == key) break;
+        s = (s + 1) & mask;
+    }
+    atomicMin(&vals[s], (int32_t)i);
+    if (slot_of) slot_of[i] = (int32_t)s;
+}
+__global__ void count_dups_kernel(const int32_t* __restrict__ coords, int64_t n, const uint64_t* __restrict__ keys,
+                                  const int32_t* __restrict__ vals, int64_t mask, int32_t* __restrict__ dup) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    i32x4 c = *(const i32x4*)(coords + i * 4);
+    int64_t s = b2m_find(keys, mask, b2m_pack(c.x, c.y, c.z, c.w));
+    if (s < 0 || vals[s] != (int32_t)i) atomicAdd(dup, 1);
+}
+
+static bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int b2m_coords_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
+                                int32_t* dup_count, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(n >= 0 && n < (1ll << 31), "n out of range");
+    B2M_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap < (1ll << 31), "cap must be a power of two >= 2n");
+    B2M_HIP(hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st));
+    B2M_HIP(hipMemsetAsync(vals, 0x7F, cap * sizeof(int32_t), st));
+    if (dup_count) B2M_HIP(hipMemsetAsync(dup_count, 0, sizeof(int32_t), st));
+    if (n == 0) return B2M_OK;
+    unsigned nb = (unsigned)cdiv64(n, 256);
+    hash_insert_kernel<<<nb, 256, 0, st>>>(coords, n, keys, vals, cap - 1, ~0, nullptr);
+    B2M_LAUNCH_CHECK();
+    if (dup_count) {
+        count_dups_kernel<<<nb, 256, 0, st>>>(coords, n, keys, vals, cap - 1, dup_count);
+        B2M_LAUNCH_CHECK();
+    }
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ strided coordinates
+__global__ void stride_flag_kernel(const int32_t* __restrict__ vals, const int32_t* __restrict__ slot_of, int64_t n,
+                                   int32_t* __restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = vals[slot_of[i]] == (int32_t)i ? 1 : 0;
+}
+// first rows write the coarse coordinate and publish their coarse row id into the table.
+// In-place update of vals is safe: a slot holds the first fine row f before and pos[f] <= f after;
+// every other row i of that slot has i > f, so neither value can equal i.
+__global__ void stride_emit_kernel(const int32_t* __restrict__ coords, int64_t n, int32_t sm,
+                                   const int32_t* __restrict__ slot_of, const int32_t* __restrict__ pos,
+                                   int32_t* vals, int32_t* __restrict__ coords_out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s = slot_of[i];
+    if (vals[s] != (int32_t)i) return;       // not the first occurrence
+    int r = pos[i];
+    i32x4 c = *(const i32x4*)(coords + i * 4);
+    i32x4 o; o.x = c.x; o.y = c.y & sm; o.z = c.z & sm; o.w = c.w & sm;
+    *(i32x4*)(coords_out + (int64_t)r * 4) = o;
+    vals[s] = r;
+}
+__global__ void stride_parent_kernel(const int32_t* __restrict__ coords, int64_t n, int32_t ts,
+                                     const int32_t* __restrict__ slot_of, const int32_t* __restrict__ newvals,
+                                     int32_t* __restrict__ parent, int32_t* __restrict__ koff) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    parent[i] = newvals[slot_of[i]];
+    i32x4 c = *(const i32x4*)(coords + i * 4);
+    int ox = (c.y & ts) ? 1 : 0, oy = (c.z & ts) ? 1 : 0, oz = (c.w & ts) ? 1 : 0;
+    koff[i] = ox + 2 * oy + 4 * oz;
+}
+extern "C" int b2m_coords_stride(const int32_t* coords, int64_t n, int32_t ts, int32_t* coords_out, int32_t* parent,
+                                 int32_t* koff, uint64_t* keys, int32_t* vals, int64_t cap, int32_t* scratch,
+                                 int64_t* n_out_host, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(n >= 0 && n < (1ll << 31), "n out of range");
+    B2M_CHECK_ARG(ts > 0 && (ts & (ts - 1)) == 0, "ts must be a power of two");
+    B2M_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap < (1ll << 31), "cap must be a power of two >= 2n");
+    B2M_CHECK_ARG(n_out_host != nullptr, "n_out_host is NULL");
+    *n_out_host = 0;
+    B2M_HIP(hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st));
+    B2M_HIP(hipMemsetAsync(vals, 0x7F, cap * sizeof(int32_t), st));
+    if (n == 0) return B2M_OK;
+    int32_t* slot_of = scratch;            // [n]
+    int32_t* pos = scratch + n;            // [n]  first-occurrence flag, then its exclusive scan in place
+    int32_t* bsum = scratch + 2 * n;       // [cdiv(n,1024)+1]
+    int64_t nbs = cdiv64(n, SCAN_ITEMS);
+    const int32_t sm = ~(2 * ts - 1);
+    unsigned nb = (unsigned)cdiv64(n, 256);
+    hash_insert_kernel<<<nb, 256, 0, st>>>(coords, n, keys, vals, cap - 1, sm, slot_of);
+    stride_flag_kernel<<<nb, 256, 0, st>>>(vals, slot_of, n, pos);
+    int rc = b2m_scan_excl(pos, n, pos, bsum, st);
+    if (rc) return rc;
+    stride_emit_kernel<<<nb, 256, 0, st>>>(coords, n, sm, slot_of, pos, vals, coords_out);
+    stride_parent_kernel<<<nb, 256, 0, st>>>(coords, n, ts, slot_of, vals, parent, koff);
+    B2M_LAUNCH_CHECK();
+    int32_t total = 0;
+    B2M_HIP(hipMemcpyAsync(&total, bsum + nbs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    B2M_HIP(hipStreamSynchronize(st));
+    *n_out_host = total;
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ stride-1 kernel map (neighbour table)
+__global__ void kernel_map_kernel(const int32_t* __restrict__ coords, int64_t n, int32_t ksize, int32_t ts,
+                                  const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, int64_t mask,
+                                  int32_t* __restrict__ nbr, int64_t ld) {
+    int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    const int K = ksize * ksize * ksize, h = ksize / 2;
+    i32x4 c = *(const i32x4*)(coords + o * 4);
+    for (int k = 0; k < K; ++k) {
+        int dx = (k % ksize - h) * ts, dy = ((k / ksize) % ksize - h) * ts, dz = (k / (ksize * ksize) - h) * ts;
+        int x = c.y + dx, y = c.z + dy, z = c.w + dz;
+        int r = -1;
+        if ((unsigned)x < 65536u && (unsigned)y < 65536u && (unsigned)z < 65536u) {
+            int64_t s = b2m_find(keys, mask, b2m_pack(c.x, x, y, z));
+            if (s >= 0) r = vals[s];
+        }
+        nbr[(int64_t)k * ld + o] = r;
+    }
+}
+extern "C" int b2m_kernel_map(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts, const uint64_t* keys,
+                              const int32_t* vals, int64_t cap, int32_t* nbr, int64_t ld, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7, "ksize must be odd (1,3,5,7)");
+    B2M_CHECK_ARG(ld >= n && is_pow2(cap), "ld < n or cap not pow2");
+    if (n == 0) return B2M_OK;
+    kernel_map_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(coords, n, ksize, ts, keys, vals, cap - 1, nbr, ld);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ k2s2 tables
+__global__ void stride_tables_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ koff, int64_t n,
+                                     int32_t* __restrict__ child, int64_t ld_c, int32_t* __restrict__ up, int64_t ld_f) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int p = parent[i], k = koff[i];
+    if (child) child[(int64_t)k * ld_c + p] = (int32_t)i;
+    if (up) up[(int64_t)k * ld_f + i] = p;
+}
+extern "C" int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int64_t n_fine, int64_t n_coarse,
+                                 int32_t* child, int64_t ld_c, int32_t* up, int64_t ld_f, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG((!child || ld_c >= n_coarse) && (!up || ld_f >= n_fine), "leading dimension too small");
+    if (child) B2M_HIP(hipMemsetAsync(child, 0xFF, 8 * ld_c * sizeof(int32_t), st));
+    if (up) B2M_HIP(hipMemsetAsync(up, 0xFF, 8 * ld_f * sizeof(int32_t), st));
+    if (n_fine == 0) return B2M_OK;
+    stride_tables_kernel<<<(unsigned)cdiv64(n_fine, 256), 256, 0, st>>>(parent, koff, n_fine, child, ld_c, up, ld_f);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ tile rulebook
+// one wave per tile of 128 output rows; per offset two ballots compact the valid pairs in row order
+__global__ __launch_bounds__(64) void rulebook_kernel(const int32_t* __restrict__ nbr, int64_t ld, int32_t K,
+                                                      int64_t n_out, int64_t ntiles, int32_t* __restrict__ rb_in,
+                                                      uint8_t* __restrict__ rb_out, int32_t* __restrict__ rb_cnt,
+                                                      int32_t* __restrict__ pair_total) {
+    const int64_t t = blockIdx.x;
+    const int lane = lane_id();
+    const int64_t ldr = ntiles * B2M_TILE;
+    const int64_t o0 = t * B2M_TILE + lane, o1 = o0 + 64;
+    for (int k = 0; k < K; ++k) {
+        int v0 = o0 < n_out ? nbr[(int64_t)k * ld + o0] : -1;
+        int v1 = o1 < n_out ? nbr[(int64_t)k * ld + o1] : -1;
+        uint64_t b0 = __ballot(v0 >= 0), b1 = __ballot(v1 >= 0);
+        int c0 = __popcll(b0), c1 = __popcll(b1);
+        int64_t base = (int64_t)k * ldr + t * B2M_TILE;
+        if (v0 >= 0) { int p = prefix_popc(b0); rb_in[base + p] = v0; rb_out[base + p] = (uint8_t)lane; }
+        if (v1 >= 0) { int p = c0 + prefix_popc(b1); rb_in[base + p] = v1; rb_out[base + p] = (uint8_t)(lane + 64); }
+        if (lane == 0) {
+            rb_cnt[(int64_t)k * ntiles + t] = c0 + c1;
+            if (pair_total && c0 + c1) atomicAdd(&pair_total[k], c0 + c1);
+        }
+    }
+}
+extern "C" int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out, int32_t* rb_in, uint8_t* rb_out,
+                            int32_t* rb_cnt, int32_t* pair_total, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(K >= 1 && K <= 343 && ld >= n_out, "bad K or ld");
+    int64_t ntiles = cdiv64(n_out, B2M_TILE);
+    if (pair_total) B2M_HIP(hipMemsetAsync(pair_total, 0, K * sizeof(int32_t), st));
+    if (ntiles == 0) return B2M_OK;
+    B2M_HIP(hipMemsetAsync(rb_in, 0xFF, (size_t)K * ntiles * B2M_TILE * sizeof(int32_t), st));
+    B2M_HIP(hipMemsetAsync(rb_out, 0, (size_t)K * ntiles * B2M_TILE, st));
+    rulebook_kernel<<<(unsigned)ntiles, 64, 0, st>>>(nbr, ld, K, n_out, ntiles, rb_in, rb_out, rb_cnt, pair_total);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}

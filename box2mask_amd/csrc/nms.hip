@@ -1,0 +1,315 @@
+// Box votes -> instance masks: non-maximum clustering, heat-map projection, mask NMS, label histogram.
+// Integer / comparison work; results must be bit-exact against models/iou_nms.py, so floating-point
+// contraction is disabled for this file and every IoU is evaluated in torch's operation order.
+#include "b2m_common.h"
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float fmax_t(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float fmin_t(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float clamp0(float x) { return x < 0.f ? 0.f : x; }
+
+// IoU of two axis-aligned boxes given as [min3,max3]; order of operations of torch_IOUs / set_IOUs
+// (/root/reference/models/iou_nms.py:4-22,26-45): prod over 3 sides as (s0*s1)*s2,
+// union = ((area_a + area_b) - inter) + 1e-6f, result = inter / union (IEEE division).
+__device__ __forceinline__ float box_iou(const float* a, const float* b) {
+    const float as0 = a[3] - a[0], as1 = a[4] - a[1], as2 = a[5] - a[2];
+    const float bs0 = b[3] - b[0], bs1 = b[4] - b[1], bs2 = b[5] - b[2];
+    const float i0 = clamp0(fmin_t(a[3], b[3]) - fmax_t(a[0], b[0]));
+    const float i1 = clamp0(fmin_t(a[4], b[4]) - fmax_t(a[1], b[1]));
+    const float i2 = clamp0(fmin_t(a[5], b[5]) - fmax_t(a[2], b[2]));
+    const float inter = (i0 * i1) * i2;
+    const float aa = (as0 * as1) * as2, ba = (bs0 * bs1) * bs2;
+    const float uni = ((aa + ba) - inter) + 0.000001f;
+    return inter / uni;
+}
+
+__global__ void set_ious_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[6], y[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) { x[u] = a[i * 6 + u]; y[u] = b[i * 6 + u]; }
+    out[i] = box_iou(x, y);
+}
+extern "C" int b2m_set_ious(const float* a, const float* b, int64_t n, float* out, void* stream) {
+    B2M_CHECK_ARG(a && b && out && n >= 0, "bad arguments");
+    if (n == 0) return B2M_OK;
+    set_ious_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, out);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ non-maximum clustering
+#define NMC_THREADS 1024
+#define NMC_LDS_SORT 4096
+#define NMC_MAX_N 262144
+
+__device__ __forceinline__ uint32_t f2ord_u(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <class P>
+__device__ __forceinline__ void bitonic_sort(P keys, int npad) {
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (npad >> 1); t += NMC_THREADS) {
+                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
+                const uint64_t a = keys[i], b = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(NMC_THREADS) void nmc_kernel(const float* __restrict__ boxes, int n, float th, int max_k,
+                                                          int32_t* __restrict__ reps, int32_t* __restrict__ assign,
+                                                          float* __restrict__ heat, int32_t* __restrict__ k_out,
+                                                          uint64_t* __restrict__ order, int npad) {
+    __shared__ uint64_t skeys[NMC_LDS_SORT];
+    __shared__ uint32_t alive[NMC_MAX_N / 32];
+    __shared__ int s_first;
+    __shared__ float s_box[6];
+    const int tid = threadIdx.x;
+    const bool in_lds = npad <= NMC_LDS_SORT;
+
+    // ---- visiting order: descending score, ties by ascending row
+    for (int j = tid; j < npad; j += NMC_THREADS) {
+        uint64_t key = ~0ull;
+        if (j < n) key = ((uint64_t)f2ord_u(-boxes[(int64_t)j * 7]) << 32) | (uint32_t)j;
+        if (in_lds) skeys[j] = key; else order[j] = key;
+    }
+    for (int w = tid; w < (n + 31) / 32; w += NMC_THREADS) {
+        const int rem = n - w * 32;
+        alive[w] = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+    }
+    if (tid == 0) s_first = 0x7FFFFFFF;
+    __syncthreads();
+    if (in_lds) {
+        bitonic_sort(skeys, npad);
+        for (int j = tid; j < npad; j += NMC_THREADS) order[j] = skeys[j];
+    } else {
+        bitonic_sort(order, npad);
+    }
+    __syncthreads();
+    auto ord = [&](int p) -> int { return (int)(uint32_t)(in_lds ? skeys[p] : order[p]); };
+    auto is_alive = [&](int j) -> bool { return (alive[j >> 5] >> (j & 31)) & 1u; };
+
+    int kc = 0, p0 = 0;
+    for (;;) {
+        // ---- next representative: first alive box in visiting order
+        int pf;
+        for (;;) {
+            const int p = p0 + tid;
+            if (p < n && is_alive(ord(p))) atomicMin(&s_first, p);
+            __syncthreads();
+            pf = s_first;
+            if (pf != 0x7FFFFFFF || p0 + NMC_THREADS >= n) break;
+            p0 += NMC_THREADS;
+        }
+        if (pf == 0x7FFFFFFF) break;
+        const int r = ord(pf);
+        if (tid < 6) s_box[tid] = boxes[(int64_t)r * 7 + 1 + tid];
+        __syncthreads();                       // s_box visible; everyone has read s_first
+        if (tid == 0) { s_first = 0x7FFFFFFF; reps[kc] = r; }
+        float rb[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) rb[u] = s_box[u];
+        for (int j = tid; j < n; j += NMC_THREADS) {
+            float bj[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) bj[u] = boxes[(int64_t)j * 7 + 1 + u];
+            float iou = box_iou(rb, bj);
+            if (j == r) iou = 1.0f;            // iou_nms.py:90
+            if (kc < max_k) heat[(int64_t)kc * n + j] = iou;
+            if (is_alive(j) && !(iou <= th)) { // iou_nms.py:97-100 (`<=` keeps the box in `remaining`)
+                assign[j] = kc;
+                atomicAnd(&alive[j >> 5], ~(1u << (j & 31)));
+            }
+        }
+        ++kc;
+        p0 = pf + 1;
+        __syncthreads();
+    }
+    if (tid == 0) *k_out = kc;
+}
+
+extern "C" int b2m_nmc(const float* boxes, int32_t n, float cluster_th, int32_t max_k, int32_t* reps, int32_t* assign,
+                       float* heat, int32_t* k_out, uint64_t* order, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(boxes && reps && assign && k_out && order && (heat || max_k == 0), "NULL argument");
+    B2M_CHECK_ARG(n >= 0 && n <= NMC_MAX_N, "n must be <= 262144");
+    B2M_CHECK_ARG(cluster_th > 0.f && cluster_th < 1.f, "cluster_th must be in (0,1)");   // iou_nms.py:71
+    if (n == 0) { B2M_HIP(hipMemsetAsync(k_out, 0, sizeof(int32_t), st)); return B2M_OK; }
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    if (npad < 2) npad = 2;
+    nmc_kernel<<<1, NMC_THREADS, 0, st>>>(boxes, n, cluster_th, max_k, reps, assign, heat, k_out, order, npad);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ heat-maps -> voxel bit masks
+__global__ __launch_bounds__(256) void mask_project_kernel(const float* __restrict__ heat, int n_fg,
+                                                           const int32_t* __restrict__ sel,
+                                                           const int32_t* __restrict__ fg_slot,
+                                                           const int64_t* __restrict__ seg2vox, int64_t n_vox, float th,
+                                                           uint64_t* __restrict__ bits, int64_t words) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = blockIdx.y;
+    if (w >= words) return;
+    const int64_t v = w * 64 + lane_id();
+    bool bit = false;
+    if (v < n_vox) {
+        const int slot = fg_slot[seg2vox[v]];
+        const float val = slot >= 0 ? heat[(int64_t)sel[r] * n_fg + slot] : 0.f;
+        bit = val > th;
+    }
+    const uint64_t m = __ballot(bit);
+    if (lane_id() == 0) bits[(int64_t)r * words + w] = m;
+}
+extern "C" int b2m_mask_project(const float* heat, int32_t n_fg, const int32_t* sel, int32_t ksel,
+                                const int32_t* fg_slot, const int64_t* seg2vox, int64_t n_vox, float mask_bin_th,
+                                uint64_t* bits, int64_t words, void* stream) {
+    B2M_CHECK_ARG(heat && sel && fg_slot && seg2vox && bits && n_fg > 0 && ksel >= 0 && words == cdiv64(n_vox, 64),
+                  "bad arguments");
+    if (ksel == 0 || n_vox == 0) return B2M_OK;
+    dim3 grid((unsigned)cdiv64(words, 4), (unsigned)ksel);
+    mask_project_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(heat, n_fg, sel, fg_slot, seg2vox, n_vox, mask_bin_th,
+                                                               bits, words);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ mask NMS
+__global__ __launch_bounds__(256) void mask_inter_kernel(const uint64_t* __restrict__ bits, int k, int64_t words,
+                                                         int32_t* __restrict__ inter) {
+    const int i = blockIdx.y, j = blockIdx.x;
+    if (j < i) return;
+    __shared__ int wsum[4];
+    int s = 0;
+    const uint64_t* a = bits + (int64_t)i * words;
+    const uint64_t* b = bits + (int64_t)j * words;
+    for (int64_t w = threadIdx.x; w < words; w += 256) s += __popcll(a[w] & b[w]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        inter[(int64_t)i * k + j] = t;
+        inter[(int64_t)j * k + i] = t;
+    }
+}
+__global__ __launch_bounds__(256) void mask_greedy_kernel(const int32_t* __restrict__ inter, int k, float th,
+                                                          int32_t* __restrict__ keep, int32_t* __restrict__ n_keep) {
+    // keep[] doubles as the alive flag: 1 = still remaining / kept, 0 = suppressed
+    for (int j = threadIdx.x; j < k; j += 256) keep[j] = 1;
+    __syncthreads();
+    int nk = 0;
+    for (int i = 0; i < k; ++i) {
+        if (keep[i]) {                                           // uniform: all threads read the same word
+            ++nk;
+            const int ci = inter[(int64_t)i * k + i];
+            for (int j = i + 1 + threadIdx.x; j < k; j += 256) {
+                if (!keep[j]) continue;
+                const int in = inter[(int64_t)i * k + j];
+                const int un = ci + inter[(int64_t)j * k + j] - in;
+                const float iou = (float)in / (float)un;         // int64 true-division -> float32 in torch
+                if (!(iou <= th)) keep[j] = 0;                   // iou_nms.py:138 keeps `ious <= th`
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_keep = nk;
+}
+extern "C" int b2m_mask_nms(const uint64_t* bits, int32_t k, int64_t words, float th, int32_t* inter, int32_t* keep,
+                            int32_t* n_keep, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(bits && inter && keep && n_keep && k >= 0 && k <= 65535 && words >= 0, "bad arguments");
+    if (k == 0) { B2M_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t), st)); return B2M_OK; }
+    mask_inter_kernel<<<dim3((unsigned)k, (unsigned)k), 256, 0, st>>>(bits, k, words, inter);
+    mask_greedy_kernel<<<1, 256, 0, st>>>(inter, k, th, keep, n_keep);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ per-instance label histogram
+__global__ __launch_bounds__(256) void label_hist_kernel(const uint64_t* __restrict__ bits, int64_t words,
+                                                         const int32_t* __restrict__ rows,
+                                                         const int32_t* __restrict__ sem, int64_t n_vox, int n_class,
+                                                         int32_t* __restrict__ labels) {
+    __shared__ int hist[256];
+    const int r = blockIdx.x;
+    const int64_t row = rows ? rows[r] : r;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t w = threadIdx.x; w < words; w += 256) {
+        uint64_t m = bits[row * words + w];
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t v = w * 64 + b;
+            if (v < n_vox) {
+                const int c = sem[v];
+                if (c >= 0 && c < n_class) atomicAdd(&hist[c], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0, bc = hist[0];
+        for (int c = 1; c < n_class; ++c) if (hist[c] > bc) { bc = hist[c]; best = c; }   // first maximum (np.argmax)
+        labels[r] = best;
+    }
+}
+extern "C" int b2m_label_hist(const uint64_t* bits, int64_t words, const int32_t* rows, int32_t k, const int32_t* sem,
+                              int64_t n_vox, int32_t n_class, int32_t* labels, void* stream) {
+    B2M_CHECK_ARG(bits && sem && labels && k >= 0 && n_class >= 1 && n_class <= 256, "bad arguments (n_class <= 256)");
+    if (k == 0) return B2M_OK;
+    label_hist_kernel<<<(unsigned)k, 256, 0, (hipStream_t)stream>>>(bits, words, rows, sem, n_vox, n_class, labels);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ bit rows -> byte masks through an index
+__global__ void mask_gather_kernel(const uint64_t* __restrict__ bits, int64_t words, const int32_t* __restrict__ rows,
+                                   const int64_t* __restrict__ index, int64_t n_pts, uint8_t* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (p >= n_pts) return;
+    const int64_t row = rows ? rows[r] : r;
+    const int64_t v = index ? index[p] : p;
+    out[(int64_t)r * n_pts + p] = (uint8_t)((bits[row * words + (v >> 6)] >> (v & 63)) & 1ull);
+}
+extern "C" int b2m_mask_gather(const uint64_t* bits, int64_t words, const int32_t* rows, int32_t k,
+                               const int64_t* index, int64_t n_pts, uint8_t* out, void* stream) {
+    B2M_CHECK_ARG(bits && out && k >= 0 && k <= 65535 && n_pts >= 0, "bad arguments");
+    if (k == 0 || n_pts == 0) return B2M_OK;
+    mask_gather_kernel<<<dim3((unsigned)cdiv64(n_pts, 256), (unsigned)k), 256, 0, (hipStream_t)stream>>>(
+        bits, words, rows, index, n_pts, out);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ bool rows -> bit rows
+__global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t* __restrict__ masks, int64_t n,
+                                                        uint64_t* __restrict__ bits, int64_t words) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = blockIdx.y;
+    if (w >= words) return;
+    const int64_t v = w * 64 + lane_id();
+    const bool bit = v < n && masks[(int64_t)r * n + v] != 0;
+    const uint64_t m = __ballot(bit);
+    if (lane_id() == 0) bits[(int64_t)r * words + w] = m;
+}
+extern "C" int b2m_mask_pack(const uint8_t* masks, int32_t k, int64_t n, uint64_t* bits, int64_t words, void* stream) {
+    B2M_CHECK_ARG(masks && bits && k >= 0 && k <= 65535 && words == cdiv64(n, 64), "bad arguments");
+    if (k == 0 || n == 0) return B2M_OK;
+    mask_pack_kernel<<<dim3((unsigned)cdiv64(words, 4), (unsigned)k), 256, 0, (hipStream_t)stream>>>(masks, n, bits, words);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}

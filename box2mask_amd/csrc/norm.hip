@@ -1,0 +1,370 @@
+// BatchNorm statistics / apply / backward, small elementwise ops and segment pooling.
+// All HBM-bound: float4 accesses, one pass per tensor, deterministic two-stage column reductions.
+#include "b2m_common.h"
+
+#define RED_MAX_BLOCKS 1024
+
+// Column reduction skeleton.  256 threads; thread -> (float4 column group cg, row slot rs).
+// F(row, cg) returns two float4 contributions (a, b); the block writes double partial sums
+// partial[blk*2c + col] (a) and partial[blk*2c + c + col] (b).
+template <class F>
+__device__ __forceinline__ void column_reduce(int64_t n, int c, double* __restrict__ partial, F f) {
+    extern __shared__ float red[];             // [nslots][c4][8]
+    const int c4 = c >> 2;
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    const int64_t rows_per_blk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > n) r1 = n;
+    f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
+    if (rs < nslots) {
+        for (int64_t r = r0 + rs; r < r1; r += nslots) {
+            f32x4 a, b;
+            f(r, cg, a, b);
+            sa += a; sb += b;
+        }
+        float* p = red + ((size_t)rs * c4 + cg) * 8;
+        *(f32x4*)p = sa; *(f32x4*)(p + 4) = sb;
+    }
+    __syncthreads();
+    if (rs == 0) {
+        double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+        for (int s = 0; s < nslots; ++s) {
+            const float* p = red + ((size_t)s * c4 + cg) * 8;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { da[u] += (double)p[u]; db[u] += (double)p[4 + u]; }
+        }
+        double* o = partial + (size_t)blockIdx.x * 2 * c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[cg * 4 + u] = da[u]; o[c + cg * 4 + u] = db[u]; }
+    }
+}
+__global__ void reduce_final_kernel(const double* __restrict__ partial, int nblk, int c2, double* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c2) return;
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * c2 + j];
+    out[j] = s;
+}
+static int reduce_blocks(int64_t n) {
+    int64_t b = (n + 511) / 512;
+    if (b < 1) b = 1;
+    if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ BN forward
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                       double* __restrict__ partial) {
+    column_reduce(n, c, partial, [&](int64_t r, int cg, f32x4& a, f32x4& b) {
+        f32x4 v = *(const f32x4*)(x + r * ldx + cg * 4);
+        a = v; b = v * v;
+    });
+}
+extern "C" int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats,
+                            void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(x && partial && stats && c > 0 && c % 4 == 0 && c <= 1024 && ldx % 4 == 0 && ldx >= c,
+                  "c and ldx must be multiples of 4, c <= 1024");
+    B2M_CHECK_ARG(((uintptr_t)x % 16) == 0, "x must be 16-byte aligned");
+    const int nblk = reduce_blocks(n);
+    const int c4 = c / 4, nslots = 256 / c4;
+    bn_stats_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(x, ldx, n, c, partial);
+    reduce_final_kernel<<<(2 * c + 255) / 256, 256, 0, st>>>(partial, nblk, 2 * c, stats);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, int c, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c) return;
+    double m, var;
+    if (stats) {
+        m = stats[j] / count;
+        var = stats[c + j] / count - m * m;
+        if (var < 0) var = 0;
+        if (running_mean) {
+            double unb = count > 1 ? var * count / (count - 1) : var;
+            running_mean[j] = (float)((1.0 - momentum) * (double)running_mean[j] + momentum * m);
+            running_var[j] = (float)((1.0 - momentum) * (double)running_var[j] + momentum * unb);
+        }
+    } else {                      // evaluation mode: running statistics
+        m = running_mean[j];
+        var = running_var[j];
+    }
+    double is = 1.0 / sqrt(var + (double)eps);
+    double g = gamma ? (double)gamma[j] : 1.0, b = beta ? (double)beta[j] : 0.0;
+    if (mean) mean[j] = (float)m;
+    if (invstd) invstd[j] = (float)is;
+    scale[j] = (float)(g * is);
+    shift[j] = (float)(b - m * g * is);
+}
+extern "C" int b2m_bn_finalize(const double* stats, double count, int32_t c, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                               float* invstd, float* scale, float* shift, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(c > 0 && scale && shift, "bad arguments");
+    B2M_CHECK_ARG(stats || (running_mean && running_var), "eval mode needs running statistics");
+    B2M_CHECK_ARG(!stats || count >= 1, "count must be >= 1");
+    bn_finalize_kernel<<<(c + 255) / 256, 256, 0, st>>>(stats, count, c, gamma, beta, eps, momentum, running_mean,
+                                                        running_var, mean, invstd, scale, shift);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int c4,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ res, int64_t ldr, int relu,
+                                                       float* __restrict__ y, int64_t ldy) {
+    const int64_t total = n * c4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c4; const int cg = (int)(e - r * c4);
+        f32x4 v = *(const f32x4*)(x + r * ldx + cg * 4);
+        const f32x4 s = *(const f32x4*)(scale + cg * 4), b = *(const f32x4*)(shift + cg * 4);
+        v = v * s + b;
+        if (res) v += *(const f32x4*)(res + r * ldr + cg * 4);
+        if (relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = v[u] > 0.f ? v[u] : 0.f;
+        }
+        *(f32x4*)(y + r * ldy + cg * 4) = v;
+    }
+}
+static unsigned ew_grid(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+extern "C" int b2m_bn_apply(const float* x, int64_t ldx, int64_t n, int32_t c, const float* scale, const float* shift,
+                            const float* residual, int64_t ldr, int32_t relu, float* y, int64_t ldy, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(x && y && scale && shift && c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
+                      (!residual || ldr % 4 == 0),
+                  "c and leading dimensions must be multiples of 4");
+    if (n == 0) return B2M_OK;
+    bn_apply_kernel<<<ew_grid(n * (c / 4)), 256, 0, st>>>(x, ldx, n, c / 4, scale, shift, residual, ldr, relu, y, ldy);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ BN backward
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ y, int64_t ldy,
+                                                            const float* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int relu,
+                                                            double* __restrict__ partial) {
+    column_reduce(n, c, partial, [&](int64_t r, int cg, f32x4& a, f32x4& b) {
+        f32x4 g = *(const f32x4*)(dy + r * lddy + cg * 4);
+        if (relu) {
+            const f32x4 yy = *(const f32x4*)(y + r * ldy + cg * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
+        }
+        const f32x4 xx = *(const f32x4*)(x + r * ldx + cg * 4);
+        const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
+        a = g; b = g * ((xx - m) * is);
+    });
+}
+extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
+                                 int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd,
+                                 int32_t relu, double* partial, double* sums, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(dy && x && mean && invstd && partial && sums && (!relu || y), "NULL argument");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && (!relu || ldy % 4 == 0),
+                  "c and leading dimensions must be multiples of 4");
+    const int nblk = reduce_blocks(n);
+    const int c4 = c / 4, nslots = 256 / c4;
+    bn_bwd_reduce_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(dy, lddy, y, ldy, x, ldx, n, c,
+                                                                                   mean, invstd, relu, partial);
+    reduce_final_kernel<<<(2 * c + 255) / 256, 256, 0, st>>>(partial, nblk, 2 * c, sums);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                           const float* __restrict__ y, int64_t ldy,
+                                                           const float* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const double* __restrict__ sums, double count, int relu,
+                                                           float* __restrict__ dx, int64_t lddx,
+                                                           float* __restrict__ dres, int64_t lddres) {
+    const int c4 = c >> 2;
+    const int64_t total = n * c4;
+    const float inv_n = (float)(1.0 / count);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c4; const int cg = (int)(e - r * c4);
+        f32x4 g = *(const f32x4*)(dy + r * lddy + cg * 4);
+        if (relu) {
+            const f32x4 yy = *(const f32x4*)(y + r * ldy + cg * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
+        }
+        const f32x4 xx = *(const f32x4*)(x + r * ldx + cg * 4);
+        const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
+        f32x4 out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xh = (xx[u] - m[u]) * is[u];
+            const float sg = (float)sums[cg * 4 + u] * inv_n, sgx = (float)sums[c + cg * 4 + u] * inv_n;
+            const float ga = gamma ? gamma[cg * 4 + u] : 1.f;
+            out[u] = ga * is[u] * (g[u] - sg - xh * sgx);
+        }
+        *(f32x4*)(dx + r * lddx + cg * 4) = out;
+        if (dres) *(f32x4*)(dres + r * lddres + cg * 4) = g;
+    }
+}
+extern "C" int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
+                                int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd,
+                                const float* gamma, const double* sums, double count, int32_t relu, float* dx,
+                                int64_t lddx, float* dres, int64_t lddres, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y), "NULL argument");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || ldy % 4 == 0) &&
+                      (!dres || lddres % 4 == 0) && count >= 1,
+                  "c and leading dimensions must be multiples of 4");
+    if (n == 0) return B2M_OK;
+    bn_bwd_apply_kernel<<<ew_grid(n * (c / 4)), 256, 0, st>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, sums,
+                                                             count, relu, dx, lddx, dres, lddres);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ elementwise
+__global__ void relu_fwd_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float v = x[e]; y[e] = v > 0.f ? v : 0.f;
+    }
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int64_t n,
+                                float* __restrict__ dx) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        dx[e] = y[e] > 0.f ? dy[e] : 0.f;
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ o) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        o[e] = a[e] + b[e];
+}
+extern "C" int b2m_relu_fwd(const float* x, int64_t n_elem, float* y, void* stream) {
+    if (n_elem == 0) return B2M_OK;
+    relu_fwd_kernel<<<ew_grid(n_elem), 256, 0, (hipStream_t)stream>>>(x, n_elem, y);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+extern "C" int b2m_relu_bwd(const float* dy, const float* y, int64_t n_elem, float* dx, void* stream) {
+    if (n_elem == 0) return B2M_OK;
+    relu_bwd_kernel<<<ew_grid(n_elem), 256, 0, (hipStream_t)stream>>>(dy, y, n_elem, dx);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+extern "C" int b2m_add(const float* a, const float* b, int64_t n_elem, float* out, void* stream) {
+    if (n_elem == 0) return B2M_OK;
+    add_kernel<<<ew_grid(n_elem), 256, 0, (hipStream_t)stream>>>(a, b, n_elem, out);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ segment pooling
+__global__ void pool_count_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t* __restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&counts[ids[i]], 1);
+}
+__global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                       const int64_t* __restrict__ ids, float* __restrict__ out) {
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c; const int col = (int)(e - r * c);
+        atomicAdd(&out[ids[r] * c + col], x[r * ldx + col]);
+    }
+}
+__global__ void pool_div_kernel(float* __restrict__ out, const int32_t* __restrict__ counts, int64_t n_seg, int c) {
+    const int64_t total = n_seg * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int cnt = counts[e / c];
+        out[e] = cnt > 0 ? out[e] / (float)cnt : 0.f;
+    }
+}
+// max: pack (order-preserving float bits, ~row) into 64 bits; atomicMax picks the largest value and,
+// among equal values, the lowest row -> deterministic argmax.
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+__global__ __launch_bounds__(256) void pool_max_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                       const int64_t* __restrict__ ids,
+                                                       unsigned long long* __restrict__ packed) {
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c; const int col = (int)(e - r * c);
+        unsigned long long p = ((unsigned long long)f2ord(x[r * ldx + col]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)r);
+        atomicMax(&packed[ids[r] * c + col], p);
+    }
+}
+__global__ void pool_max_decode_kernel(const unsigned long long* __restrict__ packed, int64_t total,
+                                       float* __restrict__ out, int32_t* __restrict__ argmax) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long p = packed[e];
+        if (p == 0ull) { out[e] = 0.f; argmax[e] = -1; }
+        else { out[e] = ord2f((uint32_t)(p >> 32)); argmax[e] = (int32_t)(0xFFFFFFFFu - (uint32_t)p); }
+    }
+}
+extern "C" int b2m_segment_pool_fwd(const float* x, int64_t ldx, int64_t n, int32_t c, const int64_t* ids,
+                                    int64_t n_seg, int32_t mode, float* out, int32_t* counts, int32_t* argmax,
+                                    uint64_t* scratch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(x && ids && out && counts && c > 0 && ldx >= c && n_seg >= 0, "bad arguments");
+    B2M_CHECK_ARG(mode == 0 || (mode == 1 && argmax && scratch), "mode 1 (max) needs argmax and scratch");
+    if (n_seg == 0) return B2M_OK;
+    B2M_HIP(hipMemsetAsync(counts, 0, n_seg * sizeof(int32_t), st));
+    if (n > 0) pool_count_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(ids, n, counts);
+    if (mode == 0) {
+        B2M_HIP(hipMemsetAsync(out, 0, (size_t)n_seg * c * sizeof(float), st));
+        if (n > 0) pool_sum_kernel<<<ew_grid(n * c), 256, 0, st>>>(x, ldx, n, c, ids, out);
+        pool_div_kernel<<<ew_grid(n_seg * c), 256, 0, st>>>(out, counts, n_seg, c);
+    } else {
+        B2M_HIP(hipMemsetAsync(scratch, 0, (size_t)n_seg * c * sizeof(uint64_t), st));
+        if (n > 0) pool_max_kernel<<<ew_grid(n * c), 256, 0, st>>>(x, ldx, n, c, ids, (unsigned long long*)scratch);
+        pool_max_decode_kernel<<<ew_grid(n_seg * c), 256, 0, st>>>((const unsigned long long*)scratch, n_seg * c, out,
+                                                                   argmax);
+    }
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, int64_t n, int c,
+                                                       const int64_t* __restrict__ ids, int mode,
+                                                       const int32_t* __restrict__ counts,
+                                                       const int32_t* __restrict__ argmax, float* __restrict__ dx,
+                                                       int64_t lddx) {
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c; const int col = (int)(e - r * c);
+        const int64_t s = ids[r];
+        float g = dout[s * c + col];
+        if (mode == 0) g = g / (float)counts[s];
+        else g = argmax[s * c + col] == (int32_t)r ? g : 0.f;
+        dx[r * lddx + col] = g;
+    }
+}
+extern "C" int b2m_segment_pool_bwd(const float* dout, int64_t n, int32_t c, const int64_t* ids, int64_t n_seg,
+                                    int32_t mode, const int32_t* counts, const int32_t* argmax, float* dx,
+                                    int64_t lddx, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(dout && ids && dx && c > 0 && lddx >= c, "bad arguments");
+    B2M_CHECK_ARG((mode == 0 && counts) || (mode == 1 && argmax), "mode 0 needs counts, mode 1 needs argmax");
+    if (n == 0) return B2M_OK;
+    pool_bwd_kernel<<<ew_grid(n * c), 256, 0, st>>>(dout, n, c, ids, mode, counts, argmax, dx, lddx);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}

@@ -1,0 +1,286 @@
+"""SelectionNet: the 8-level sparse residual U-Net, segment pooling, MLP heads and the
+votes -> instance-mask post-processing, with the class surface and parameter names of
+/root/reference/models/detection_net.py (network_initialization 34-230, forward 234-364,
+detection2mask 369-488, get_prediction 493-521).  All sparse arithmetic runs in the HIP library.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from . import iou_nms
+from . import nn as ME
+from .resnet import BasicBlock, ResNetBase
+from .util import to_bbs_min_max
+
+_call = _lib.call
+
+
+class SelectionNet(ResNetBase):
+    BLOCK = BasicBlock
+    DILATIONS = (1, 1, 1, 1, 1, 1, 1, 1)
+    PLANES = (32, 64, 128, 256, 256, 128, 96, 96)
+    added_PLANES = (256, 256, 256, 256, 256, 256)
+    INIT_DIM = 32
+    OUT_TENSOR_STRIDE = 1
+
+    def __init__(self, cfg, device, semantic_valid_class_ids, is_foreground, out_channels=[96, 96, 3], D=3,
+                 mlp_head=False):
+        self.device = device
+        self.cfg = cfg
+        self.mlp_head = mlp_head
+        self.LAYERS = (cfg.layers,) * 8
+        self.added_LAYERS = (cfg.layers,) * 6
+        self.semantic_valid_class_ids = semantic_valid_class_ids
+        self.is_foreground = is_foreground
+        ResNetBase.__init__(self, cfg.in_channels, out_channels, D)
+
+    def network_initialization(self, in_channels, out_channels=[96, 96, 3], D=None, mlp_head=False):
+        P, A = self.PLANES, self.added_PLANES
+        self.inplanes = self.INIT_DIM
+        self.conv0p1s1 = ME.MinkowskiConvolution(in_channels, self.inplanes, kernel_size=5, dimension=D)
+        self.bn0 = ME.MinkowskiBatchNorm(self.inplanes)
+
+        def down(name_conv, name_bn, name_block, planes, layers):
+            setattr(self, name_conv, ME.MinkowskiConvolution(self.inplanes, self.inplanes, kernel_size=2, stride=2,
+                                                             dimension=D))
+            setattr(self, name_bn, ME.MinkowskiBatchNorm(self.inplanes))
+            setattr(self, name_block, self._make_layer(self.BLOCK, planes, layers))
+
+        down('conv1p1s2', 'bn1', 'block1', P[0], self.LAYERS[0])
+        down('conv2p2s2', 'bn2', 'block2', P[1], self.LAYERS[1])
+        down('conv3p4s2', 'bn3', 'block3', P[2], self.LAYERS[2])
+        down('conv4p8s2', 'bn4', 'block4', P[3], self.LAYERS[3])
+        down('added_conv1p16s2', 'added_bn1', 'added_block1', A[0], self.added_LAYERS[0])
+        down('added_conv2p32s2', 'added_bn2', 'added_block2', A[1], self.added_LAYERS[1])
+        down('added_conv3p64s2', 'added_bn3', 'added_block3', A[2], self.added_LAYERS[2])
+
+        def up(name_conv, name_bn, name_block, planes, skip_planes, layers):
+            setattr(self, name_conv, ME.MinkowskiConvolutionTranspose(self.inplanes, planes, kernel_size=2, stride=2,
+                                                                      dimension=D))
+            setattr(self, name_bn, ME.MinkowskiBatchNorm(planes))
+            self.inplanes = planes + skip_planes
+            setattr(self, name_block, self._make_layer(self.BLOCK, planes, layers))
+
+        E = self.BLOCK.expansion
+        up('added_convtr4p128s2', 'added_bntr4', 'added_block4', A[3], A[1] * E, self.added_LAYERS[3])
+        up('added_convtr5p64s2', 'added_bntr5', 'added_block5', A[4], A[0] * E, self.added_LAYERS[4])
+        up('added_convtr6p32s2', 'added_bntr6', 'added_block6', A[5], P[3] * E, self.added_LAYERS[5])
+        up('convtr4p16s2', 'bntr4', 'block5', P[4], P[2] * E, self.LAYERS[4])
+        up('convtr5p8s2', 'bntr5', 'block6', P[5], P[1] * E, self.LAYERS[5])
+        up('convtr6p4s2', 'bntr6', 'block7', P[6], P[0] * E, self.LAYERS[6])
+        up('convtr7p2s2', 'bntr7', 'block8', P[7], self.INIT_DIM, self.LAYERS[7])
+
+        if self.cfg.load_unused_head:           # detection_net.py:142-164 (old checkpoints only)
+            self.final0 = ME.MinkowskiConvolution(P[7] * E, out_channels[0], kernel_size=1, bias=True, dimension=D)
+            self.final0_bn = ME.MinkowskiBatchNorm(out_channels[0])
+            self.final1 = ME.MinkowskiConvolution(out_channels[0], out_channels[1], kernel_size=1, bias=True,
+                                                  dimension=D)
+            self.final1_bn = ME.MinkowskiBatchNorm(out_channels[1])
+            self.final2 = ME.MinkowskiConvolution(out_channels[1], out_channels[2], kernel_size=1, bias=True,
+                                                  dimension=D)
+        self.relu = ME.MinkowskiReLU()
+
+        def mlp_head(output_dim):               # detection_net.py:170-194: conv1x1-ReLU-BN x2, conv1x1
+            return nn.Sequential(
+                ME.MinkowskiConvolution(P[7] * E, out_channels[0], kernel_size=1, bias=True, dimension=D),
+                ME.MinkowskiReLU(),
+                ME.MinkowskiBatchNorm(out_channels[0]),
+                ME.MinkowskiConvolution(out_channels[0], out_channels[1], kernel_size=1, bias=True, dimension=D),
+                ME.MinkowskiReLU(),
+                ME.MinkowskiBatchNorm(out_channels[1]),
+                ME.MinkowskiConvolution(out_channels[1], output_dim, kernel_size=1, bias=True, dimension=D))
+
+        cfg = self.cfg
+        self.network_heads = {}
+        self.requires_voxel_outputs = False
+        for network_head in cfg.network_heads:
+            if network_head == cfg.mlp_offsets:
+                self.mlp_offsets = mlp_head(3)
+                self.network_heads[network_head] = self.mlp_offsets
+            if network_head == cfg.mlp_bounds:
+                self.mlp_bounds = mlp_head(3)
+                self.network_heads[network_head] = self.mlp_bounds
+            if network_head == cfg.mlp_bb_scores:
+                self.mlp_score = mlp_head(1)    # the reference builds it twice (208-209); only RNG-stream parity
+                self.mlp_score = mlp_head(1)
+                self.network_heads[network_head] = self.mlp_score
+            if network_head == cfg.mlp_center_scores:
+                self.mlp_center_score = mlp_head(1)
+                self.network_heads[network_head] = self.mlp_center_score
+            if network_head == cfg.mlp_semantics:
+                self.mlp_semantics = mlp_head(len(self.semantic_valid_class_ids))
+                self.network_heads[network_head] = self.mlp_semantics
+            if network_head == cfg.mlp_per_vox_semantics:
+                self.mlp_per_vox_semantics = mlp_head(len(self.semantic_valid_class_ids))
+                self.network_heads[network_head] = self.mlp_per_vox_semantics
+                self.requires_voxel_outputs = True
+
+    # conv -> BN -> ReLU with the BN+ReLU epilogue fused into one launch
+    @staticmethod
+    def _cbr(conv, bn, x):
+        out = conv(x)
+        return out.new(bn.apply_bn(out.F, relu=True))
+
+    def forward(self, x, pooling_ids=None, n_segments=None):
+        """x: SparseTensor at tensor stride 1 -> dict head-name -> tensor holder with `.F`
+        (detection_net.py:234-364)."""
+        cbr = self._cbr
+        out_p1 = cbr(self.conv0p1s1, self.bn0, x)
+        out_b1p2 = self.block1(cbr(self.conv1p1s2, self.bn1, out_p1))
+        out_b2p4 = self.block2(cbr(self.conv2p2s2, self.bn2, out_b1p2))
+        out_b3p8 = self.block3(cbr(self.conv3p4s2, self.bn3, out_b2p4))
+        out_b4p16 = self.block4(cbr(self.conv4p8s2, self.bn4, out_b3p8))
+        out_added_b1p32 = self.added_block1(cbr(self.added_conv1p16s2, self.added_bn1, out_b4p16))
+        out_added_b2p64 = self.added_block2(cbr(self.added_conv2p32s2, self.added_bn2, out_added_b1p32))
+        out = self.added_block3(cbr(self.added_conv3p64s2, self.added_bn3, out_added_b2p64))
+
+        out = self.added_block4(ME.cat(cbr(self.added_convtr4p128s2, self.added_bntr4, out), out_added_b2p64))
+        out = self.added_block5(ME.cat(cbr(self.added_convtr5p64s2, self.added_bntr5, out), out_added_b1p32))
+        out = self.added_block6(ME.cat(cbr(self.added_convtr6p32s2, self.added_bntr6, out), out_b4p16))
+        out = self.block5(ME.cat(cbr(self.convtr4p16s2, self.bntr4, out), out_b3p8))
+        out = self.block6(ME.cat(cbr(self.convtr5p8s2, self.bntr5, out), out_b2p4))
+        out = self.block7(ME.cat(cbr(self.convtr6p4s2, self.bntr6, out), out_b1p2))
+        out = self.block8(ME.cat(cbr(self.convtr7p2s2, self.bntr7, out), out_p1))
+
+        outputs = {}
+        if self.requires_voxel_outputs:
+            outputs['vox_feats'] = out
+        if self.cfg.do_segment_pooling:
+            assert pooling_ids is not None
+            mode = 'max' if self.cfg.max_pool_segments_detection_net else 'avg'
+            if n_segments is None:
+                n_segments = int(pooling_ids.max().item()) + 1
+            from . import functional as F_
+            out = ME.PooledTensor(F_.segment_pool(out.F, pooling_ids, n_segments, mode))
+        for network_head in self.cfg.network_heads:
+            if self.requires_voxel_outputs and 'per_vox' in network_head:
+                outputs[network_head] = self.network_heads[network_head](outputs['vox_feats'])
+            else:
+                outputs[network_head] = self.network_heads[network_head](out)
+            if self.cfg.mlp_bounds_relu and network_head == self.cfg.mlp_bounds:
+                outputs[network_head] = self.relu(outputs[network_head])
+        return outputs
+
+    # ------------------------------------------------------------------ votes -> instance masks
+    def detection2mask(self, batch, pred, cfg, mode, score_filtering=True, cluster_th=0.3, score_th=0.3,
+                       mask_bin_th=0.3, mask_nms_th=0.3):
+        """Predictions -> {scene name: {'conf','label_id','mask'}} (detection_net.py:369-488).
+        Box construction and the sigmoid run with torch on the device `pred` lives on (CPU in the
+        reference's evaluation flow); clustering, mask projection, mask NMS, the label histogram and
+        the voxel->point projection are HIP kernels; only scalars and the final results cross PCIe."""
+        _lib.require_gpu()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        pdev = pred[cfg.mlp_offsets].device
+        pred_bbs = to_bbs_min_max(batch['input_location'].to(pdev), pred[cfg.mlp_offsets], pred[cfg.mlp_bounds],
+                                  torch.nn.Sigmoid()(pred[cfg.mlp_bb_scores]))
+        if cfg.mlp_per_vox_semantics in cfg.network_heads:
+            pred_semantics = torch.argmax(pred[cfg.mlp_per_vox_semantics], 1)
+        else:
+            pred_semantics = torch.argmax(pred[cfg.mlp_semantics], 1)
+            pred_semantics = self.semantic_valid_class_ids.to(pdev)[pred_semantics].long()
+        n_class = int(max(int(self.semantic_valid_class_ids.max()) + 1, 1))
+        batch_ids = batch['batch_ids'].to(pdev)
+        results = {}
+        vox_start = 0
+        for scene_idx, scene in enumerate(batch['scene']):
+            scene_mask = batch_ids == scene_idx
+            seg2vox = torch.as_tensor(batch['seg2vox'][scene_idx]).long()
+            n_vox = seg2vox.shape[0]
+            if not self.requires_voxel_outputs:
+                scene_pred_semantics = pred_semantics[scene_mask]
+                scene_pred_fg = self.is_foreground(scene_pred_semantics)
+                sem_vox = scene_pred_semantics.to(dev)[seg2vox.to(dev)]
+            else:
+                # S3DIS flow (detection_net.py:398-415): per-voxel semantics, majority vote per segment
+                sem_vox_all = pred_semantics[vox_start:vox_start + n_vox] if pred_semantics.shape[0] != n_vox \
+                    else pred_semantics
+                sem_vox = sem_vox_all.to(dev)
+                s2v = seg2vox.to(dev)
+                n_seg = int(s2v.max()) + 1
+                votes = torch.bincount(s2v * n_class + sem_vox, minlength=n_seg * n_class).reshape(n_seg, n_class)
+                scene_pred_fg = self.is_foreground(torch.argmax(votes, 1)).to(pdev)
+            vox_start += n_vox
+            scene_pred_bbs = pred_bbs[scene_mask][scene_pred_fg]
+            boxes = scene_pred_bbs.detach().to(dev, torch.float32).contiguous()
+            n_fg = boxes.shape[0]
+
+            # ---------- instance clusters (iou_nms.py:68-105)
+            r = iou_nms.nmc_device(boxes, cluster_th)
+            reps = r.reps[:r.k].long()
+            scores = boxes[reps, 0]
+            # ---------- score filter (detection_net.py:427-432)
+            sel = torch.nonzero(scores > score_th).reshape(-1) if score_filtering else torch.arange(r.k, device=dev)
+            ksel = sel.shape[0]
+            # ---------- heat-maps -> voxel masks (436-446): zero-padded background, seg2vox projection
+            fg_dev = scene_pred_fg.to(dev)
+            fg_slot = torch.where(fg_dev, torch.cumsum(fg_dev.int(), 0) - 1, torch.full_like(fg_dev.int(), -1)).int()
+            s2v = seg2vox.to(dev)
+            words = (n_vox + 63) // 64
+            bits = torch.empty((max(ksel, 1), max(words, 1)), dtype=torch.int64, device=dev)
+            sel32 = sel.int().contiguous()
+            _call('b2m_mask_project', r.heat.data_ptr(), n_fg, sel32.data_ptr(), ksel, fg_slot.data_ptr(),
+                  s2v.data_ptr(), n_vox, float(mask_bin_th), bits.data_ptr(), words)
+            # ---------- duplicate removal (448): mask NMS, skipped for per-voxel predictions (449-451)
+            if not self.requires_voxel_outputs and ksel > 0:
+                keep, _ = iou_nms.mask_nms_device(bits, ksel, words, mask_nms_th)
+                kept = torch.nonzero(keep).reshape(-1)
+            else:
+                kept = torch.arange(ksel, device=dev)
+            kk = kept.shape[0]
+            kept32 = kept.int().contiguous()
+            # ---------- label per instance: argmax of the label histogram inside the mask (461-466)
+            labels = torch.zeros(max(kk, 1), dtype=torch.int32, device=dev)
+            sem32 = sem_vox.int().contiguous()
+            _call('b2m_label_hist', bits.data_ptr(), words, kept32.data_ptr(), kk, sem32.data_ptr(), n_vox, n_class,
+                  labels.data_ptr())
+            instance_labels = labels[:kk].cpu().numpy().astype('int32')
+            final_rows = sel[kept]                       # cluster row of every surviving instance
+            bb_scores = scene_pred_bbs[reps[final_rows].to(pdev), 0]
+            if mode == 'eval':
+                v2p = torch.as_tensor(batch['vox2point'][scene_idx]).long().to(dev)
+                n_pts = v2p.shape[0]
+                out = torch.empty((kk, n_pts), dtype=torch.uint8, device=dev)
+                _call('b2m_mask_gather', bits.data_ptr(), words, kept32.data_ptr(), kk, v2p.data_ptr(), n_pts,
+                      out.data_ptr())
+                results[scene['name']] = {'conf': bb_scores, 'label_id': instance_labels,
+                                          'mask': out.bool().to(pdev)}
+            else:
+                out = torch.empty((kk, n_vox), dtype=torch.uint8, device=dev)
+                _call('b2m_mask_gather', bits.data_ptr(), words, kept32.data_ptr(), kk, None, n_vox, out.data_ptr())
+                heat_w_bg = torch.zeros((kk, fg_dev.shape[0]), device=dev)
+                heat_w_bg[:, fg_dev] = r.heat[final_rows]
+                results[scene['name']] = {
+                    'conf': bb_scores, 'label_id': instance_labels, 'mask': out.bool().to(pdev),
+                    'cluster_representatives': reps[final_rows].to(pdev),
+                    'cluster_heatmaps': heat_w_bg[:, s2v].to(pdev),
+                    'bbs': scene_pred_bbs[reps[final_rows].to(pdev)],
+                    'pred_fg': scene_pred_fg,
+                }
+        return results
+
+    # ------------------------------------------------------------------ prediction
+    def get_prediction(self, batch, with_grad=True, to_cpu=False, to_numpy=False, min_size=True):
+        """detection_net.py:493-517."""
+        n_seg = batch['input_location'].shape[0] if self.cfg.do_segment_pooling else None
+        if not with_grad:
+            with torch.no_grad():
+                sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=self.device)
+                pred = self(sin, batch['pooling_ids'].to(self.device), n_seg)
+        else:
+            sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=self.device)
+            pred = self(sin, batch['pooling_ids'].to(self.device), n_seg)
+        for mlp_head, sparse_tensor in pred.items():
+            pred[mlp_head] = sparse_tensor.F if not to_cpu else sparse_tensor.F.cpu()
+        if min_size:
+            self.to_min_size(pred)
+        if to_numpy:
+            for mlp_head, tensor in pred.items():
+                pred[mlp_head] = tensor.numpy()
+        return pred
+
+    def to_min_size(self, pred):
+        if self.cfg.mlp_bounds in pred.keys() and self.cfg.min_bb_size is not None:
+            pred[self.cfg.mlp_bounds] = torch.clamp(pred[self.cfg.mlp_bounds], min=self.cfg.min_bb_size)

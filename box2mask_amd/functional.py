@@ -1,0 +1,268 @@
+"""Autograd operators over the HIP C ABI (include/b2m.h).
+
+torch is used for device memory, streams and the autograd graph only; every forward/backward body
+is one or more b2m_* launches on the current stream.  The semantics of each operator are those of
+the MinkowskiEngine operator the reference calls (file:line cited per function).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .sparse import Rulebook
+
+_call = _lib.call
+_ptr = _lib.ptr
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def conv_raw(x1, x2, w3, bias, rb: Rulebook | None, n_out: int, cout: int, w_col0: int = 0, out=None,
+             accumulate=False):
+    """Y = sum_k [x1|x2][in_k] @ w3[k][:, w_col0:w_col0+cout]  (w3: (K, Cin, ldw) contiguous)."""
+    K, cin, ldw = w3.shape
+    c1 = x1.shape[1]
+    c2 = x2.shape[1] if x2 is not None else 0
+    assert c1 + c2 == cin, (c1, c2, cin)
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=x1.device)
+    if rb is None:
+        assert K == 1
+        rbi = rbo = rbc = None
+    else:
+        assert rb.K == K and rb.n_out == n_out
+        rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
+    _call('b2m_conv_fwd', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
+          w3.data_ptr() + 4 * w_col0, ldw, K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
+          1 if accumulate else 0)
+    return out
+
+
+def weight_transpose(w3, mirror: bool):
+    """(K,Cin,Cout) -> (K,Cout,Cin) with optional offset mirroring (data-gradient weights)."""
+    K, cin, cout = w3.shape
+    wt = torch.empty((K, cout, cin), dtype=torch.float32, device=w3.device)
+    _call('b2m_weight_transpose', w3.data_ptr(), cout, K, cin, cout, wt.data_ptr(), cin, 1 if mirror else 0)
+    return wt
+
+
+def wgrad_raw(x, dy, rb: Rulebook | None, K: int, dw3, ci0: int):
+    """dw3[:, ci0:ci0+x.shape[1], :] += sum_pairs x[in]^T dy[out]."""
+    cin_total, cout = dw3.shape[1], dw3.shape[2]
+    n_out = dy.shape[0]
+    if rb is None:
+        rbi = rbo = rbc = None
+    else:
+        rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
+    _call('b2m_conv_wgrad', x.data_ptr(), x.stride(0), x.shape[1], dy.data_ptr(), dy.stride(0), cout, rbi, rbo, rbc,
+          n_out, K, dw3.data_ptr() + 4 * ci0 * cout, cout, cin_total * cout)
+
+
+class _SparseConv(torch.autograd.Function):
+    """Sparse convolution Y[o] = sum_k X[in_k(o)] W[k] (+bias).  [ME-mem] MinkowskiConvolution /
+    MinkowskiConvolutionTranspose forward+backward (/root/reference/models/resnet.py:61-65,
+    detection_net.py:37-135).  `rb_f` maps input rows to output rows; `rb_b` is the reverse map used
+    for the data gradient (same rulebook for stride-1 kernels, whose offsets mirror)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, rb_f, rb_b, mirror, n_out):
+        x1 = _f32c(x1)
+        x2 = _f32c(x2) if x2 is not None else None
+        w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        w3 = _f32c(w3)
+        y = conv_raw(x1, x2, w3, bias, rb_f, n_out, w3.shape[2])
+        ctx.save_for_backward(x1, x2, weight, bias)
+        ctx.rb_f, ctx.rb_b, ctx.mirror = rb_f, rb_b, mirror
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, weight, bias = ctx.saved_tensors
+        dy = _f32c(dy)
+        w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        w3 = _f32c(w3)
+        K, cin, cout = w3.shape
+        dx1 = dx2 = dw = db = None
+        need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
+        if need1 or need2:
+            wt = weight_transpose(w3, ctx.mirror)          # (K, cout, cin)
+            c1 = x1.shape[1]
+            if need1:
+                dx1 = conv_raw(dy, None, wt, None, ctx.rb_b, x1.shape[0], c1, w_col0=0)
+            if need2:
+                dx2 = conv_raw(dy, None, wt, None, ctx.rb_b, x2.shape[0], x2.shape[1], w_col0=c1)
+        if ctx.needs_input_grad[2]:
+            dw3 = torch.zeros_like(w3)
+            wgrad_raw(x1, dy, ctx.rb_f, K, dw3, 0)
+            if x2 is not None:
+                wgrad_raw(x2, dy, ctx.rb_f, K, dw3, x1.shape[1])
+            dw = dw3 if weight.dim() == 3 else dw3[0]
+        if bias is not None and ctx.needs_input_grad[3]:
+            db = dy.sum(0, keepdim=True).reshape(bias.shape)
+        return dx1, dx2, dw, db, None, None, None, None
+
+
+def sparse_conv(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out):
+    return _SparseConv.apply(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out)
+
+
+# ----------------------------------------------------------------------------- batch norm
+_RED_BLOCKS = 1024
+
+
+def _sync_group():
+    return dist.group.WORLD if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+def merge_bn_sums(local_sums: torch.Tensor, local_count: float, group=None):
+    """SyncBN statistics exchange: all-reduce (sum x, sum x^2, count) over the data-parallel group.
+    Device-agnostic (used by the world_size-2 gloo tests).  Replaces the per-layer collectives of
+    torch.nn.SyncBatchNorm that ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm installs
+    (/root/reference/models/model.py:25)."""
+    if group is None:
+        return local_sums, float(local_count)
+    packed = torch.cat([local_sums, local_sums.new_tensor([float(local_count)])])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed[:-1], float(packed[-1].item())
+
+
+class _BatchNorm(torch.autograd.Function):
+    """y = BN(x) (+residual) (ReLU).  BatchNorm1d over all rows of the batch
+    (/root/reference/models/resnet.py:63,66,73-82); residual add + ReLU fused as the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync):
+        x = _f32c(x)
+        n, c = x.shape
+        dev = x.device
+        scale = torch.empty(c, dtype=torch.float32, device=dev)
+        shift = torch.empty(c, dtype=torch.float32, device=dev)
+        mean = invstd = None
+        count = float(n)
+        if training:
+            partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
+            stats = torch.empty(2 * c, dtype=torch.float64, device=dev)
+            _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), stats.data_ptr())
+            group = _sync_group() if sync else None
+            if group is not None:
+                stats, count = merge_bn_sums(stats, count, group)
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            invstd = torch.empty(c, dtype=torch.float32, device=dev)
+            _call('b2m_bn_finalize', stats.data_ptr(), count, c, _ptr(gamma), _ptr(beta), eps, momentum,
+                  _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                  shift.data_ptr())
+        else:
+            _call('b2m_bn_finalize', None, 1.0, c, _ptr(gamma), _ptr(beta), eps, momentum, running_mean.data_ptr(),
+                  running_var.data_ptr(), None, None, scale.data_ptr(), shift.data_ptr())
+        if residual is not None:
+            residual = _f32c(residual)
+        y = torch.empty_like(x)
+        _call('b2m_bn_apply', x.data_ptr(), x.stride(0), n, c, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
+              residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
+        ctx.training, ctx.relu, ctx.count, ctx.sync = training, relu, count, sync
+        ctx.has_res = residual is not None
+        if training:
+            ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        else:
+            ctx.save_for_backward(x, y if relu else None, gamma, scale, None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, c = x.shape
+        dev = x.device
+        relu = 1 if ctx.relu else 0
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[8]) else None
+        if not ctx.training:
+            # eval-mode BN is an affine map: dx = scale * g (mean holds `scale` here)
+            g = dy if not relu else dy * (y > 0)
+            dx = g * mean.reshape(1, -1)
+            return dx, None, None, None, None, None, None, None, (g if dres is not None else None), None, None
+        partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+        _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
+              x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, partial.data_ptr(),
+              sums.data_ptr())
+        dbeta = sums[:c].float()
+        dgamma = sums[c:].float()
+        gsums, count = sums, ctx.count
+        group = _sync_group() if ctx.sync else None
+        if group is not None:
+            gsums = sums.clone()
+            dist.all_reduce(gsums, op=dist.ReduceOp.SUM, group=group)
+        _call('b2m_bn_bwd_apply', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
+              x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), gsums.data_ptr(),
+              count, relu, dx.data_ptr(), dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0)
+        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                None, None, None, None, None, dres, None, None)
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None,
+               relu=False, sync=False):
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync)
+
+
+class _ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        _call('b2m_relu_fwd', x.data_ptr(), x.numel(), y.data_ptr())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        _call('b2m_relu_bwd', dy.data_ptr(), y.data_ptr(), y.numel(), dx.data_ptr())
+        return dx
+
+
+def relu(x):
+    return _ReLU.apply(x)
+
+
+class _SegmentPool(torch.autograd.Function):
+    """Segment pooling: out[s] = mean/max of rows with ids == s
+    (/root/reference/models/detection_net.py:345-352)."""
+
+    @staticmethod
+    def forward(ctx, x, ids, n_seg, mode):
+        x = _f32c(x)
+        n, c = x.shape
+        dev = x.device
+        ids = ids.to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty((n_seg, c), dtype=torch.float32, device=dev)
+        counts = torch.empty(max(n_seg, 1), dtype=torch.int32, device=dev)
+        argmax = scratch = None
+        if mode == 1:
+            argmax = torch.empty(max(n_seg * c, 1), dtype=torch.int32, device=dev)
+            scratch = torch.empty(max(n_seg * c, 1), dtype=torch.int64, device=dev)
+        _call('b2m_segment_pool_fwd', x.data_ptr(), x.stride(0), n, c, ids.data_ptr(), n_seg, mode, out.data_ptr(),
+              counts.data_ptr(), _ptr(argmax), _ptr(scratch))
+        ctx.save_for_backward(ids, counts, argmax)
+        ctx.n, ctx.c, ctx.n_seg, ctx.mode = n, c, n_seg, mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, counts, argmax = ctx.saved_tensors
+        dout = _f32c(dout)
+        dx = torch.empty((ctx.n, ctx.c), dtype=torch.float32, device=dout.device)
+        _call('b2m_segment_pool_bwd', dout.data_ptr(), ctx.n, ctx.c, ids.data_ptr(), ctx.n_seg, ctx.mode,
+              counts.data_ptr(), _ptr(argmax), dx.data_ptr(), dx.stride(0))
+        return dx, None, None, None
+
+
+def segment_pool(x, ids, n_seg, mode='avg'):
+    return _SegmentPool.apply(x, ids, n_seg, 0 if mode == 'avg' else 1)

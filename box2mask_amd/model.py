@@ -1,0 +1,234 @@
+"""Model wrapper: the drop-in boundary.  Same constructor, methods, loss-dict keys and
+state-dict layout as /root/reference/models/model.py:14-288, so models/training.py and
+models/evaluation.py can drive it unchanged.  Losses are the reference formulas evaluated with torch
+on the GPU; the forward/backward of the network goes through the HIP library.
+"""
+from __future__ import annotations
+
+import os
+from glob import glob
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import iou_nms
+from . import nn as ME
+from .detection_net import SelectionNet
+from .iou_nms import semIOU
+from .util import convertSecs, to_bbs_min_max_
+
+
+def _pearsonr(a: torch.Tensor, b: torch.Tensor):
+    """Pearson correlation on the device (scipy.stats.pearsonr at model.py:170,191 is logging only;
+    computing it here removes two blocking D2H copies per step).  Returns a 0-dim tensor (`.item()` works)."""
+    a = a.double() - a.double().mean()
+    b = b.double() - b.double().mean()
+    return (a * b).sum() / torch.sqrt((a * a).sum() * (b * b).sum()).clamp_min(1e-300)
+
+
+class Model:
+    def __init__(self, cfg, semantic_valid_class_ids, semantic_id2idx, instance_id2idx, is_foreground, device='cuda'):
+        _lib.require_gpu()                       # fails loudly without the HIP extension / a GPU
+        self.cfg = cfg
+        self.device = device
+        self.semantic_valid_class_ids = semantic_valid_class_ids
+        self.semantic_id2idx = semantic_id2idx
+        self.instance_id2idx = instance_id2idx
+        self.is_foreground = is_foreground
+        self.detection_model = SelectionNet(cfg, device, semantic_valid_class_ids, is_foreground,
+                                            out_channels=[96, 96, 6]).to(device)
+        self._dp = None
+        if cfg.multigpu:
+            # model.py:24-25: DDP + SyncBN.  Here: packed SyncBN statistics and a flat-bucket RCCL
+            # gradient all-reduce (box2mask_amd/parallel.py) instead of torch DDP's hook machinery.
+            from .parallel import GradAllReduce
+            ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(self.detection_model)
+            self._dp = GradAllReduce(list(self.detection_model.parameters()))
+            self._dp.broadcast_parameters()
+        self.BCEWithLogitsLoss = torch.nn.BCEWithLogitsLoss().to(device)
+        self.semantics_loss = torch.nn.CrossEntropyLoss(ignore_index=-100).to(device)
+        self._id2idx_dev = None
+
+    def compute_loss(self, batch, epoch):
+        losses_dict, pred = self.compute_loss_detection(batch, epoch)
+        return losses_dict
+
+    def _sem_lut(self):
+        if self._id2idx_dev is None:
+            self._id2idx_dev = self.semantic_id2idx.to(self.device)
+        return self._id2idx_dev
+
+    def compute_loss_detection(self, batch, epoch):
+        """model.py:38-225: same loss terms, keys and weights."""
+        device = self.device
+        cfg = self.cfg
+        sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=device)
+        n_seg = batch['input_location'].shape[0] if cfg.do_segment_pooling else None
+        pred = self.detection_model(sin, batch['pooling_ids'].to(device), n_seg)
+        for mlp_head, sparse_tensor in pred.items():
+            pred[mlp_head] = sparse_tensor.F
+        losses_dict = {'optimization_loss': 0}
+        fg = batch['fg_instances'].to(device) if 'fg_instances' in batch else None
+        on_fg = cfg.loss_on_fg_instances or cfg.bb_supervision
+
+        if cfg.mlp_offsets in cfg.network_heads:                     # model.py:62-73
+            gt_offsets, pred_offsets = batch['gt_bb_offsets'].to(device), pred[cfg.mlp_offsets]
+            if on_fg:
+                pred_offsets, gt_offsets = pred_offsets[fg], gt_offsets[fg]
+            offset_loss_per_pred = torch.sum(torch.abs(pred_offsets - gt_offsets), axis=1)
+            offset_loss = torch.mean(offset_loss_per_pred)
+            losses_dict['optimization_loss'] += cfg.loss_weight_bb_offsets * offset_loss
+            losses_dict['offset_loss'] = offset_loss.detach()
+
+        if cfg.mlp_bounds in cfg.network_heads:                      # model.py:76-88
+            gt_bounds, pred_bounds = batch['gt_bb_bounds'].to(device), pred[cfg.mlp_bounds]
+            if on_fg:
+                pred_bounds, gt_bounds = pred_bounds[fg], gt_bounds[fg]
+            bounds_loss = torch.mean(torch.sum(torch.abs(pred_bounds - gt_bounds), axis=1))
+            losses_dict['optimization_loss'] += cfg.loss_weight_bb_bounds * bounds_loss
+            losses_dict['bounds_loss'] = bounds_loss.detach()
+
+        if cfg.use_bb_iou_loss:                                      # model.py:91-129
+            pred_bounds, pred_offsets = pred[cfg.mlp_bounds], pred[cfg.mlp_offsets]
+            loc = batch['input_location'].to(device)
+            gt_offsets, gt_bounds = batch['gt_bb_offsets'].to(device), batch['gt_bb_bounds'].to(device)
+            if on_fg:
+                pred_bounds, pred_offsets = pred_bounds[fg], pred_offsets[fg]
+                gt_bounds, gt_offsets, loc = gt_bounds[fg], gt_offsets[fg], loc[fg]
+            pred_bounds = torch.clamp(pred_bounds, min=cfg.min_bb_size)
+            pr_bbs = to_bbs_min_max_(pred_offsets + loc, pred_bounds, device)
+            gt_bbs = to_bbs_min_max_(gt_offsets + loc, gt_bounds, device)
+            area1 = (pr_bbs[..., 3] - pr_bbs[..., 0]) * (pr_bbs[..., 4] - pr_bbs[..., 1]) * (pr_bbs[..., 5] - pr_bbs[..., 2])
+            area2 = (gt_bbs[..., 3] - gt_bbs[..., 0]) * (gt_bbs[..., 4] - gt_bbs[..., 1]) * (gt_bbs[..., 5] - gt_bbs[..., 2])
+            lt = torch.max(pr_bbs[..., :3], gt_bbs[..., :3])
+            rb = torch.min(pr_bbs[..., 3:], gt_bbs[..., 3:])
+            wh = (rb - lt).clamp(min=0)
+            overlap = wh[..., 0] * wh[..., 1] * wh[..., 2]
+            union = area1 + area2 - overlap
+            union = torch.max(union, union.new_tensor([1e-6]))
+            iou_loss = torch.mean(1.0 - overlap / union)
+            losses_dict['optimization_loss'] += cfg.loss_weight_bb_iou * iou_loss
+            losses_dict['iou_loss'] = iou_loss.detach()
+
+        if cfg.mlp_bb_scores in cfg.network_heads:                   # model.py:133-176
+            loss_weight_bb_scores = cfg.loss_weight_bb_scores
+            if epoch < cfg.mlp_bb_scores_start_epoch:
+                loss_weight_bb_scores = 0
+            pred_scores = pred[cfg.mlp_bb_scores].reshape(-1)
+            pred_bounds, pred_offsets = pred[cfg.mlp_bounds], pred[cfg.mlp_offsets]
+            loc = batch['input_location'].to(device)
+            gt_offsets, gt_bounds = batch['gt_bb_offsets'].to(device), batch['gt_bb_bounds'].to(device)
+            if on_fg:
+                pred_scores, pred_bounds, pred_offsets = pred_scores[fg], pred_bounds[fg], pred_offsets[fg]
+                loc, gt_offsets, gt_bounds = loc[fg], gt_offsets[fg], gt_bounds[fg]
+            gt_bbs = to_bbs_min_max_(gt_offsets + loc, gt_bounds, device)
+            pred_bounds = torch.clamp(pred_bounds, min=cfg.min_bb_size)
+            pred_bbs = to_bbs_min_max_(pred_offsets + loc, pred_bounds, device)
+            ious = iou_nms.set_IOUs(gt_bbs, pred_bbs, check=False).detach()   # sides >= 0 by construction
+            score_loss = self.BCEWithLogitsLoss(pred_scores, ious)
+            losses_dict['bb_scores_correlation'] = _pearsonr(ious, pred_scores.detach())
+            losses_dict['optimization_loss'] += loss_weight_bb_scores * score_loss
+            losses_dict['bb_score_loss'] = score_loss.detach()
+            losses_dict['bb_target_scores'] = torch.mean(ious)
+
+        if cfg.mlp_center_scores in cfg.network_heads and epoch >= cfg.mlp_center_scores_start_epoch:   # 179-192
+            pred_scores = pred[cfg.mlp_center_scores].reshape(-1)
+            gt_scores = offset_loss_per_pred.detach()
+            if cfg.loss_on_fg_instances:
+                pred_scores = pred_scores[fg]
+            score_loss = torch.mean(torch.abs(pred_scores - gt_scores))
+            losses_dict['optimization_loss'] += cfg.loss_weight_center_scores * score_loss
+            losses_dict['center_score_loss'] = score_loss.detach()
+            losses_dict['center_scores_correlation'] = _pearsonr(gt_scores, pred_scores.detach())
+
+        if cfg.mlp_semantics in cfg.network_heads:                   # model.py:194-210
+            pred_semantics = pred[cfg.mlp_semantics]
+            gt_semantics = self._sem_lut()[batch['gt_semantics'].to(device)]
+            semantics_loss = self.semantics_loss(pred_semantics, gt_semantics)
+            pred_semantics_int = torch.argmax(pred_semantics, 1)
+            semantics_acc = torch.sum(pred_semantics_int == gt_semantics) / len(gt_semantics)
+            losses_dict['optimization_loss'] += cfg.loss_weight_semantics * semantics_loss
+            losses_dict['semantics_loss'] = semantics_loss.detach()
+            losses_dict['semantics_acc'] = semantics_acc.detach()
+            losses_dict['semantics_mIoU'] = _LazyMean(pred_semantics_int, gt_semantics)
+
+        if cfg.mlp_per_vox_semantics in cfg.network_heads:           # model.py:212-223
+            pred_semantics = pred[cfg.mlp_per_vox_semantics]
+            gt_semantics = self._sem_lut()[batch['gt_per_vox_semantics'].to(device)]
+            per_vox_semantics_loss = self.semantics_loss(pred_semantics, gt_semantics)
+            pred_semantics_int = torch.argmax(pred_semantics, 1)
+            per_vox_semantics_acc = torch.sum(pred_semantics_int == gt_semantics) / len(gt_semantics)
+            losses_dict['optimization_loss'] += cfg.loss_weight_per_vox_semantics * per_vox_semantics_loss
+            losses_dict['per_vox_semantics_loss'] = per_vox_semantics_loss.detach()
+            losses_dict['per_vox_semantics_acc'] = per_vox_semantics_acc.detach()
+        return losses_dict, pred
+
+    def sync_gradients(self):
+        """Data-parallel gradient mean (DDP's job in the reference, model.py:24); no-op on one GPU."""
+        if self._dp is not None:
+            self._dp.all_reduce_mean()
+
+    def get_prediction(self, batch, with_grad=False, to_cpu=True, min_size=True, get_all=False):
+        return self.detection_model.get_prediction(batch, with_grad=with_grad, to_cpu=to_cpu, min_size=min_size)
+
+    def pred2mask(self, batch, pred, mode):
+        return self.detection_model.detection2mask(batch, pred, self.cfg, mode, True, *self.cfg.eval_ths)
+
+    def parameters(self):
+        return self.detection_model.parameters()
+
+    def to(self, device):
+        self.detection_model = self.detection_model.to(device)
+        return self
+
+    def eval(self):
+        self.detection_model.eval()
+
+    def train(self):
+        self.detection_model.train()
+
+    def load_state_dict(self, state_dict, strict=True):
+        return self.detection_model.load_state_dict(state_dict, strict)
+
+    def state_dict(self):
+        return self.detection_model.state_dict()
+
+    def load_checkpoint(self, checkpoint=None, closest_to=None):
+        """model.py:264-288 (same file-name convention, same return tuple)."""
+        checkpoints = glob(self.cfg.checkpoint_path + '/*')
+        if checkpoint is None:
+            if len(checkpoints) == 0:
+                print('No checkpoints found at {}'.format(self.cfg.checkpoint_path))
+                return 0, 0
+            checkpoints = [os.path.splitext(os.path.basename(path))[0].split('_')[-1] for path in checkpoints]
+            checkpoints = np.sort(np.array(checkpoints, dtype=float))
+            if closest_to:
+                ckpt_idx = np.argmin(np.abs(checkpoints - (closest_to * 60 * 60)))
+            else:
+                ckpt_idx = -1
+            path = self.cfg.checkpoint_path + 'checkpoint_{}h:{}m:{}s_{}.tar'.format(
+                *[*convertSecs(checkpoints[ckpt_idx]), checkpoints[ckpt_idx]])
+        else:
+            path = self.cfg.checkpoint_path + '{}.tar'.format(checkpoint)
+        print('Loaded checkpoint from: {}'.format(path))
+        checkpoint = torch.load(path, map_location=self.device)
+        self.load_state_dict(checkpoint['model_state_dict'])
+        return checkpoint['epoch'], checkpoint['training_time'], os.path.basename(path)[:-4], checkpoint['iteration_num']
+
+
+class _LazyMean:
+    """semantics_mIoU is a logging value (model.py:205,210); evaluating it lazily keeps the blocking
+    host transfer out of the training step unless the caller actually asks for `.item()`."""
+
+    def __init__(self, pred, gt):
+        self._p, self._g, self._v = pred.detach(), gt, None
+
+    def item(self):
+        if self._v is None:
+            v = semIOU(self._p, self._g)
+            self._v = float(v.mean()) if v.size else float('nan')
+        return self._v
+
+    def __float__(self):
+        return self.item()

@@ -1,0 +1,176 @@
+"""Sparse layers with the MinkowskiEngine names and parameter layout the reference uses.
+
+Import as ``import box2mask_amd.nn as ME`` and the model code reads like
+/root/reference/models/detection_net.py / resnet.py.  State-dict keys and shapes follow SURVEY.md
+§8(b): ``<conv>.kernel`` (K,Cin,Cout) — 2-D (Cin,Cout) for 1x1 —, ``<conv>.bias`` (1,Cout),
+``<bn>.bn.{weight,bias,running_mean,running_var,num_batches_tracked}``  [shapes ME-mem].
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import functional as F_
+from .sparse import CoordinateManager, SparseTensor  # noqa: F401  (re-exported, ME.SparseTensor)
+
+
+class CatTensor(SparseTensor):
+    """Result of :func:`cat`: two feature matrices on the same coordinate key, concatenated lazily.
+    Convolutions read both sources directly (no (N, C1+C2) copy is materialised)."""
+
+    def __init__(self, a: SparseTensor, b: SparseTensor):
+        assert a.manager is b.manager and a.level == b.level, 'ME.cat needs equal coordinate keys'
+        self.manager, self.level = a.manager, a.level
+        self.parts = (a.F, b.F)
+        self._F = None
+
+    @property
+    def F(self):
+        if self._F is None:
+            self._F = torch.cat(self.parts, 1)
+        return self._F
+
+
+def cat(a: SparseTensor, b: SparseTensor) -> SparseTensor:
+    """ME.cat (/root/reference/models/detection_net.py:286-336): channel concat [a, b]."""
+    return CatTensor(a, b)
+
+
+def _sources(x: SparseTensor):
+    if isinstance(x, CatTensor):
+        return x.parts
+    return x.F, None
+
+
+class _ConvBase(nn.Module):
+    transposed = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=3,
+                 expand_coordinates=False):
+        super().__init__()
+        assert dimension == 3 and dilation == 1 and not expand_coordinates
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = kernel_size, stride
+        self.kernel_volume = kernel_size ** 3
+        if self.kernel_volume == 1:
+            self.kernel = nn.Parameter(torch.empty(in_channels, out_channels))
+        else:
+            self.kernel = nn.Parameter(torch.empty(self.kernel_volume, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):          # [ME-mem] default init: uniform(+-1/sqrt(fan))
+        n = (self.out_channels if self.transposed else self.in_channels) * self.kernel_volume
+        stdv = 1.0 / math.sqrt(n)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def extra_repr(self):
+        return 'in=%d, out=%d, kernel_size=%d, stride=%d' % (self.in_channels, self.out_channels, self.kernel_size,
+                                                             self.stride)
+
+
+class MinkowskiConvolution(_ConvBase):
+    """[ME-mem] stride 1 (odd kernel, centred) or kernel 2 / stride 2."""
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        m, l = x.manager, x.level
+        x1, x2 = _sources(x)
+        if self.kernel_volume == 1:
+            assert self.stride == 1
+            y = F_.sparse_conv(x1, x2, self.kernel, self.bias, None, None, False, x1.shape[0])
+            return x.new(y)
+        if self.stride == 1:
+            rb = m.rulebook_same(l, self.kernel_size)
+            y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb, rb, True, rb.n_out)
+            return x.new(y)
+        assert self.stride == 2 and self.kernel_size == 2, 'only k2s2 strided convolutions are on the path'
+        rb_f, rb_b = m.rulebook_down(l), m.rulebook_up(l)
+        y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out)
+        return x.new(y, level=l + 1)
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    """[ME-mem] kernel 2 / stride 2 transposed convolution onto the EXISTING finer coordinate map
+    (required by the ME.cat key equality at detection_net.py:286-336)."""
+    transposed = True
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        assert self.stride == 2 and self.kernel_size == 2 and x.level >= 1
+        m, l = x.manager, x.level - 1
+        x1, x2 = _sources(x)
+        rb_f, rb_b = m.rulebook_up(l), m.rulebook_down(l)
+        y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out)
+        return x.new(y, level=l)
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """BatchNorm1d on the feature matrix; parameters live under ``.bn`` like ME's wrapper.
+    ``sync`` turns on the packed statistics exchange (MinkowskiSyncBatchNorm, model.py:25)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
+        self.sync = False
+
+    def apply_bn(self, feats, residual=None, relu=False):
+        bn = self.bn
+        training = self.training or not bn.track_running_stats
+        if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return F_.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                             bn.momentum, bn.eps, residual, relu, self.sync)
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        return x.new(self.apply_bn(x.F))
+
+
+class MinkowskiSyncBatchNorm:
+    @staticmethod
+    def convert_sync_batchnorm(module: nn.Module):
+        for m in module.modules():
+            if isinstance(m, MinkowskiBatchNorm):
+                m.sync = True
+        return module
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        return x.new(F_.relu(x.F))
+
+
+class PooledTensor:
+    """Dense per-segment features after segment pooling (row r <-> pooling id r)."""
+
+    def __init__(self, F):
+        self.F = F
+        self.manager, self.level = None, None
+
+    def new(self, F, level=None):
+        return PooledTensor(F)
+
+
+def segment_pool(x: SparseTensor, pooling_ids, mode='avg') -> PooledTensor:
+    """`out.C[:,0] = pooling_ids; ME.SparseTensor(out.F, out.C); global pool`
+    (/root/reference/models/detection_net.py:345-352) as one segmented reduction."""
+    n_seg = int(pooling_ids.max().item()) + 1 if pooling_ids.numel() else 0
+    return PooledTensor(F_.segment_pool(x.F, pooling_ids, n_seg, mode))
+
+
+def kaiming_normal_(tensor, mode='fan_out', nonlinearity='relu'):
+    """[ME-mem] ME.utils.kaiming_normal_ on (K,Cin,Cout) kernels (resnet.py:142)."""
+    if tensor.dim() == 2:
+        fan_in, fan_out = tensor.size(0), tensor.size(1)
+    else:
+        fan_in, fan_out = tensor.size(1) * tensor.size(0), tensor.size(2) * tensor.size(0)
+    fan = fan_in if mode == 'fan_in' else fan_out
+    std = math.sqrt(2.0) / math.sqrt(fan)
+    with torch.no_grad():
+        return tensor.normal_(0, std)

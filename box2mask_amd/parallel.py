@@ -1,0 +1,119 @@
+"""Data-parallel glue: one process per GPU, scenes sharded across ranks, gradients averaged with
+bucketed all-reduces over RCCL/xGMI that overlap the rest of backward.
+
+Replaces torch DistributedDataParallel as the reference intends to use it
+(/root/reference/models/model.py:24, training.py:286-297 — the published launcher cannot run,
+SURVEY.md Appendix A).  The class is device-agnostic torch code, so the N>1 path is covered by
+world_size-2 gloo tests on the CPU; on the GPU the backend "nccl" is RCCL.
+
+Buckets are filled in reverse parameter order (the order backward produces gradients).  When the
+last gradient of a bucket has been accumulated, the bucket is packed into one flat buffer and an
+asynchronous all-reduce is launched; `all_reduce_mean()` waits, divides by the world size and
+scatters the result back into the `.grad` tensors.  Large buckets (default 64 MiB) keep the
+xGMI links busy with few, large collectives.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1
+    rank = int(os.environ['RANK'])
+    local = int(os.environ.get('LOCAL_RANK', rank))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend == 'nccl':
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def shard_scenes(n_scenes: int, rank: int, world: int):
+    """Scene indices of this rank (DistributedSampler semantics without shuffling,
+    /root/reference/models/dataloader.py:334-341): rank r takes scenes r, r+world, ..."""
+    return list(range(rank, n_scenes, world))
+
+
+class GradAllReduce:
+    def __init__(self, params, bucket_bytes: int = 64 << 20, group=None, overlap: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = []          # list of lists of params, reverse order
+        cur, size = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self._bucket_of[p] = bi
+        self._pending = [len(b) for b in self.buckets]
+        self._work = [None] * len(self.buckets)
+        self._flat = [None] * len(self.buckets)
+        self._hooks = []
+        if overlap and self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -- hooks (overlap with backward)
+    def _on_grad(self, p):
+        bi = self._bucket_of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self._flat[bi] = flat
+        self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    # -- public
+    def broadcast_parameters(self, src: int = 0):
+        if self.world <= 1:
+            return
+        for p in self.params:
+            dist.broadcast(p.data, src=src, group=self.group)
+
+    def all_reduce_mean(self):
+        """Finish (or perform) the gradient all-reduce and write the mean back into `.grad`."""
+        if self.world <= 1:
+            return
+        for bi, b in enumerate(self.buckets):
+            if self._work[bi] is None:
+                self._launch(bi)
+        inv = 1.0 / self.world
+        for bi, b in enumerate(self.buckets):
+            self._work[bi].wait()
+            flat = self._flat[bi]
+            off = 0
+            for p in b:
+                n = p.numel()
+                g = flat[off:off + n].reshape(p.shape) * inv
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+            self._work[bi], self._flat[bi] = None, None
+        self._pending = [len(b) for b in self.buckets]

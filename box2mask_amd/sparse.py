@@ -1,0 +1,178 @@
+"""Coordinate manager, tile rulebooks and the SparseTensor holder.
+
+Host-side mirror of what the reference gets from MinkowskiEngine's coordinate manager
+([ME-mem]): a SparseTensor owns a feature matrix ``F`` and a key
+(level) into a :class:`CoordinateManager` that caches coordinate maps and kernel maps per
+(level, kernel) for the lifetime of one batch.  All heavy work happens in the HIP library
+(``b2m_coords_*``, ``b2m_kernel_map``, ``b2m_rulebook``); torch only allocates device memory.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+TILE = 128
+
+
+def _pow2_at_least(n: int) -> int:
+    c = 1
+    while c < n:
+        c <<= 1
+    return c
+
+
+class Rulebook:
+    """Tile rulebook of one kernel map: for every (offset k, tile of 128 output rows) the valid
+    (input row, output row) pairs, compacted in output-row order (include/b2m.h: b2m_rulebook)."""
+
+    def __init__(self, nbr: torch.Tensor, K: int, n_out: int, n_in: int, keep_table: bool = False):
+        dev = nbr.device
+        self.K, self.n_out, self.n_in = K, n_out, n_in
+        self.ntiles = (n_out + TILE - 1) // TILE
+        ldr = self.ntiles * TILE
+        self.rb_in = torch.empty(max(K * ldr, 1), dtype=torch.int32, device=dev)
+        self.rb_out = torch.empty(max(K * ldr, 1), dtype=torch.uint8, device=dev)
+        self.rb_cnt = torch.empty(max(K * self.ntiles, 1), dtype=torch.int32, device=dev)
+        self.pair_total = torch.zeros(K, dtype=torch.int32, device=dev)
+        ld = nbr.shape[1] if nbr.dim() == 2 else n_out
+        _lib.call('b2m_rulebook', nbr.data_ptr(), ld, K, n_out, self.rb_in.data_ptr(), self.rb_out.data_ptr(),
+                  self.rb_cnt.data_ptr(), self.pair_total.data_ptr())
+        self.nbr = nbr if keep_table else None
+        self._pairs = None
+
+    @property
+    def pairs(self) -> int:
+        """Total number of (in,out) pairs (syncs once; used for FLOP accounting only)."""
+        if self._pairs is None:
+            self._pairs = int(self.pair_total.sum().item())
+        return self._pairs
+
+
+class CoordinateManager:
+    """Coordinate maps of one batch at tensor strides 1,2,4,... and their kernel maps."""
+
+    def __init__(self, coords: torch.Tensor, keep_tables: bool = False, check: bool = True):
+        _lib.require_gpu()
+        assert coords.dim() == 2 and coords.shape[1] == 4, 'coords must be (N,4) [b,x,y,z]'
+        if check and coords.numel():
+            mn, mx = int(coords.min()), int(coords.max())
+            if mn < 0 or mx >= 65535:
+                raise ValueError('coordinates must lie in [0, 65534] (got %d..%d)' % (mn, mx))
+        dev = torch.device('cuda', torch.cuda.current_device())
+        c0 = coords.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous()
+        self.device = dev
+        self.keep_tables = keep_tables
+        self.coords = [c0]                 # level -> (n,4) int32
+        self.tables = []                   # level -> (keys, vals, cap)
+        self.parent, self.koff = [], []    # level l -> maps of level l rows into level l+1
+        self._rb = {}
+        self.dup_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tables.append(self._build_table(c0, self.dup_count))
+
+    # -- coordinate maps
+    def _build_table(self, c, dup=None):
+        n = c.shape[0]
+        cap = _pow2_at_least(max(2 * n, 16))
+        keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+        vals = torch.empty(cap, dtype=torch.int32, device=self.device)
+        _lib.call('b2m_coords_build', c.data_ptr(), n, keys.data_ptr(), vals.data_ptr(), cap, _lib.ptr(dup))
+        return keys, vals, cap
+
+    def n(self, level: int) -> int:
+        self.ensure_level(level)
+        return self.coords[level].shape[0]
+
+    def ensure_level(self, level: int):
+        while len(self.coords) <= level:
+            l = len(self.coords) - 1
+            c = self.coords[l]
+            n = c.shape[0]
+            cap = _pow2_at_least(max(2 * n, 16))
+            keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+            vals = torch.empty(cap, dtype=torch.int32, device=self.device)
+            cout = torch.empty((max(n, 1), 4), dtype=torch.int32, device=self.device)
+            parent = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+            koff = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+            scratch = torch.empty(2 * n + n // 1024 + 2, dtype=torch.int32, device=self.device)
+            n_out = ctypes.c_int64(0)
+            _lib.call('b2m_coords_stride', c.data_ptr(), n, 1 << l, cout.data_ptr(), parent.data_ptr(),
+                      koff.data_ptr(), keys.data_ptr(), vals.data_ptr(), cap, scratch.data_ptr(),
+                      ctypes.byref(n_out))
+            m = int(n_out.value)
+            self.coords.append(cout[:m])
+            self.tables.append((keys, vals, cap))
+            self.parent.append(parent[:n])
+            self.koff.append(koff[:n])
+
+    # -- kernel maps
+    def rulebook_same(self, level: int, ksize: int) -> Rulebook:
+        """Stride-1 map of a cubic odd kernel on `level` (in == out coordinate set)."""
+        key = ('same', level, ksize)
+        if key not in self._rb:
+            self.ensure_level(level)
+            c = self.coords[level]
+            n = c.shape[0]
+            keys, vals, cap = self.tables[level]
+            K = ksize ** 3
+            nbr = torch.empty((K, max(n, 1)), dtype=torch.int32, device=self.device)
+            _lib.call('b2m_kernel_map', c.data_ptr(), n, ksize, 1 << level, keys.data_ptr(), vals.data_ptr(), cap,
+                      nbr.data_ptr(), nbr.shape[1])
+            self._rb[key] = Rulebook(nbr, K, n, n, self.keep_tables)
+        return self._rb[key]
+
+    def _stride_tables(self, level: int):
+        self.ensure_level(level + 1)
+        nf, nc = self.n(level), self.n(level + 1)
+        child = torch.empty((8, max(nc, 1)), dtype=torch.int32, device=self.device)
+        up = torch.empty((8, max(nf, 1)), dtype=torch.int32, device=self.device)
+        _lib.call('b2m_stride_tables', self.parent[level].data_ptr(), self.koff[level].data_ptr(), nf, nc,
+                  child.data_ptr(), child.shape[1], up.data_ptr(), up.shape[1])
+        self._rb[('down', level)] = Rulebook(child, 8, nc, nf, self.keep_tables)
+        self._rb[('up', level)] = Rulebook(up, 8, nf, nc, self.keep_tables)
+
+    def rulebook_down(self, level: int) -> Rulebook:
+        """k2s2 map level -> level+1, tiled over the coarse (output) rows."""
+        if ('down', level) not in self._rb:
+            self._stride_tables(level)
+        return self._rb[('down', level)]
+
+    def rulebook_up(self, level: int) -> Rulebook:
+        """Transposed k2s2 map level+1 -> level, tiled over the fine (output) rows."""
+        if ('up', level) not in self._rb:
+            self._stride_tables(level)
+        return self._rb[('up', level)]
+
+
+class SparseTensor:
+    """Feature matrix + coordinate key; mirrors the part of ME.SparseTensor the reference uses
+    (``.F``, ``.C``; /root/reference/models/model.py:43,55-56, detection_net.py:347-348,506-510)."""
+
+    def __init__(self, features, coordinates=None, device=None, coordinate_manager: CoordinateManager | None = None,
+                 level: int = 0):
+        if coordinate_manager is None:
+            assert coordinates is not None
+            coordinate_manager = CoordinateManager(coordinates)
+        self.manager = coordinate_manager
+        self.level = level
+        dev = coordinate_manager.device
+        self.F = features if features.device == dev else features.to(dev, non_blocking=True)
+        if self.F.dtype != torch.float32:
+            self.F = self.F.float()
+        assert self.F.shape[0] == coordinate_manager.n(level), 'feature rows must match the coordinate map'
+
+    @property
+    def C(self):
+        return self.manager.coords[self.level]
+
+    @property
+    def tensor_stride(self):
+        return 1 << self.level
+
+    def new(self, F, level=None):
+        return SparseTensor(F, coordinate_manager=self.manager, level=self.level if level is None else level)
+
+    def __len__(self):
+        return self.F.shape[0]

@@ -1,0 +1,217 @@
+/*
+ * b2m.h — C ABI of the MI355X (gfx950) hot path of Box2Mask.
+ *
+ * The reference reaches this path through a *Python* surface (MinkowskiEngine 0.5.4 operators and
+ * models/iou_nms.py); the functions below are what a binding for that surface calls.  Each entry
+ * cites the reference interface it replaces (paths relative to /root/reference; [ME] = behaviour
+ * of the un-vendored MinkowskiEngine 0.5.4 dependency, docs/installation.md:6,42).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it; no function
+ *     synchronises unless documented ("syncs")
+ *   - no allocation inside: the caller owns every buffer, including scratch
+ *   - return value: 0 = ok, negative = error (b2m_last_error() gives a thread-local message)
+ *   - coordinates: int32 rows [b,x,y,z], all fields in [0, 65535]; features: fp32 row-major with
+ *     an explicit leading dimension (in floats)
+ *   - TILE = 128 output rows is the unit of the "tile rulebook" 
+ */
+#ifndef B2M_H
+#define B2M_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B2M_TILE 128
+#define B2M_OK 0
+#define B2M_ERR_ARG (-1)
+#define B2M_ERR_HIP (-2)
+#define B2M_ERR_UNSUPPORTED (-3)
+
+const char* b2m_last_error(void);
+int b2m_version(void);
+/* 1 if the library was built for gfx950 and a device is present */
+int b2m_device_ok(void);
+
+/* ---------------------------------------------------------------- coordinate maps (integer) */
+
+/* Hash table of a coordinate set.  Replaces [ME] CoordinateMap insert reached from
+ * ME.SparseTensor(feats, coords) — models/model.py:43, models/detection_net.py:499,503.
+ * keys[cap] (uint64) and vals[cap] (int32), cap a power of two >= 2*n.  After the call
+ * vals[slot(key)] = smallest row index carrying that key (row i for unique coordinates).
+ * dup_count (1 int32, may be NULL) receives the number of duplicate rows. */
+int b2m_coords_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
+                     int32_t* dup_count, void* stream);
+
+/* Strided (kernel 2, stride 2) coordinate generation: out = floor(c / 2ts) * 2ts, unique, rows in
+ * order of first occurrence.  Replaces [ME] stride() reached from the seven k=2,s=2 convolutions,
+ * models/detection_net.py:42,48,54,61,68,74,81.
+ *   coords_out[n*4]   coarse coordinates (first *n_out_host rows valid)
+ *   parent[n]         coarse row of every fine row
+ *   koff[n]           kernel offset index of the fine row inside its parent, ox + 2*oy + 4*oz
+ *   keys/vals[cap]    hash table of the coarse level (key -> coarse row), cap >= 2*n pow2
+ *   scratch           int32[2*n + n/1024 + 2]
+ * Syncs the stream once to return the coarse row count in *n_out_host. */
+int b2m_coords_stride(const int32_t* coords, int64_t n, int32_t ts,
+                      int32_t* coords_out, int32_t* parent, int32_t* koff,
+                      uint64_t* keys, int32_t* vals, int64_t cap,
+                      int32_t* scratch, int64_t* n_out_host, void* stream);
+
+/* Stride-1 kernel map as a neighbour table: nbr[k*ld + o] = row of coords[o] + offset_k, or -1.
+ * offsets: odd ksize centred, x fastest (k = (dx+h) + ks*(dy+h) + ks^2*(dz+h)), times ts.
+ * Replaces [ME] kernel_map() for kernel_size 3 / 5, stride 1 — models/resnet.py:61-65,
+ * models/detection_net.py:37.  ld >= n. */
+int b2m_kernel_map(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts,
+                   const uint64_t* keys, const int32_t* vals, int64_t cap,
+                   int32_t* nbr, int64_t ld, void* stream);
+
+/* k2s2 maps from (parent, koff):  child[k*ld_c + o] = fine row (table over coarse rows, used by the
+ * strided convolution) and up[k*ld_f + i] = parent[i] iff koff[i]==k (table over fine rows, used by
+ * the transposed convolution, models/detection_net.py:88-133).  Either table may be NULL. */
+int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int64_t n_fine, int64_t n_coarse,
+                      int32_t* child, int64_t ld_c, int32_t* up, int64_t ld_f, void* stream);
+
+/* Tile rulebook: per (offset k, tile t of 128 output rows) the valid pairs compacted in row order.
+ *   rb_in [k*ldr + t*128 + j]  input row of pair j      (-1 beyond the count)
+ *   rb_out[k*ldr + t*128 + j]  output row - t*128       (0 beyond the count)
+ *   rb_cnt[k*ntiles + t]       number of pairs
+ *   pair_total[K]              pairs per offset (may be NULL)
+ * ldr = ntiles*128, ntiles = ceil(n_out/128). */
+int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out,
+                 int32_t* rb_in, uint8_t* rb_out, int32_t* rb_cnt, int32_t* pair_total, void* stream);
+
+/* ---------------------------------------------------------------- sparse convolution (fp32, MFMA) */
+
+/* Y[o, 0:cout] (+)= sum_k [X1|X2][in_k(o), :] @ W[k]  (+ bias)
+ * Replaces [ME] ConvolutionForward / ConvolutionTransposeForward (resnet.py:61-65,
+ * detection_net.py:37-135) and, with an identity rulebook (rb_in == NULL, K == 1), the 1x1
+ * `mm` fast path (resnet.py:151-158, detection_net.py:172-193).  Two sources implement
+ * ME.cat (detection_net.py:286-336) without materialising the concatenation: input channel
+ * c < c1 comes from x1, the rest from x2 (c2 may be 0, x2 NULL).
+ *   w     [K][c1+c2][ldw]   (ldw >= cout)
+ *   bias  [cout] or NULL
+ *   accumulate != 0: add to the existing Y instead of overwriting
+ * The same entry computes the data gradient when called with the transposed/mirrored weights
+ * produced by b2m_weight_transpose. */
+int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
+                 const float* w, int64_t ldw, int32_t K, const float* bias,
+                 const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                 int64_t n_out, float* y, int64_t ldy, int32_t cout, int32_t accumulate, void* stream);
+
+/* wt[kk][co][ci] = w[src(kk)][ci][co], src(kk) = mirror ? K-1-kk : kk.
+ * w: [K][cin][ldw], wt: [K][cout][ldwt]. */
+int b2m_weight_transpose(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t cout,
+                         float* wt, int64_t ldwt, int32_t mirror, void* stream);
+
+/* dW[k][ci][co] += sum over pairs (i,o) of offset k:  X[i, ci] * dY[o, co]     (fp32 atomics)
+ * Replaces [ME] ConvolutionBackward (weight part).  x: rows indexed by rb_in (ldx, cin columns used),
+ * dy: rows indexed by tile*128+rb_out.  dw element (k,ci,co) lives at dw[k*dw_kstride + ci*lddw + co]
+ * (so a channel sub-block of a wider weight tensor can be targeted); the caller zeroes it. */
+int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const float* dy, int64_t lddy, int32_t cout,
+                   const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                   int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, void* stream);
+
+/* ---------------------------------------------------------------- batch norm / elementwise (fp32, HBM-bound) */
+
+/* Column sums for BatchNorm: stats[0:c] = sum x, stats[c:2c] = sum x^2 (double), deterministic
+ * two-stage reduction.  partial: double[2*c*nblk_max] scratch with nblk_max = 1024.
+ * Replaces the reduction inside torch.nn.BatchNorm1d wrapped by ME.MinkowskiBatchNorm
+ * (resnet.py:63,66; detection_net.py:40-135). */
+int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats, void* stream);
+
+/* From (possibly all-reduced) sums: scale/shift for the apply kernel, saved mean/invstd, and the
+ * running-statistics update (momentum, unbiased variance), all on device.
+ * count = number of rows the sums cover (global count under SyncBN). */
+int b2m_bn_finalize(const double* stats, double count, int32_t c, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* y = x*scale + shift (+ residual) (ReLU if relu) */
+int b2m_bn_apply(const float* x, int64_t ldx, int64_t n, int32_t c, const float* scale, const float* shift,
+                 const float* residual, int64_t ldr, int32_t relu, float* y, int64_t ldy, void* stream);
+
+/* Backward reduction: g = dy * (relu ? y>0 : 1);  sums[0:c] = sum g, sums[c:2c] = sum g*xhat. */
+int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                      int64_t n, int32_t c, const float* mean, const float* invstd, int32_t relu,
+                      double* partial, double* sums, void* stream);
+
+/* dx = gamma*invstd*(g - sum_g/count - xhat*sum_gxhat/count); optionally dres = g. */
+int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                     int64_t n, int32_t c, const float* mean, const float* invstd, const float* gamma,
+                     const double* sums, double count, int32_t relu,
+                     float* dx, int64_t lddx, float* dres, int64_t lddres, void* stream);
+
+/* out = relu(a) (b == NULL) or a + b, optional relu; grad helper: dx = dy * (y > 0). */
+int b2m_relu_fwd(const float* x, int64_t n_elem, float* y, void* stream);
+int b2m_relu_bwd(const float* dy, const float* y, int64_t n_elem, float* dx, void* stream);
+int b2m_add(const float* a, const float* b, int64_t n_elem, float* out, void* stream);
+
+/* ---------------------------------------------------------------- segment pooling */
+
+/* out[s,:] = mean (mode 0) or max (mode 1) of the x rows with ids[row]==s; output row s <-> pooling id s.
+ * Replaces the "overwrite batch column, rebuild SparseTensor, global pool" sequence of
+ * models/detection_net.py:345-352 with a direct segmented reduction (no second hash build).
+ * mode 0 sums with fp32 atomics (order-dependent in the last bits) and divides by the exact integer
+ * count; mode 1 is deterministic (64-bit packed atomicMax, lowest row wins ties).
+ *   counts[n_seg] int32 out; argmax[n_seg*c] int32 out (mode 1 only); scratch uint64[n_seg*c] (mode 1 only) */
+int b2m_segment_pool_fwd(const float* x, int64_t ldx, int64_t n, int32_t c, const int64_t* ids, int64_t n_seg,
+                         int32_t mode, float* out, int32_t* counts, int32_t* argmax, uint64_t* scratch,
+                         void* stream);
+int b2m_segment_pool_bwd(const float* dout, int64_t n, int32_t c, const int64_t* ids, int64_t n_seg,
+                         int32_t mode, const int32_t* counts, const int32_t* argmax,
+                         float* dx, int64_t lddx, void* stream);
+
+/* ---------------------------------------------------------------- box votes -> instance masks */
+
+/* Greedy non-maximum clustering of n boxes [score,min3,max3] (fp32, one scene).
+ * Replaces NMS_clustering(boxes, cluster_th, get_heatmaps=True), models/iou_nms.py:68-105
+ * (IoU formula of torch_IOUs, iou_nms.py:26-45, evaluated in the same fp32 operation order).
+ * Score ties are broken by the lower row index (the reference's unstable argsort leaves them
+ * undefined).  Outputs: reps[<=n] representative row per cluster, assign[n] cluster index of every
+ * box, heat[max_k*n] row-major IoU heat-maps (row r = IoU(box reps[r], all boxes), heat[r, reps[r]]=1),
+ * *k_out = number of clusters (device int32).  If the cluster count exceeds max_k the extra
+ * heat-map rows are not written (k_out still holds the true count).
+ * order: uint64[npow2(n)] scratch (npow2 = next power of two); on return its first n entries hold
+ * the box rows in visiting order (descending score) in their low 32 bits.  n <= 262144. */
+int b2m_nmc(const float* boxes, int32_t n, float cluster_th, int32_t max_k,
+            int32_t* reps, int32_t* assign, float* heat, int32_t* k_out, uint64_t* order, void* stream);
+
+/* Heat-map rows -> voxel bit masks.  For selected cluster rows sel[0:ksel] of heat (k x n_fg):
+ * value(v) = fg_slot[seg2vox[v]] >= 0 ? heat[sel[r], fg_slot[seg2vox[v]]] : 0;
+ * bit v of bits[r*words + v/64] = value(v) > mask_bin_th.  Replaces models/detection_net.py:436-446
+ * (zero-padded background, projection through seg2vox, threshold).  words = ceil(n_vox/64). */
+int b2m_mask_project(const float* heat, int32_t n_fg, const int32_t* sel, int32_t ksel,
+                     const int32_t* fg_slot, const int64_t* seg2vox, int64_t n_vox, float mask_bin_th,
+                     uint64_t* bits, int64_t words, void* stream);
+
+/* Greedy mask NMS in the given (score-descending) order; IoU = |a&b| / |a|b| from popcounts,
+ * evaluated as float32(inter)/float32(union) like torch's int64 true-division.
+ * Replaces mask_NMS(sorted_masks, th), models/iou_nms.py:130-144 (masks_iou 109-121).
+ * inter: int32[k*k] scratch, keep[k] int32 flags out, *n_keep device int32. */
+int b2m_mask_nms(const uint64_t* bits, int32_t k, int64_t words, float th,
+                 int32_t* inter, int32_t* keep, int32_t* n_keep, void* stream);
+
+/* labels[r] = argmax_c |{v in mask rows[r] : sem[v]==c}| (lowest c on ties; 0 for an empty mask).
+ * Replaces the bincount/argmax loop of models/detection_net.py:461-466.  0 <= sem < n_class <= 256.
+ * rows: int32[k] mask row per output (NULL = identity). */
+int b2m_label_hist(const uint64_t* bits, int64_t words, const int32_t* rows, int32_t k, const int32_t* sem,
+                   int64_t n_vox, int32_t n_class, int32_t* labels, void* stream);
+
+/* Gather bits through an index (vox2point) into a byte mask: out[r*n_pts + p] = bit index[p] of row rows[r]
+ * (rows NULL = identity, index NULL = identity).
+ * Replaces pred_masks[:, vox2point], models/detection_net.py:469-471. */
+int b2m_mask_gather(const uint64_t* bits, int64_t words, const int32_t* rows, int32_t k,
+                    const int64_t* index, int64_t n_pts, uint8_t* out, void* stream);
+
+/* Pack k boolean (byte) mask rows of n elements into bit rows: bit v of bits[r*words + v/64].
+ * Input adaptor for b2m_mask_nms when the caller holds torch bool masks (mask_NMS, iou_nms.py:130). */
+int b2m_mask_pack(const uint8_t* masks, int32_t k, int64_t n, uint64_t* bits, int64_t words, void* stream);
+
+/* Row-wise IoU of two (n,6) [min,max] box sets: set_IOUs, models/iou_nms.py:4-22. */
+int b2m_set_ious(const float* a, const float* b, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

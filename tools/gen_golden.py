@@ -1,0 +1,227 @@
+"""Generate golden vectors from the REAL reference code (run in the build container only).
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+
+It imports /root/reference/models/iou_nms.py and utils/util.py unmodified, and drives
+SelectionNet.detection2mask / Model.compute_loss_detection through import stand-ins for the
+absent MinkowskiEngine / open3d modules (only needed so `import models.detection_net` succeeds;
+the two functions themselves use torch / numpy / scipy only — SURVEY.md Appendix B).
+Nothing from /root/reference is copied: the fixtures hold inputs and outputs only.
+This script is never needed on the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from box2mask_amd import synth  # noqa: E402
+
+
+def _install_stubs():
+    class Holder:
+        def __init__(self, F=None, C=None, **kw):
+            self.F, self.C = F, C
+
+    me = types.ModuleType('MinkowskiEngine')
+    me.SparseTensor = Holder
+    me.TensorField = Holder
+    me.MinkowskiConvolution = me.MinkowskiBatchNorm = me.MinkowskiReLU = object
+    mods = types.ModuleType('MinkowskiEngine.modules')
+    rb = types.ModuleType('MinkowskiEngine.modules.resnet_block')
+    rb.Bottleneck = type('Bottleneck', (), {'expansion': 4})
+    rb.BasicBlock = type('BasicBlock', (), {'expansion': 1})
+    sys.modules['MinkowskiEngine'] = me
+    sys.modules['MinkowskiEngine.modules'] = mods
+    sys.modules['MinkowskiEngine.modules.resnet_block'] = rb
+    sys.modules['open3d'] = types.ModuleType('open3d')
+    if 'tqdm' not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except ImportError:
+            t = types.ModuleType('tqdm'); t.tqdm = lambda x, **k: x; sys.modules['tqdm'] = t
+    return Holder
+
+
+def gen_iou_nms():
+    sys.path.insert(0, REF)
+    import models.iou_nms as R
+    import utils.util as U
+    rng = np.random.default_rng(7)
+    out = {}
+    cases = {}
+    for n, nobj in ((1, 1), (64, 6), (512, 30), (2000, 60)):
+        cases['votes%d' % n] = synth.make_votes(n, n_obj=nobj, n_seg=n)
+    # degenerate boxes: zero side length (the "Invalid boxes" warning path), identical boxes
+    b = synth.make_votes(91, n_obj=8, n_seg=200)
+    b[5, 4:] = b[5, 1:4]                     # zero volume
+    b[17, 4] = b[17, 1]                      # one zero side
+    b[30, 1:] = b[31, 1:]                    # identical geometry, different scores
+    b[40, 1:] = b[31, 1:]
+    cases['degenerate'] = b
+    # a box whose IoU with the top box equals the threshold exactly (kept in `remaining` by `<=`)
+    e = np.zeros((3, 7), np.float32)
+    e[0] = [0.9, 0, 0, 0, 1, 1, 1]
+    e[1] = [0.8, 0, 0, 0, 1, 1, 2]            # IoU = 1/(2+1e-6) < 0.5 ; use th computed from actual value
+    e[2] = [0.7, 5, 5, 5, 6, 6, 6]
+    cases['edge_th'] = e
+    for name, boxes in cases.items():
+        bt = torch.from_numpy(boxes)
+        th = 0.5
+        if name == 'edge_th':
+            th = float(R.torch_IOUs(bt[0, 1:], bt[:, 1:])[1])     # threshold == IoU exactly
+        reps, clusters, heat = R.NMS_clustering(bt, th)
+        out[name + '_boxes'] = boxes
+        out[name + '_th'] = np.float64(th)
+        out[name + '_reps'] = reps.numpy()
+        out[name + '_heat'] = heat.numpy()
+        out[name + '_assign'] = _assign(clusters, len(boxes))
+        out[name + '_order'] = np.concatenate([c.numpy() for c in clusters]) if False else np.zeros(0)
+        # mask NMS on the thresholded heat-maps in descending score order of the representatives
+        masks = heat > 0.3
+        kept, supp = R.mask_NMS(masks, 0.6)
+        out[name + '_masks'] = masks.numpy()
+        out[name + '_mask_kept'] = kept.numpy()
+    # set_IOUs / semIOU / to_bbs_min_max
+    a = np.sort(rng.uniform(0, 3, (300, 2, 3)).astype(np.float32), 1).reshape(300, 6)
+    c = np.sort(rng.uniform(0, 3, (300, 2, 3)).astype(np.float32), 1).reshape(300, 6)
+    out['set_a'], out['set_b'] = a, c
+    out['set_iou'] = R.set_IOUs(torch.from_numpy(a), torch.from_numpy(c)).numpy()
+    pl = rng.integers(0, 20, 500); gl = rng.integers(0, 20, 500); gl[rng.random(500) < 0.2] = -100
+    out['sem_pred'], out['sem_gt'] = pl, gl
+    out['sem_iou'] = R.semIOU(torch.from_numpy(pl), torch.from_numpy(gl))
+    loc = rng.normal(0, 1, (50, 3)).astype(np.float32); off = rng.normal(0, .3, (50, 3)).astype(np.float32)
+    bnd = rng.uniform(.05, .5, (50, 3)).astype(np.float32); sc = rng.random((50, 1)).astype(np.float32)
+    out['bbs_loc'], out['bbs_off'], out['bbs_bnd'], out['bbs_sc'] = loc, off, bnd, sc
+    out['bbs_out'] = U.to_bbs_min_max(*(torch.from_numpy(v) for v in (loc, off, bnd, sc))).numpy()
+    segs = [rng.integers(0, 9, 40), rng.integers(3, 14, 55), rng.integers(0, 5, 30)]
+    out['uniq_in0'], out['uniq_in1'], out['uniq_in2'] = segs
+    out['uniq_out'] = U.to_unique([s.copy() for s in segs]).numpy()
+    np.savez_compressed(os.path.join(OUT, 'iou_nms.npz'), **out)
+    print('iou_nms.npz: %d arrays' % len(out))
+
+
+def _assign(clusters, n):
+    a = np.full(n, -1, np.int32)
+    for c, idx in enumerate(clusters):
+        a[idx.numpy()] = c
+    return a
+
+
+def _scene_inputs(seed, n_scenes=2, target_voxels=12000):
+    """Synthetic batch + head outputs that vote for the scene's furniture boxes (so clusters are meaningful)."""
+    batch = synth.make_batch(n_scenes, seed0=seed, target_voxels=target_voxels, pts_per_m2=6000.0)
+    rng = np.random.default_rng(seed)
+    S = batch['input_location'].shape[0]
+    fg = batch['fg_instances'].numpy()
+    off = batch['gt_bb_offsets'].numpy() + rng.normal(0, 0.03, (S, 3)).astype(np.float32)
+    bnd = np.maximum(batch['gt_bb_bounds'].numpy() + rng.normal(0, 0.03, (S, 3)).astype(np.float32), 0.04)
+    bnd[~fg] = rng.uniform(0.05, 0.3, ((~fg).sum(), 3))
+    logits = rng.normal(0.5, 2.0, (S, 1)).astype(np.float32)
+    valid = synth.SCANNET_SEMANTIC_VALID_CLASS_IDS
+    sem_logits = rng.normal(0, 1, (S, len(valid))).astype(np.float32)
+    gt = batch['gt_semantics'].numpy()
+    for s in range(S):           # mostly-correct semantics so that foreground selection is realistic
+        if rng.random() < 0.9 and gt[s] in valid:
+            sem_logits[s, int(np.nonzero(valid == gt[s])[0][0])] += 6.0
+    pred = {'mlp_offsets': torch.from_numpy(off.astype(np.float32)), 'mlp_bounds': torch.from_numpy(bnd.astype(np.float32)),
+            'mlp_bb_scores': torch.from_numpy(logits), 'mlp_semantics': torch.from_numpy(sem_logits)}
+    return batch, pred
+
+
+def gen_detection2mask():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import models.detection_net as dn
+    valid, id2idx, _, is_fg = synth.scannet_tables()
+    cfg = SimpleNamespace(mlp_per_vox_semantics='mlp_per_vox_semantics', mlp_semantics='mlp_semantics',
+                          network_heads=['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics'],
+                          do_segment_pooling=True)
+    ns = SimpleNamespace(requires_voxel_outputs=False, semantic_valid_class_ids=valid, is_foreground=is_fg)
+    out = {}
+    for case, seed in (('a', 11), ('b', 23)):
+        batch, pred = _scene_inputs(seed)
+        ths = [0.5, 0.05, 0.3, 0.6]
+        for mode in ('eval', 'train'):
+            res = dn.SelectionNet.detection2mask(ns, batch, {k: v.clone() for k, v in pred.items()}, cfg, mode, True, *ths)
+            for si, sc in enumerate(batch['scene']):
+                r = res[sc['name']]
+                pre = 'd2m_%s_%s_s%d_' % (case, mode, si)
+                out[pre + 'conf'] = r['conf'].numpy()
+                out[pre + 'label_id'] = np.asarray(r['label_id'])
+                out[pre + 'mask'] = np.packbits(r['mask'].numpy(), axis=1)
+                out[pre + 'mask_shape'] = np.asarray(r['mask'].shape)
+                if mode != 'eval':
+                    out[pre + 'reps'] = r['cluster_representatives'].numpy()
+        for k, v in pred.items():
+            out['d2m_%s_pred_%s' % (case, k)] = v.numpy()
+        out['d2m_%s_input_location' % case] = batch['input_location'].numpy()
+        out['d2m_%s_batch_ids' % case] = batch['batch_ids'].numpy()
+        for si in range(len(batch['scene'])):
+            out['d2m_%s_seg2vox%d' % (case, si)] = np.asarray(batch['seg2vox'][si])
+            out['d2m_%s_vox2point%d' % (case, si)] = np.asarray(batch['vox2point'][si])
+        out['d2m_%s_names' % case] = np.asarray([s['name'] for s in batch['scene']])
+        out['d2m_%s_ths' % case] = np.asarray(ths)
+    np.savez_compressed(os.path.join(OUT, 'detection2mask.npz'), **out)
+    print('detection2mask.npz: %d arrays' % len(out))
+
+
+def gen_losses():
+    Holder = _install_stubs()
+    sys.path.insert(0, REF)
+    import models.model as M
+    valid, id2idx, _, is_fg = synth.scannet_tables()
+
+    class LUT:                                  # swallows the hard-coded .to('cuda') at model.py:199
+        def __init__(self, t): self.t = t
+        def __getitem__(self, i):
+            r = self.t[i]
+            return SimpleNamespace(to=lambda *_: r)
+
+    out = {}
+    for case, seed, epoch in (('a', 5, 150), ('b', 9, 3)):
+        batch, pred0 = _scene_inputs(seed)
+        pred = {k: v.clone().requires_grad_(True) for k, v in pred0.items()}
+        cfg = SimpleNamespace(mlp_offsets='mlp_offsets', mlp_bounds='mlp_bounds', mlp_bb_scores='mlp_bb_scores',
+                              mlp_center_scores='mlp_center_scores', mlp_semantics='mlp_semantics',
+                              mlp_per_vox_semantics='mlp_per_vox_semantics',
+                              network_heads=['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics'],
+                              loss_on_fg_instances=True, bb_supervision=True, use_bb_iou_loss=(case == 'b'),
+                              loss_weight_bb_offsets=1.0, loss_weight_bb_bounds=0.5, loss_weight_bb_iou=1.0,
+                              loss_weight_bb_scores=1.0, loss_weight_semantics=1.0, min_bb_size=0.04,
+                              mlp_bb_scores_start_epoch=100, mlp_center_scores_start_epoch=0)
+        ns = SimpleNamespace(cfg=cfg, device='cpu',
+                             detection_model=lambda sin, ids: {k: Holder(v) for k, v in pred.items()},
+                             BCEWithLogitsLoss=torch.nn.BCEWithLogitsLoss(),
+                             semantics_loss=torch.nn.CrossEntropyLoss(ignore_index=-100),
+                             semantic_id2idx=LUT(id2idx))
+        losses, _ = M.Model.compute_loss_detection(ns, batch, epoch)
+        losses['optimization_loss'].backward()
+        for k, v in losses.items():
+            out['loss_%s_%s' % (case, k)] = np.asarray(v.detach().numpy() if torch.is_tensor(v) else v, dtype=np.float64)
+        for k, v in pred.items():
+            out['loss_%s_pred_%s' % (case, k)] = pred0[k].numpy()
+            out['loss_%s_grad_%s' % (case, k)] = v.grad.numpy() if v.grad is not None else np.zeros_like(pred0[k].numpy())
+        for k in ('input_location', 'gt_bb_offsets', 'gt_bb_bounds', 'gt_semantics', 'fg_instances', 'pooling_ids'):
+            out['loss_%s_batch_%s' % (case, k)] = batch[k].numpy()
+        out['loss_%s_epoch' % case] = np.asarray(epoch)
+    np.savez_compressed(os.path.join(OUT, 'losses.npz'), **out)
+    print('losses.npz: %d arrays' % len(out))
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    gen_iou_nms()
+    gen_detection2mask()
+    gen_losses()
