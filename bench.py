@@ -1,0 +1,235 @@
+"""Benchmark of the hot path: ScanNet-shaped scenes/sec for one training step
+(coordinate/kernel-map build, forward, losses, backward, gradient all-reduce, Adam step).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: ScanNet 2 cm voxels, batch_size 8 per GPU, ~150 k voxels per scene,
+synthetic scenes (box2mask_amd/synth.py), random-init weights, fp32.  One JSON line on rank 0.
+`roofline` is measured live with HIP events around every launch of the dominant kernel
+(conv_fwd_kernel, forward + data-gradient) inside the timed region; `cpu_baseline` times the CPU
+oracle (kind "port": MinkowskiEngine itself is unavailable) on a bounded sample on rank 0 at N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+class LaunchTimer:
+    """Brackets selected b2m_* launches with HIP events on torch's current stream (the stream the
+    kernels are launched on) and keeps what is needed to compute algorithmic FLOPs afterwards."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []          # (name, start_event, end_event, meta)
+        self.enabled = False
+
+    def hook(self, name, args):
+        if not self.enabled or name not in self.names:
+            return None
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        if name == 'b2m_conv_fwd':
+            # x1, ldx1, c1, x2, ldx2, c2, w, ldw, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
+            meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12])
+        else:   # b2m_conv_wgrad: x, ldx, cin, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
+            meta = dict(cin=args[2], cout=args[5], K=args[10], n_out=args[9], rb_cnt=args[8])
+
+        def done():
+            e.record()
+            self.records.append((name, s, e, meta))
+        return done
+
+
+def pairs_of(meta, cache, rb_lookup):
+    """Total (in,out) pairs of the launch's kernel map (identity map: one pair per row)."""
+    if meta['rb_cnt'] is None:
+        return meta['n_out']
+    key = meta['rb_cnt']
+    if key not in cache:
+        cache[key] = rb_lookup[key].pairs if key in rb_lookup else 0
+    return cache[key]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch-size', type=int, default=8, help='scenes per GPU (configs/scannet.txt: 8)')
+    ap.add_argument('--target-voxels', type=int, default=150_000)
+    ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing')
+    ap.add_argument('--cpu-voxels', type=int, default=150_000, help='voxels of the CPU baseline sample scene')
+    args = ap.parse_args()
+
+    from box2mask_amd import _lib, synth
+    from box2mask_amd import sparse as sparse_mod
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    from box2mask_amd.parallel import init_distributed
+
+    rank, world = init_distributed()
+    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node == --gpus'
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    torch.manual_seed(1234)
+
+    cfg = scannet_config(multigpu=(world > 1), batch_size=args.batch_size)
+    model = Model(cfg, *synth.scannet_tables(), device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    model.train()
+
+    # ---- synthetic batch of this rank (weak scaling: every rank gets batch_size scenes), resident in HBM
+    t0 = time.time()
+    seeds0 = rank * args.batch_size
+    batch = synth.make_batch(args.batch_size, seed0=seeds0, target_voxels=args.target_voxels)
+    n_vox = int(batch['vox_coords'].shape[0])
+    for k in ('vox_coords', 'vox_features', 'pooling_ids', 'input_location', 'gt_bb_offsets', 'gt_bb_bounds',
+              'gt_semantics', 'fg_instances', 'batch_ids'):
+        batch[k] = batch[k].to(dev)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+
+    # keep every rulebook built during the timed steps reachable for the FLOP accounting
+    rb_lookup = {}
+    orig_init = sparse_mod.Rulebook.__init__
+
+    def rb_init(self, *a, **k):
+        orig_init(self, *a, **k)
+        rb_lookup[self.rb_cnt.data_ptr()] = self
+    sparse_mod.Rulebook.__init__ = rb_init
+
+    timer = LaunchTimer(['b2m_conv_fwd', 'b2m_conv_wgrad'])
+    _lib.set_hook(timer.hook)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        losses = model.compute_loss(batch, 150)
+        losses['optimization_loss'].backward()
+        model.sync_gradients()
+        opt.step()
+        return losses
+
+    for _ in range(args.warmup):
+        step()
+        rb_lookup.clear()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(losses['optimization_loss'].item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+        return
+
+    # ---- roofline of the dominant kernels from the live event timings
+    cache = {}
+    agg = {}
+    for name, s, e, meta in timer.records:
+        ms = s.elapsed_time(e)
+        P = pairs_of(meta, cache, rb_lookup)
+        flops = 2.0 * P * meta['cin'] * meta['cout']
+        a = agg.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
+        a['ms'] += ms; a['flops'] += flops; a['launches'] += 1
+
+    def roof(a):
+        tf = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] > 0 else 0.0
+        return {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'launches_per_step': a['launches'] // max(args.steps, 1),
+                'avg_launch_ms': round(a['ms'] / max(a['launches'], 1), 4),
+                'gflop_per_step': round(a['flops'] / max(args.steps, 1) / 1e9, 2),
+                'ms_per_step': round(a['ms'] / max(args.steps, 1), 3)}
+
+    fwd = agg.get('b2m_conv_fwd', dict(ms=0.0, flops=0.0, launches=0))
+    wg = agg.get('b2m_conv_wgrad', dict(ms=0.0, flops=0.0, launches=0))
+    roofline = roof(fwd)
+    roofline['kernel'] = 'conv_fwd_kernel<16> (forward + data gradient)'
+    roofline_wgrad = roof(wg)
+    roofline_wgrad['kernel'] = 'conv_wgrad_kernel'
+
+    scenes = world * args.batch_size * args.steps
+    value = scenes / elapsed
+    result = {
+        'metric': 'ScanNet scenes/sec (fwd+bwd, ~150k voxels @2cm)', 'value': round(value, 3), 'unit': 'scenes/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'ScanNet 2cm voxels, batch_size=%d per GPU, sparse-conv fwd/bwd + losses + Adam '
+                               '(BASELINE configs[1])' % args.batch_size,
+                   'global_batch': world * args.batch_size, 'voxels_per_scene': n_vox // args.batch_size,
+                   'voxels_per_gpu_batch': n_vox, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 4),
+                   'scene_gen_s': round(gen_s, 1)},
+        'roofline': roofline, 'roofline_wgrad': roofline_wgrad,
+    }
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
+    if args.cpu_baseline and world == 1:
+        result['cpu_baseline'] = cpu_baseline(cfg, args.cpu_voxels)
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+
+
+def cpu_baseline(cfg, voxels):
+    """fwd + losses-equivalent scalar + bwd of ONE synthetic scene on the CPU oracle (torch CPU,
+    per-offset index_select -> mm -> index_add_, all host cores)."""
+    from box2mask_amd import synth
+    from box2mask_amd.detection_net import SelectionNet
+    from oracle import unet_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    valid, _, _, is_fg = synth.scannet_tables()
+    torch.manual_seed(0)
+    net = SelectionNet(cfg, 'cpu', valid, is_fg, out_channels=[96, 96, 6])
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
+         for k, v in net.state_dict().items()}
+    b = synth.make_batch(1, seed0=0, target_voxels=voxels)
+    t0 = time.perf_counter()
+    out = unet_ref.forward(p, b['vox_coords'].numpy(), b['vox_features'], b['pooling_ids'], cfg, training=True,
+                           n_segments=b['input_location'].shape[0])
+    loss = sum(v.abs().mean() for k, v in out.items())
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {'value': round(1.0 / dt, 5), 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 synthetic scene of %d voxels (seed 0), coordinate/kernel-map build + forward + backward '
+                      'on the CPU oracle (oracle/unet_ref.py, torch %s, %d threads): %.1f s'
+                      % (b['vox_coords'].shape[0], torch.__version__, cores, dt)}
+
+
+if __name__ == '__main__':
+    main()

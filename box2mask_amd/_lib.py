@@ -91,10 +91,22 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# optional observer used by bench.py to bracket launches with HIP events: hook(name, args) -> finish()
+_hook = None
+
+
+def set_hook(fn):
+    global _hook
+    _hook = fn
+
+
 def call(name, *args):
     """Invoke a b2m_* entry on the current stream; raise B2MError on a negative return."""
     lib = load()
+    done = _hook(name, args) if _hook is not None else None
     rc = getattr(lib, name)(*args, stream())
+    if done is not None:
+        done()
     if rc != 0:
         raise B2MError('%s failed (%d): %s' % (name, rc, lib.b2m_last_error().decode()))
 

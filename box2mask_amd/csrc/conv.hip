@@ -1,14 +1,18 @@
 // Sparse convolution on the tile rulebook: forward / data-gradient (one kernel) and weight gradient.
 // fp32 in, fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain).
 //
-// Forward work decomposition: an ITEM is (tile of 128 output rows, strip of 32 output
-// channels) and belongs to ONE wave; the four waves of a workgroup take four consecutive items so that
-// their gathers share L1.  A wave walks the tile's active kernel offsets; for every offset the valid
-// (in,out) pairs are already compacted (rulebook), so MFMA row groups are dense: 16 pairs x 16 input
-// channels per step.  A comes straight from global memory (each lane owns one gathered row),
-// B (weights) straight from L2 into registers, and the 128x32 output strip accumulates in a wave-private
-// LDS region with ds_add_f32 -- no workgroup barrier anywhere.
+// Forward work decomposition: an ITEM is (tile of 64 output rows, strip of 32 output channels)
+// and belongs to ONE wave; the four waves of a workgroup take four consecutive items so that their gathers
+// share L1.  A wave walks the tile's active kernel offsets; for every offset the valid (in,out) pairs are
+// already compacted (rulebook), so the MFMA row groups are dense: up to 4 groups of 16 pairs.  A comes
+// straight from global memory (each lane owns one gathered row, 4 consecutive channels), B (weights)
+// straight from L2 into registers, the per-offset result accumulates in registers over all input-channel
+// chunks and is then added into the wave-private 64x32 output strip in LDS with plain read-modify-write
+// (LDS float atomics measured ~200 cycles per wave instruction: 5 TFLOP/s; never use them here).
+// No workgroup barrier anywhere; latency is covered by occupancy (8 KiB LDS, <=128 VGPRs: 4 waves/SIMD)
+// and by issuing two chunks of loads before the first MFMA block.
 #include "b2m_common.h"
+#include <stdlib.h>
 
 struct ConvArgs {
     const float* x1; int64_t ldx1; int c1;
@@ -20,12 +24,18 @@ struct ConvArgs {
     float* y; int64_t ldy; int cout; int accumulate; int nstrips; int vec_store; int a_scalar;
 };
 
+// loads of padded / out-of-range operands are redirected here (pointer select, no select on the loaded value)
+__device__ float g_zeros[64];
+
+static_assert(B2M_TILE == 64, "conv kernels assume 64-row tiles (4 row groups of 16)");
+#define NG 4     // row groups per tile
+
 __device__ __forceinline__ int cs_index(int row, int col) { return row * 32 + (col ^ ((row & 1) << 4)); }
 
-template <int KC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+template <int KC, bool IDENT, bool ASCALAR, bool PAIR>
+__global__ __launch_bounds__(256, PAIR ? 3 : 4) void conv_fwd_kernel(ConvArgs a) {
     constexpr int KS = KC / 4;                // k-steps per chunk == floats per lane per gathered row
-    extern __shared__ float smem[];
+    __shared__ float smem[4 * B2M_TILE * 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
@@ -37,7 +47,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     const int nchunk = (cin + KC - 1) / KC;
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int64_t row0 = tile * B2M_TILE;
-    const bool identity = a.rb_in == nullptr;
     float* Cs = smem + wave * (B2M_TILE * 32);
 
     // ---- init the strip: 0 | Y (accumulate) | + bias
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 
     // ---- active offsets of this tile (K <= 128): lane k holds the pair count of offset k / k+64
     int cnt0 = 0, cnt1 = 0;
-    if (identity) {
+    if (IDENT) {
         int64_t rem = a.n_out - row0;
         if (lane == 0) cnt0 = rem < B2M_TILE ? (int)rem : B2M_TILE;
     } else {
@@ -67,142 +76,129 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
     }
     uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
-    auto next_active = [&]() -> int {
-        int k;
-        if (m0) { k = __builtin_ctzll(m0); m0 &= m0 - 1; }
-        else if (m1) { k = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
-        else k = -1;
-        return k;
-    };
-    auto get_cnt = [&](int k) -> int {
-        return k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
-    };
-    auto load_idx = [&](int k, int n, int (&idx)[8], uint32_t (&out)[8]) {
-        const int G = (n + 15) >> 4;
-        const int64_t base = (int64_t)k * ldr + row0;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            idx[g] = -1; out[g] = 0;
-            if (g < G) {
-                if (identity) {
-                    int64_t r = row0 + 16 * g + i;
-                    idx[g] = r < a.n_out ? (int)r : -1;
-                    const int p = 16 * g + 4 * q;
-                    out[g] = (uint32_t)p | ((uint32_t)(p + 1) << 8) | ((uint32_t)(p + 2) << 16) | ((uint32_t)(p + 3) << 24);
-                } else {
-                    idx[g] = a.rb_in[base + 16 * g + i];
-                    out[g] = *(const uint32_t*)(a.rb_out + base + 16 * g + 4 * q);
-                }
-            }
-        }
-    };
-    auto load_a = [&](float (&av)[8][KS], const int (&idx)[8], int n, int c) {
-        const int G = (n + 15) >> 4;
+
+    // one chunk of operands: B = weights of (offset, chunk), A = gathered rows of the 4 row groups.
+    // All loads are unconditional (pointer select to a zero buffer), so their number is static.
+    auto load_chunk = [&](float (&av)[NG][KS], float (&bv)[KS][2], const int (&idx)[NG], int k, int c) {
         const int cb = c * KC;
+        const bool cv = c < nchunk;            // wave-uniform: the second chunk of the last pair may not exist
         const float* src; int64_t ld; int cl, climit;
         if (cb < a.c1) { src = a.x1; ld = a.ldx1; cl = cb + KS * q; climit = a.c1; }
         else { src = a.x2; ld = a.ldx2; cl = cb - a.c1 + KS * q; climit = a.c2; }
-        const bool vc = cl < climit;
+        const bool vc = cv && cl < climit;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int s = 0; s < KS; ++s) {
+            const int ci = cb + KS * q + s;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) av[g][s] = 0.f;
-            if (g < G) {
-                const int r = idx[g];
-                if (r >= 0 && a.a_scalar) {                      // odd channel counts (head gradients): per-element
-                    const float* p = src + (int64_t)r * ld + cl;
+            for (int t = 0; t < 2; ++t) {
+                const int col = col0 + 16 * t + i;
+                const float* p = a.w + ((int64_t)k * cin + ci) * a.ldw + col;
+                bv[s][t] = *((cv && ci < cin && col < a.cout) ? p : g_zeros);
+            }
+        }
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) if (cl + s < climit) av[g][s] = p[s];
-                } else if (r >= 0 && vc) {
-                    const float* p = src + (int64_t)r * ld + cl;
-                    if constexpr (KS == 4) {
-                        f32x4 v = *(const f32x4*)p;
-                        av[g][0] = v[0]; av[g][1] = v[1]; av[g][2] = v[2]; av[g][3] = v[3];
-                    } else {
-                        f32x2 v = *(const f32x2*)p;
-                        av[g][0] = v[0]; av[g][1] = v[1];
+        for (int g = 0; g < NG; ++g) {
+            const int r = idx[g];
+            const float* p = src + (int64_t)r * ld + cl;
+            if constexpr (ASCALAR) {           // odd channel counts (head gradients): per-element
+#pragma unroll
+                for (int s = 0; s < KS; ++s) av[g][s] = *((r >= 0 && cv && cl + s < climit) ? p + s : g_zeros);
+            } else if constexpr (KS == 4) {
+                const f32x4 v = *(const f32x4*)((r >= 0 && vc) ? p : g_zeros);
+                av[g][0] = v[0]; av[g][1] = v[1]; av[g][2] = v[2]; av[g][3] = v[3];
+            } else {
+                const f32x2 v = *(const f32x2*)((r >= 0 && vc) ? p : g_zeros);
+                av[g][0] = v[0]; av[g][1] = v[1];
+            }
+        }
+    };
+
+    for (;;) {
+        int k;
+        if (m0) { k = __builtin_ctzll(m0); m0 &= m0 - 1; }
+        else if (m1) { k = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+        else break;
+        const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
+        const int G = (n + 15) >> 4;           // 1..4 dense row groups
+        // pair lists: lane (i,q) gathers input row idx[g] and later flushes the 4 output rows packed in out[g]
+        int idx[NG]; uint32_t out[NG];
+        const int64_t base = (int64_t)k * ldr + row0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (IDENT) {
+                int64_t r = row0 + 16 * g + i;
+                idx[g] = r < a.n_out ? (int)r : -1;
+                const int p = 16 * g + 4 * q;
+                out[g] = (uint32_t)p | ((uint32_t)(p + 1) << 8) | ((uint32_t)(p + 2) << 16) | ((uint32_t)(p + 3) << 24);
+            } else {                           // slots beyond the pair count hold -1 / 0 by construction
+                idx[g] = a.rb_in[base + 16 * g + i];
+                out[g] = *(const uint32_t*)(a.rb_out + base + 16 * g + 4 * q);
+            }
+        }
+        f32x4 acc[NG][2];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+        if constexpr (PAIR) {
+            // two chunks of loads in flight before the first MFMA block (<=168 VGPRs, 3 waves per SIMD)
+            for (int c = 0; c < nchunk; c += 2) {
+                float av0[NG][KS], bv0[KS][2], av1[NG][KS], bv1[KS][2];
+                load_chunk(av0, bv0, idx, k, c);
+                load_chunk(av1, bv1, idx, k, c + 1);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g < G) {                        // wave-uniform
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g][s], bv0[s][0], acc[g][0], 0, 0, 0);
+                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g][s], bv0[s][1], acc[g][1], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g < G) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[g][s], bv1[s][0], acc[g][0], 0, 0, 0);
+                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[g][s], bv1[s][1], acc[g][1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+            // one chunk at a time (<=128 VGPRs, 4 waves per SIMD)
+            for (int c = 0; c < nchunk; ++c) {
+                float av0[NG][KS], bv0[KS][2];
+                load_chunk(av0, bv0, idx, k, c);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g < G) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g][s], bv0[s][0], acc[g][0], 0, 0, 0);
+                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g][s], bv0[s][1], acc[g][1], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
-    };
-    auto load_b = [&](float (&bv)[KS][2], int k, int c) {
+        // ---- add the offset's result into the strip.  D[row = 4q + r][col = i]; the pairs of one offset have
+        // distinct output rows, and padded pairs (A == 0 -> acc == 0) are skipped, so no two lanes of an
+        // instruction touch the same address: plain read-modify-write is race free inside the wave.
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int ci = c * KC + KS * q + s;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int col = col0 + 16 * t + i;
-                bv[s][t] = (ci < cin && col < a.cout) ? a.w[((int64_t)k * cin + ci) * a.ldw + col] : 0.f;
-            }
-        }
-    };
-    auto compute = [&](const float (&av)[8][KS], const float (&bv)[KS][2], const uint32_t (&out)[8], int n) {
-        const int G = (n + 15) >> 4;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int g = 0; g < NG; ++g) {
             if (g < G) {
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][s], bv[s][0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][s], bv[s][1], acc1, 0, 0, 0);
-                }
                 const uint32_t o4 = out[g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (16 * g + 4 * q + r < n) {
                         const int row = (o4 >> (8 * r)) & 255;
-                        atomicAdd(&Cs[cs_index(row, i)], acc0[r]);
-                        atomicAdd(&Cs[cs_index(row, 16 + i)], acc1[r]);
+                        Cs[cs_index(row, i)] += acc[g][0][r];
+                        Cs[cs_index(row, 16 + i)] += acc[g][1][r];
                     }
                 }
             }
-        }
-    };
-
-    int k = next_active();
-    if (k >= 0) {
-        int n = get_cnt(k);
-        int idxc[8], idxn[8];
-        uint32_t outc[8], outn[8];
-        load_idx(k, n, idxc, outc);
-        int k2 = next_active();
-        int n2 = k2 >= 0 ? get_cnt(k2) : 0;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) { idxn[g] = -1; outn[g] = 0; }
-        if (k2 >= 0) load_idx(k2, n2, idxn, outn);
-        float ac[8][KS], bc[KS][2];
-        load_a(ac, idxc, n, 0);
-        load_b(bc, k, 0);
-        int c = 0;
-        for (;;) {
-            float an[8][KS], bn[KS][2];
-            const bool same = c + 1 < nchunk;
-            const int nk = same ? k : k2;
-            if (nk >= 0) {
-                if (same) { load_a(an, idxc, n, c + 1); load_b(bn, k, c + 1); }
-                else { load_a(an, idxn, n2, 0); load_b(bn, k2, 0); }
-            }
-            compute(ac, bc, outc, n);
-            if (nk < 0) break;
-            if (!same) {
-                k = k2; n = n2;
-#pragma unroll
-                for (int g = 0; g < 8; ++g) { idxc[g] = idxn[g]; outc[g] = outn[g]; }
-                k2 = next_active();
-                n2 = k2 >= 0 ? get_cnt(k2) : 0;
-                if (k2 >= 0) load_idx(k2, n2, idxn, outn);
-                c = 0;
-            } else {
-                ++c;
-            }
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) ac[g][s] = an[g][s];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { bc[s][0] = bn[s][0]; bc[s][1] = bn[s][1]; }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -253,15 +249,21 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     a.a_scalar = aligned ? 0 : 1;
     const int64_t items = a.ntiles * a.nstrips;
     const unsigned grid = (unsigned)cdiv64(items, 4);
-    const size_t lds = 4 * B2M_TILE * 32 * sizeof(float);     // 64 KiB: two workgroups per CU
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    const bool ident = rb_in == nullptr;
+    const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (a.a_scalar ? 1 : 0);
+    static int pair = -1;                       // B2M_CONV_PAIR=0/1 selects the chunk pipelining variant
+    if (pair < 0) { const char* e = getenv("B2M_CONV_PAIR"); pair = e ? (atoi(e) != 0) : 0; }
+#define B2M_CONV_CASE(V, KCV, ID, AS)                                             \
+    case V:                                                                       \
+        if (pair) conv_fwd_kernel<KCV, ID, AS, true><<<grid, 256, 0, st>>>(a);    \
+        else conv_fwd_kernel<KCV, ID, AS, false><<<grid, 256, 0, st>>>(a);        \
+        break;
+    switch (variant) {
+        B2M_CONV_CASE(0, 8, false, false) B2M_CONV_CASE(1, 8, false, true) B2M_CONV_CASE(2, 8, true, false)
+        B2M_CONV_CASE(3, 8, true, true) B2M_CONV_CASE(4, 16, false, false) B2M_CONV_CASE(5, 16, false, true)
+        B2M_CONV_CASE(6, 16, true, false) B2M_CONV_CASE(7, 16, true, true)
     }
-    if (KC == 16) conv_fwd_kernel<16><<<grid, 256, lds, st>>>(a);
-    else conv_fwd_kernel<8><<<grid, 256, lds, st>>>(a);
+#undef B2M_CONV_CASE
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

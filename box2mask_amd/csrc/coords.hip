@@ -247,7 +247,9 @@ extern "C" int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int
 }
 
 // ------------------------------------------------------------------ tile rulebook
-// one wave per tile of 128 output rows; per offset two ballots compact the valid pairs in row order
+// one wave per tile of B2M_TILE (= 64) output rows: lane = row; per offset one ballot compacts the valid
+// pairs in row order
+static_assert(B2M_TILE == 64, "the rulebook kernel maps one lane to one tile row");
 __global__ __launch_bounds__(64) void rulebook_kernel(const int32_t* __restrict__ nbr, int64_t ld, int32_t K,
                                                       int64_t n_out, int64_t ntiles, int32_t* __restrict__ rb_in,
                                                       uint8_t* __restrict__ rb_out, int32_t* __restrict__ rb_cnt,
@@ -255,18 +257,16 @@ __global__ __launch_bounds__(64) void rulebook_kernel(const int32_t* __restrict_
     const int64_t t = blockIdx.x;
     const int lane = lane_id();
     const int64_t ldr = ntiles * B2M_TILE;
-    const int64_t o0 = t * B2M_TILE + lane, o1 = o0 + 64;
+    const int64_t o = t * B2M_TILE + lane;
     for (int k = 0; k < K; ++k) {
-        int v0 = o0 < n_out ? nbr[(int64_t)k * ld + o0] : -1;
-        int v1 = o1 < n_out ? nbr[(int64_t)k * ld + o1] : -1;
-        uint64_t b0 = __ballot(v0 >= 0), b1 = __ballot(v1 >= 0);
-        int c0 = __popcll(b0), c1 = __popcll(b1);
-        int64_t base = (int64_t)k * ldr + t * B2M_TILE;
-        if (v0 >= 0) { int p = prefix_popc(b0); rb_in[base + p] = v0; rb_out[base + p] = (uint8_t)lane; }
-        if (v1 >= 0) { int p = c0 + prefix_popc(b1); rb_in[base + p] = v1; rb_out[base + p] = (uint8_t)(lane + 64); }
+        const int v = o < n_out ? nbr[(int64_t)k * ld + o] : -1;
+        const uint64_t b = __ballot(v >= 0);
+        const int c = __popcll(b);
+        const int64_t base = (int64_t)k * ldr + t * B2M_TILE;
+        if (v >= 0) { const int p = prefix_popc(b); rb_in[base + p] = v; rb_out[base + p] = (uint8_t)lane; }
         if (lane == 0) {
-            rb_cnt[(int64_t)k * ntiles + t] = c0 + c1;
-            if (pair_total && c0 + c1) atomicAdd(&pair_total[k], c0 + c1);
+            rb_cnt[(int64_t)k * ntiles + t] = c;
+            if (pair_total && c) atomicAdd(&pair_total[k], c);
         }
     }
 }

@@ -33,8 +33,8 @@ __global__ void set_ious_kernel(const float* __restrict__ a, const float* __rest
     out[i] = box_iou(x, y);
 }
 extern "C" int b2m_set_ious(const float* a, const float* b, int64_t n, float* out, void* stream) {
-    B2M_CHECK_ARG(a && b && out && n >= 0, "bad arguments");
     if (n == 0) return B2M_OK;
+    B2M_CHECK_ARG(a && b && out && n > 0, "bad arguments");
     set_ious_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, out);
     B2M_LAUNCH_CHECK();
     return B2M_OK;

@@ -128,22 +128,29 @@ class SelectionNet(ResNetBase):
         """x: SparseTensor at tensor stride 1 -> dict head-name -> tensor holder with `.F`
         (detection_net.py:234-364)."""
         cbr = self._cbr
-        out_p1 = cbr(self.conv0p1s1, self.bn0, x)
-        out_b1p2 = self.block1(cbr(self.conv1p1s2, self.bn1, out_p1))
-        out_b2p4 = self.block2(cbr(self.conv2p2s2, self.bn2, out_b1p2))
-        out_b3p8 = self.block3(cbr(self.conv3p4s2, self.bn3, out_b2p4))
-        out_b4p16 = self.block4(cbr(self.conv4p8s2, self.bn4, out_b3p8))
-        out_added_b1p32 = self.added_block1(cbr(self.added_conv1p16s2, self.added_bn1, out_b4p16))
-        out_added_b2p64 = self.added_block2(cbr(self.added_conv2p32s2, self.added_bn2, out_added_b1p32))
-        out = self.added_block3(cbr(self.added_conv3p64s2, self.added_bn3, out_added_b2p64))
+        tr = getattr(self, '_trace', None)          # optional dict: named intermediates for parity debugging
 
-        out = self.added_block4(ME.cat(cbr(self.added_convtr4p128s2, self.added_bntr4, out), out_added_b2p64))
-        out = self.added_block5(ME.cat(cbr(self.added_convtr5p64s2, self.added_bntr5, out), out_added_b1p32))
-        out = self.added_block6(ME.cat(cbr(self.added_convtr6p32s2, self.added_bntr6, out), out_b4p16))
-        out = self.block5(ME.cat(cbr(self.convtr4p16s2, self.bntr4, out), out_b3p8))
-        out = self.block6(ME.cat(cbr(self.convtr5p8s2, self.bntr5, out), out_b2p4))
-        out = self.block7(ME.cat(cbr(self.convtr6p4s2, self.bntr6, out), out_b1p2))
-        out = self.block8(ME.cat(cbr(self.convtr7p2s2, self.bntr7, out), out_p1))
+        def T(name, t):
+            if tr is not None:
+                tr[name] = t.F
+            return t
+
+        out_p1 = T('out_p1', cbr(self.conv0p1s1, self.bn0, x))
+        out_b1p2 = T('block1', self.block1(T('down1', cbr(self.conv1p1s2, self.bn1, out_p1))))
+        out_b2p4 = T('block2', self.block2(T('down2', cbr(self.conv2p2s2, self.bn2, out_b1p2))))
+        out_b3p8 = T('block3', self.block3(T('down3', cbr(self.conv3p4s2, self.bn3, out_b2p4))))
+        out_b4p16 = T('block4', self.block4(T('down4', cbr(self.conv4p8s2, self.bn4, out_b3p8))))
+        out_added_b1p32 = T('added_block1', self.added_block1(T('down5', cbr(self.added_conv1p16s2, self.added_bn1, out_b4p16))))
+        out_added_b2p64 = T('added_block2', self.added_block2(T('down6', cbr(self.added_conv2p32s2, self.added_bn2, out_added_b1p32))))
+        out = T('added_block3', self.added_block3(T('down7', cbr(self.added_conv3p64s2, self.added_bn3, out_added_b2p64))))
+
+        out = T('added_block4', self.added_block4(ME.cat(T('up6', cbr(self.added_convtr4p128s2, self.added_bntr4, out)), out_added_b2p64)))
+        out = T('added_block5', self.added_block5(ME.cat(T('up5', cbr(self.added_convtr5p64s2, self.added_bntr5, out)), out_added_b1p32)))
+        out = T('added_block6', self.added_block6(ME.cat(T('up4', cbr(self.added_convtr6p32s2, self.added_bntr6, out)), out_b4p16)))
+        out = T('block5', self.block5(ME.cat(T('up3', cbr(self.convtr4p16s2, self.bntr4, out)), out_b3p8)))
+        out = T('block6', self.block6(ME.cat(T('up2', cbr(self.convtr5p8s2, self.bntr5, out)), out_b2p4)))
+        out = T('block7', self.block7(ME.cat(T('up1', cbr(self.convtr6p4s2, self.bntr6, out)), out_b1p2)))
+        out = T('block8', self.block8(ME.cat(T('up0', cbr(self.convtr7p2s2, self.bntr7, out)), out_p1)))
 
         outputs = {}
         if self.requires_voxel_outputs:

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 
-TILE = 128
+TILE = 64       # B2M_TILE of include/b2m.h
 
 
 def _pow2_at_least(n: int) -> int:
@@ -25,7 +25,7 @@ def _pow2_at_least(n: int) -> int:
 
 
 class Rulebook:
-    """Tile rulebook of one kernel map: for every (offset k, tile of 128 output rows) the valid
+    """Tile rulebook of one kernel map: for every (offset k, tile of TILE output rows) the valid
     (input row, output row) pairs, compacted in output-row order (include/b2m.h: b2m_rulebook)."""
 
     def __init__(self, nbr: torch.Tensor, K: int, n_out: int, n_in: int, keep_table: bool = False):

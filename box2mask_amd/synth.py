@@ -76,7 +76,7 @@ def make_scene(seed: int, target_voxels: int = 150_000, voxel_size: float = 0.02
     boxes = []
     target_area = target_voxels / vox_per_m2
     for b in range(n_box):
-        if area > 0.85 * target_area - 0.3 * 2 * (L + W):      # leave room for >= 0.3 m of wall
+        if b >= 3 and area > 0.85 * target_area - 0.3 * 2 * (L + W):   # leave room for >= 0.3 m of wall
             break
         sx, sy = rng.uniform(0.3, 1.2, 2) * min(scale, 1.0)
         sz = rng.uniform(0.3, 1.0) * min(scale, 1.0)

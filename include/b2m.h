@@ -14,7 +14,7 @@
  *   - return value: 0 = ok, negative = error (b2m_last_error() gives a thread-local message)
  *   - coordinates: int32 rows [b,x,y,z], all fields in [0, 65535]; features: fp32 row-major with
  *     an explicit leading dimension (in floats)
- *   - TILE = 128 output rows is the unit of the "tile rulebook" 
+ *   - B2M_TILE = 64 output rows is the unit of the "tile rulebook" 
  */
 #ifndef B2M_H
 #define B2M_H
@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define B2M_TILE 128
+#define B2M_TILE 64
 #define B2M_OK 0
 #define B2M_ERR_ARG (-1)
 #define B2M_ERR_HIP (-2)
@@ -72,12 +72,12 @@ int b2m_kernel_map(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts,
 int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int64_t n_fine, int64_t n_coarse,
                       int32_t* child, int64_t ld_c, int32_t* up, int64_t ld_f, void* stream);
 
-/* Tile rulebook: per (offset k, tile t of 128 output rows) the valid pairs compacted in row order.
- *   rb_in [k*ldr + t*128 + j]  input row of pair j      (-1 beyond the count)
- *   rb_out[k*ldr + t*128 + j]  output row - t*128       (0 beyond the count)
+/* Tile rulebook: per (offset k, tile t of B2M_TILE output rows) the valid pairs compacted in row order.
+ *   rb_in [k*ldr + t*TILE + j]  input row of pair j      (-1 beyond the count)
+ *   rb_out[k*ldr + t*TILE + j]  output row - t*TILE      (0 beyond the count)
  *   rb_cnt[k*ntiles + t]       number of pairs
  *   pair_total[K]              pairs per offset (may be NULL)
- * ldr = ntiles*128, ntiles = ceil(n_out/128). */
+ * ldr = ntiles*TILE, ntiles = ceil(n_out/TILE). */
 int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out,
                  int32_t* rb_in, uint8_t* rb_out, int32_t* rb_cnt, int32_t* pair_total, void* stream);
 
@@ -106,7 +106,7 @@ int b2m_weight_transpose(const float* w, int64_t ldw, int32_t K, int32_t cin, in
 
 /* dW[k][ci][co] += sum over pairs (i,o) of offset k:  X[i, ci] * dY[o, co]     (fp32 atomics)
  * Replaces [ME] ConvolutionBackward (weight part).  x: rows indexed by rb_in (ldx, cin columns used),
- * dy: rows indexed by tile*128+rb_out.  dw element (k,ci,co) lives at dw[k*dw_kstride + ci*lddw + co]
+ * dy: rows indexed by tile*TILE+rb_out.  dw element (k,ci,co) lives at dw[k*dw_kstride + ci*lddw + co]
  * (so a channel sub-block of a wider weight tensor can be targeted); the caller zeroes it. */
 int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const float* dy, int64_t lddy, int32_t cout,
                    const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,

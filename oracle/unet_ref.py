@@ -57,7 +57,7 @@ HEAD_ATTR = {'mlp_offsets': 'mlp_offsets', 'mlp_bounds': 'mlp_bounds', 'mlp_bb_s
 
 
 def forward(p, coords, feats, pooling_ids, cfg, training=True, hier: S.Hierarchy | None = None, n_segments=None,
-            return_trunk=False):
+            return_trunk=False, trace=None):
     """p: dict name -> CPU tensor (the product's state_dict moved to the CPU).  Returns head -> tensor."""
     h = hier if hier is not None else S.Hierarchy(coords)
     L = cfg.layers
@@ -66,24 +66,29 @@ def forward(p, coords, feats, pooling_ids, cfg, training=True, hier: S.Hierarchy
     def cbr(conv, bn, x, nbr):
         return torch.relu(_bn(p, bn, S.conv_nbr(x, p[conv + '.kernel'], nbr), training))
 
-    out_p1 = cbr('conv0p1s1', 'bn0', x, h.k_first())
+    def T(name, t):
+        if trace is not None:
+            trace[name] = t
+        return t
+
+    out_p1 = T('out_p1', cbr('conv0p1s1', 'bn0', x, h.k_first()))
     enc = [out_p1]
     names = [('conv1p1s2', 'bn1', 'block1'), ('conv2p2s2', 'bn2', 'block2'), ('conv3p4s2', 'bn3', 'block3'),
              ('conv4p8s2', 'bn4', 'block4'), ('added_conv1p16s2', 'added_bn1', 'added_block1'),
              ('added_conv2p32s2', 'added_bn2', 'added_block2'), ('added_conv3p64s2', 'added_bn3', 'added_block3')]
     out = out_p1
     for l, (c, b, blk) in enumerate(names):          # level l -> l+1
-        out = cbr(c, b, out, h.down(l))
-        out = _layer(p, blk, out, h.k3(l + 1), training, L)
+        out = T('down%d' % (l + 1), cbr(c, b, out, h.down(l)))
+        out = T(blk, _layer(p, blk, out, h.k3(l + 1), training, L))
         enc.append(out)
     ups = [('added_convtr4p128s2', 'added_bntr4', 'added_block4'), ('added_convtr5p64s2', 'added_bntr5', 'added_block5'),
            ('added_convtr6p32s2', 'added_bntr6', 'added_block6'), ('convtr4p16s2', 'bntr4', 'block5'),
            ('convtr5p8s2', 'bntr5', 'block6'), ('convtr6p4s2', 'bntr6', 'block7'), ('convtr7p2s2', 'bntr7', 'block8')]
     for j, (c, b, blk) in enumerate(ups):            # level 7-j -> 6-j
         l = 6 - j
-        out = cbr(c, b, out, h.up(l))
+        out = T('up%d' % l, cbr(c, b, out, h.up(l)))
         out = torch.cat([out, enc[l]], 1)            # ME.cat(upsampled, skip): detection_net.py:286-336
-        out = _layer(p, blk, out, h.k3(l), training, L)
+        out = T(blk, _layer(p, blk, out, h.k3(l), training, L))
     trunk = out
     outputs = {}
     per_vox = any('per_vox' in hd for hd in cfg.network_heads)

@@ -1,0 +1,113 @@
+"""GPU parity: coordinate maps, kernel maps and tile rulebooks are bit-exact against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode_rulebook(rb):
+    """tile rulebook -> neighbour table (K, n_out)."""
+    from box2mask_amd.sparse import TILE
+    K, n_out, nt = rb.K, rb.n_out, rb.ntiles
+    ldr = nt * TILE
+    rin = rb.rb_in[:K * ldr].cpu().numpy().reshape(K, nt, TILE)
+    rout = rb.rb_out[:K * ldr].cpu().numpy().reshape(K, nt, TILE)
+    cnt = rb.rb_cnt[:K * nt].cpu().numpy().reshape(K, nt)
+    nbr = np.full((K, nt * TILE), -1, np.int32)
+    for k in range(K):
+        for t in range(nt):
+            c = cnt[k, t]
+            assert (rin[k, t, c:] == -1).all() and (rout[k, t, c:] == 0).all()
+            o = rout[k, t, :c].astype(np.int64)
+            assert (np.diff(o) > 0).all()                      # compacted in output-row order
+            nbr[k, t * TILE + o] = rin[k, t, :c]
+    return nbr[:, :n_out], int(cnt.sum())
+
+
+def _check(coords, levels=4, k0=5):
+    from box2mask_amd.sparse import CoordinateManager
+    from oracle import sparse_ref as S
+    m = CoordinateManager(torch.from_numpy(coords), keep_tables=True)
+    h = S.Hierarchy(coords, n_levels=levels, k0=k0)
+    assert int(m.dup_count.item()) == 0
+    for l in range(levels):
+        assert np.array_equal(m.coords[l].cpu().numpy(), h.coords[l]), 'level %d coords' % l
+        if l + 1 < levels:
+            m.ensure_level(l + 1)
+            assert np.array_equal(m.parent[l].cpu().numpy(), h.parent[l])
+            assert np.array_equal(m.koff[l].cpu().numpy(), h.koff[l])
+        rb = m.rulebook_same(l, 3)
+        assert np.array_equal(rb.nbr.cpu().numpy()[:, :h.n(l)], h.k3(l)), 'level %d k3 map' % l
+        dec, pairs = _decode_rulebook(rb)
+        assert np.array_equal(dec, h.k3(l)) and pairs == int((h.k3(l) >= 0).sum()) == rb.pairs
+    rb5 = m.rulebook_same(0, k0)
+    assert np.array_equal(rb5.nbr.cpu().numpy()[:, :h.n(0)], h.k_first())
+    assert np.array_equal(_decode_rulebook(rb5)[0], h.k_first())
+    for l in range(levels - 1):
+        assert np.array_equal(_decode_rulebook(m.rulebook_down(l))[0], h.down(l)), 'down %d' % l
+        assert np.array_equal(_decode_rulebook(m.rulebook_up(l))[0], h.up(l)), 'up %d' % l
+    return m, h
+
+
+def test_random_coords():
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 60, (20000, 4)).astype(np.int32)
+    c[:, 0] %= 3
+    c = np.unique(c, axis=0)          # lexicographic, as np.unique in the reference data loader
+    _check(c, levels=5)
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 127, 128, 129, 300])
+def test_ragged_sizes(n):
+    rng = np.random.default_rng(n)
+    c = rng.integers(0, 12, (4 * n, 4)).astype(np.int32)
+    c[:, 0] = 0
+    c = np.unique(c, axis=0)[:n]
+    _check(c, levels=3)
+
+
+def test_synthetic_scene_batch():
+    from box2mask_amd import synth
+    b = synth.make_batch(2, seed0=1, target_voxels=12000, pts_per_m2=6000.0)
+    m, h = _check(b['vox_coords'].numpy(), levels=8)
+    assert [m.n(l) for l in range(8)] == [h.n(l) for l in range(8)]
+
+
+def test_duplicates_are_counted_and_bounds_checked():
+    from box2mask_amd.sparse import CoordinateManager
+    c = np.array([[0, 1, 1, 1], [0, 1, 1, 1], [0, 2, 2, 2]], np.int32)
+    m = CoordinateManager(torch.from_numpy(c))
+    assert int(m.dup_count.item()) == 1
+    with pytest.raises(ValueError):
+        CoordinateManager(torch.tensor([[0, -1, 0, 0]], dtype=torch.int32))
+    with pytest.raises(ValueError):
+        CoordinateManager(torch.tensor([[0, 70000, 0, 0]], dtype=torch.int32))
+
+
+def test_full_size_scene_properties():
+    """BASELINE size (150k voxels): size-independent properties instead of the slow oracle."""
+    from box2mask_amd import synth
+    from box2mask_amd.sparse import CoordinateManager
+    sc = synth.make_scene(0)
+    c = synth.batched_coordinates([sc['vox_coords']])
+    m = CoordinateManager(c, keep_tables=True)
+    rb = m.rulebook_same(0, 3)
+    nbr = rb.nbr.cpu().numpy()
+    n = m.n(0)
+    assert np.array_equal(nbr[13], np.arange(n))                      # centre offset = identity
+    for k in (0, 5, 12):                                              # mirror symmetry
+        o = np.nonzero(nbr[k] >= 0)[0]
+        assert np.array_equal(nbr[26 - k][nbr[k][o]], o)
+    cc = m.coords[0].cpu().numpy()
+    offs = np.array([[(k % 3) - 1, (k // 3) % 3 - 1, k // 9 - 1] for k in range(27)])
+    for k in (1, 20):
+        o = np.nonzero(nbr[k] >= 0)[0][:5000]
+        assert np.array_equal(cc[nbr[k][o]][:, 1:], cc[o][:, 1:] + offs[k])
+    m.ensure_level(7)
+    ns = [m.n(l) for l in range(8)]
+    assert all(a > b for a, b in zip(ns, ns[1:]))
+    tot = 0
+    for l in range(7):
+        tot = m.rulebook_down(l).pairs
+        assert tot == m.n(l)                                          # every fine voxel is exactly one pair

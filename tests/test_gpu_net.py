@@ -1,0 +1,165 @@
+"""GPU parity of the whole SelectionNet (forward, backward) against the oracle U-Net, the reference
+loss formulas against golden vectors, and the drop-in surface (state-dict layout)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from box2mask_amd import synth
+from box2mask_amd.config import scannet_config
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-9)
+
+
+def test_state_dict_layout_cpu():
+    """Key names / shapes of the drop-in contract; needs no GPU."""
+    from box2mask_amd.detection_net import SelectionNet
+    valid, _, _, is_fg = synth.scannet_tables()
+    net = SelectionNet(scannet_config(), 'cpu', valid, is_fg, out_channels=[96, 96, 6])
+    sd = net.state_dict()
+    exp = {'conv0p1s1.kernel': (125, 6, 32), 'bn0.bn.weight': (32,), 'bn0.bn.running_var': (32,),
+           'bn0.bn.num_batches_tracked': (), 'block2.0.conv1.kernel': (27, 32, 64), 'block2.0.norm1.bn.bias': (64,),
+           'block2.0.downsample.0.kernel': (32, 64), 'block2.0.downsample.1.bn.weight': (64,),
+           'convtr7p2s2.kernel': (8, 96, 96), 'added_block4.0.conv1.kernel': (27, 512, 256),
+           'block8.0.conv1.kernel': (27, 128, 96), 'mlp_offsets.0.kernel': (96, 96), 'mlp_offsets.0.bias': (1, 96),
+           'mlp_offsets.2.bn.weight': (96,), 'mlp_semantics.6.kernel': (96, 20), 'mlp_semantics.6.bias': (1, 20),
+           'mlp_score.6.kernel': (96, 1), 'mlp_bounds.6.kernel': (96, 3)}
+    for k, shp in exp.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == shp, (k, tuple(sd[k].shape))
+    n_conv = sum(v.numel() for k, v in sd.items() if k.endswith('.kernel') and not k.startswith('mlp_'))
+    assert n_conv == 73_016_768            # trunk conv weights
+    assert sum(1 for k in sd if k.endswith('.bn.weight')) == 89      # 89 BN layers
+    assert 'block1.0.downsample.0.kernel' not in sd and 'block8.0.downsample.0.kernel' in sd
+
+
+@pytest.mark.gpu
+def test_network_forward_backward_matches_oracle():
+    from box2mask_amd.detection_net import SelectionNet
+    from box2mask_amd import nn as ME
+    from oracle import unet_ref
+    cfg = scannet_config()
+    valid, _, _, is_fg = synth.scannet_tables()
+    torch.manual_seed(0)
+    net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6]).cuda()
+    net.train()
+    # 8 small scenes: every level keeps >= 8 rows, so that BatchNorm over the rows of the deepest levels
+    # stays well conditioned (with 2 rows, x_hat = +-1 and fp32 noise decides the sign -> no parity possible)
+    batch = synth.make_batch(8, seed0=4, target_voxels=2000, pts_per_m2=6000.0)
+    S_ = batch['input_location'].shape[0]
+    p_cpu = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    # product
+    sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'])
+    net._trace = {}
+    out = net(sin, batch['pooling_ids'].cuda(), S_)
+    heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
+    torch.manual_seed(1)
+    gws = {h: torch.randn(out[h].F.shape) for h in heads}
+    loss = sum((out[h].F * gws[h].cuda()).sum() for h in heads)
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle in fp32 (the parity target) and in fp64 (ground truth for the conditioning of each gradient)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        p_req = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+                     else (v.to(dt) if v.is_floating_point() else v)) for k, v in p_cpu.items()}
+        otrace = {}
+        oout = unet_ref.forward(p_req, batch['vox_coords'].numpy(), batch['vox_features'].to(dt), batch['pooling_ids'],
+                                cfg, training=True, n_segments=S_, trace=otrace)
+        sum((oout[h] * gws[h].to(dt)).sum() for h in heads).backward()
+        res[dt] = (p_req, oout, otrace)
+    p32, o32, t32 = res[torch.float32]
+    p64, o64, t64 = res[torch.float64]
+    for name, t in net._trace.items():
+        print('layer %-14s rows %6d  rel err vs oracle32 %.3e  vs fp64 %.3e' % (name, t.shape[0], _rel(t, t32[name]), _rel(t, t64[name])))
+    assert min(t.shape[0] for t in net._trace.values()) >= 8
+    errs = {h: _rel(out[h].F, o32[h]) for h in heads}
+    print('forward rel errors', errs)
+    assert max(errs.values()) < 1e-3, errs                      # north_star: conv features within 1e-3 fp32
+    # Gradients: BatchNorm over the 8-row deepest levels makes the backward pass ill-conditioned in fp32
+    # (the fp32 oracle itself is ~2e-2 away from the fp64 oracle), so every gradient is judged against the
+    # fp64 truth and must be no worse than a small multiple of the fp32 oracle's own error.
+    bad, e_gpu, e_o32 = [], [], []
+    for name, prm in net.named_parameters():
+        g64 = p64[name].grad
+        assert g64 is not None and prm.grad is not None, name
+        eg, eo = _rel(prm.grad, g64), _rel(p32[name].grad, g64)
+        e_gpu.append(eg); e_o32.append(eo)
+        if eg > max(2e-3, 4.0 * eo):
+            bad.append((name, eg, eo))
+    med_g, med_o = sorted(e_gpu)[len(e_gpu) // 2], sorted(e_o32)[len(e_o32) // 2]
+    print('gradient error vs fp64: median gpu %.3e, median oracle32 %.3e, max gpu %.3e' % (med_g, med_o, max(e_gpu)))
+    assert not bad, bad[:5]
+    assert med_g < 2.0 * med_o + 1e-4
+    # running statistics were updated like BatchNorm1d
+    sd = net.state_dict()
+    assert int(sd['bn0.bn.num_batches_tracked']) == 1
+    assert not torch.equal(sd['bn0.bn.running_mean'].cpu(), p_cpu['bn0.bn.running_mean'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['a', 'b'])
+def test_losses_match_reference_golden(golden_dir, case):
+    """Model.compute_loss_detection against vectors produced by the real reference
+    (Model.compute_loss_detection driven through import stand-ins, tools/gen_golden.py)."""
+    from box2mask_amd.model import Model
+    g = np.load(os.path.join(golden_dir, 'losses.npz'))
+    cfg = scannet_config(use_bb_iou_loss=(case == 'b'))
+    model = Model(cfg, *synth.scannet_tables())
+    pre = 'loss_%s_' % case
+    heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
+    pred = {h: torch.from_numpy(g[pre + 'pred_' + h]).cuda().requires_grad_(True) for h in heads}
+
+    class H:
+        def __init__(self, F): self.F = F
+    model.detection_model = lambda sin, ids, n=None: {h: H(v) for h, v in pred.items()}
+    batch = {k: torch.from_numpy(g[pre + 'batch_' + k]) for k in
+             ('input_location', 'gt_bb_offsets', 'gt_bb_bounds', 'gt_semantics', 'fg_instances', 'pooling_ids')}
+    batch['vox_features'] = torch.zeros(4, 6); batch['vox_coords'] = torch.tensor([[0, i, 0, 0] for i in range(4)], dtype=torch.int32)
+    losses, _ = model.compute_loss_detection(batch, int(g[pre + 'epoch']))
+    losses['optimization_loss'].backward()
+    for k in [k[len(pre):] for k in g.files if k.startswith(pre) and not any(s in k for s in ('pred_', 'grad_', 'batch_', 'epoch'))]:
+        v = losses[k]
+        v = v.item() if hasattr(v, 'item') else float(v)
+        tol = 2e-4 if 'correlation' in k or 'mIoU' in k else 2e-5
+        assert abs(v - float(g[pre + k])) <= tol * max(1.0, abs(float(g[pre + k]))), (k, v, float(g[pre + k]))
+    for h in heads:
+        ref = torch.from_numpy(g[pre + 'grad_' + h])
+        got = pred[h].grad.cpu() if pred[h].grad is not None else torch.zeros_like(ref)
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-7), h
+
+
+@pytest.mark.gpu
+def test_model_train_step_and_prediction_roundtrip():
+    """compute_loss -> backward -> Adam step, then get_prediction/pred2mask on the same batch."""
+    from box2mask_amd.model import Model
+    cfg = scannet_config()
+    torch.manual_seed(0)
+    model = Model(cfg, *synth.scannet_tables())
+    batch = synth.make_batch(2, seed0=7, target_voxels=4000, pts_per_m2=6000.0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    model.train()
+    l0 = None
+    for it in range(3):
+        opt.zero_grad()
+        ld = model.compute_loss(batch, 150)
+        ld['optimization_loss'].backward()
+        opt.step()
+        for k, v in ld.items():
+            assert np.isfinite(v.item() if hasattr(v, 'item') else float(v)), k
+        l0 = l0 or ld['optimization_loss'].item()
+    assert ld['optimization_loss'].item() < l0          # three steps on one batch reduce the loss
+    model.eval()
+    pred = model.get_prediction(batch)
+    assert pred['mlp_offsets'].device.type == 'cpu' and float(pred['mlp_bounds'].min()) >= float(np.float32(cfg.min_bb_size))
+    sd = model.state_dict()
+    model2 = Model(cfg, *synth.scannet_tables())
+    missing, unexpected = model2.load_state_dict(sd)
+    assert not missing and not unexpected
+    model2.eval()
+    pred2 = model2.get_prediction(batch)
+    assert torch.allclose(pred['mlp_semantics'], pred2['mlp_semantics'], atol=1e-5)

@@ -1,0 +1,140 @@
+"""GPU parity of the votes -> instance-mask path: bit-exact against golden vectors from the real
+reference (tests/golden/*.npz) and, at sizes the reference takes seconds for, against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CASES = ['votes1', 'votes64', 'votes512', 'votes2000', 'degenerate', 'edge_th']
+
+
+@pytest.fixture(scope='module')
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, 'iou_nms.npz'))
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('where', ['cpu', 'cuda'])
+def test_nms_clustering_golden(g, case, where):
+    from box2mask_amd import iou_nms
+    boxes = torch.from_numpy(g[case + '_boxes']).to(where)
+    reps, clusters, heat = iou_nms.NMS_clustering(boxes, float(g[case + '_th']))
+    assert reps.dtype == torch.int64 and reps.device.type == where
+    assert np.array_equal(reps.cpu().numpy(), g[case + '_reps'])
+    assert np.array_equal(heat.cpu().numpy().view(np.uint32), g[case + '_heat'].view(np.uint32))
+    assign = np.full(len(boxes), -1, np.int32)
+    for c, idx in enumerate(clusters):
+        assign[idx.cpu().numpy()] = c
+    assert np.array_equal(assign, g[case + '_assign'])
+    # members of a cluster are listed in visiting (descending score) order, like the reference
+    sc = g[case + '_boxes'][:, 0]
+    for idx in clusters:
+        s = sc[idx.cpu().numpy()]
+        assert (np.diff(s) <= 0).all()
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_mask_nms_golden(g, case):
+    from box2mask_amd import iou_nms
+    masks = torch.from_numpy(g[case + '_masks'])
+    kept, supp = iou_nms.mask_NMS(masks, 0.6)
+    assert np.array_equal(kept.numpy(), g[case + '_mask_kept'])
+    assert len(supp) == len(kept)
+
+
+def test_small_functions_golden(g):
+    from box2mask_amd import iou_nms
+    from box2mask_amd.util import to_bbs_min_max, to_unique
+    iou = iou_nms.set_IOUs(torch.from_numpy(g['set_a']), torch.from_numpy(g['set_b']))
+    assert np.array_equal(iou.numpy().view(np.uint32), g['set_iou'].view(np.uint32))
+    one = iou_nms.torch_IOUs(torch.from_numpy(g['set_a'][0]), torch.from_numpy(g['set_b']))
+    from oracle import nms_ref
+    assert np.array_equal(one.numpy().view(np.uint32), nms_ref.box_ious(g['set_a'][0], g['set_b']).view(np.uint32))
+    s = iou_nms.semIOU(torch.from_numpy(g['sem_pred']).cuda(), torch.from_numpy(g['sem_gt']).cuda())
+    assert np.array_equal(s, g['sem_iou'])
+    bbs = to_bbs_min_max(*(torch.from_numpy(g[k]) for k in ('bbs_loc', 'bbs_off', 'bbs_bnd', 'bbs_sc')))
+    assert np.array_equal(bbs.numpy().view(np.uint32), g['bbs_out'].view(np.uint32))
+    assert np.array_equal(to_unique([g['uniq_in0'].copy(), g['uniq_in1'].copy(), g['uniq_in2'].copy()]).numpy(), g['uniq_out'])
+    m = torch.from_numpy(g['votes512_masks'])
+    mi = iou_nms.masks_iou(m[0], m[1:])
+    assert np.array_equal(mi.numpy().view(np.uint32), nms_ref.masks_iou(g['votes512_masks'][0], g['votes512_masks'][1:]).view(np.uint32))
+
+
+def test_empty_input_raises_like_reference():
+    from box2mask_amd import iou_nms
+    with pytest.raises(ValueError):
+        iou_nms.NMS_clustering(torch.zeros(0, 7), 0.5)
+
+
+@pytest.mark.parametrize('case', ['a', 'b'])
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_detection2mask_golden(golden_dir, case, mode):
+    """Model.pred2mask against SelectionNet.detection2mask of the real reference."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.detection_net import SelectionNet
+    d = np.load(os.path.join(golden_dir, 'detection2mask.npz'))
+    cfg = scannet_config()
+    valid, _, _, is_fg = synth.scannet_tables()
+    net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6])
+    names = [str(s) for s in d['d2m_%s_names' % case]]
+    batch = {'input_location': torch.from_numpy(d['d2m_%s_input_location' % case]),
+             'batch_ids': torch.from_numpy(d['d2m_%s_batch_ids' % case]),
+             'scene': [{'name': n} for n in names],
+             'seg2vox': [d['d2m_%s_seg2vox%d' % (case, i)] for i in range(len(names))],
+             'vox2point': [d['d2m_%s_vox2point%d' % (case, i)] for i in range(len(names))]}
+    pred = {h: torch.from_numpy(d['d2m_%s_pred_%s' % (case, h)]) for h in
+            ('mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics')}
+    res = net.detection2mask(batch, pred, cfg, mode, True, *d['d2m_%s_ths' % case].tolist())
+    total = 0
+    for si, n in enumerate(names):
+        pre = 'd2m_%s_%s_s%d_' % (case, mode, si)
+        r = res[n]
+        assert np.array_equal(r['conf'].numpy().view(np.uint32), d[pre + 'conf'].view(np.uint32))
+        assert r['label_id'].dtype == np.int32 and np.array_equal(r['label_id'], d[pre + 'label_id'])
+        assert r['mask'].dtype == torch.bool and tuple(r['mask'].shape) == tuple(d[pre + 'mask_shape'])
+        assert np.array_equal(np.packbits(r['mask'].numpy(), axis=1), d[pre + 'mask'])
+        if mode != 'eval':
+            assert np.array_equal(r['cluster_representatives'].numpy(), d[pre + 'reps'])
+        total += r['mask'].shape[0]
+    assert total > 0
+
+
+@pytest.mark.parametrize('n,nobj', [(6000, 120), (1500, 30)])
+def test_s3dis_sized_votes_against_oracle(n, nobj):
+    from box2mask_amd import iou_nms, synth
+    from oracle import nms_ref
+    boxes = synth.make_votes(5, n_obj=nobj, n_seg=n)
+    reps, clusters, heat = iou_nms.NMS_clustering(torch.from_numpy(boxes), 0.5)
+    oreps, oclusters, oheat = nms_ref.nms_clustering(boxes, 0.5)
+    assert np.array_equal(reps.numpy(), oreps)
+    assert np.array_equal(heat.numpy().view(np.uint32), oheat.view(np.uint32))
+    masks = oheat > np.float32(0.3)
+    kept, _ = iou_nms.mask_NMS(torch.from_numpy(masks), 0.6)
+    assert np.array_equal(kept.numpy(), nms_ref.mask_nms(masks, 0.6)[0])
+
+
+def test_score_ties_are_visited_in_row_order():
+    from box2mask_amd import iou_nms
+    from oracle import nms_ref
+    b = np.zeros((6, 7), np.float32)
+    for i in range(6):
+        b[i] = [0.5, 3 * i, 0, 0, 3 * i + 1, 1, 1]       # disjoint boxes, identical scores
+    reps, _, _ = iou_nms.NMS_clustering(torch.from_numpy(b), 0.5)
+    assert reps.tolist() == list(range(6)) == nms_ref.nms_clustering(b, 0.5)[0].tolist()
+
+
+def test_large_n_global_sort_path():
+    """n > 4096 takes the global-memory bitonic sort; idempotence: clustering the representatives
+    again leaves every one of them its own cluster."""
+    from box2mask_amd import iou_nms, synth
+    from oracle import nms_ref
+    boxes = synth.make_votes(9, n_obj=200, n_seg=9000)
+    reps, clusters, heat = iou_nms.NMS_clustering(torch.from_numpy(boxes), 0.5)
+    oreps, _, _ = nms_ref.nms_clustering(boxes, 0.5)
+    assert np.array_equal(reps.numpy(), oreps)
+    assert sum(len(c) for c in clusters) == len(boxes)
+    reps2, _, _ = iou_nms.NMS_clustering(torch.from_numpy(boxes[reps.numpy()]), 0.5)
+    assert len(reps2) == len(reps)

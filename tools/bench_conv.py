@@ -1,0 +1,36 @@
+"""Micro-benchmark of the sparse-conv kernels on one synthetic scene batch (GPU box)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from box2mask_amd import synth, functional as F_
+from box2mask_amd.sparse import CoordinateManager
+
+bs = int(os.environ.get('BS', '4'))
+b = synth.make_batch(bs, seed0=0)
+m = CoordinateManager(b['vox_coords'])
+torch.cuda.synchronize()
+t = time.time(); rb0 = m.rulebook_same(0, 3); m.ensure_level(2); rb1 = m.rulebook_same(1, 3); rbu = m.rulebook_up(0); rbd = m.rulebook_down(0); rb5 = m.rulebook_same(0, 5)
+torch.cuda.synchronize(); print('maps %.1f ms' % ((time.time() - t) * 1e3), 'N0', m.n(0), 'pairs k3', rb0.pairs, 'k5', rb5.pairs)
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+for name, rb, K, c1, c2, co in [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
+                               ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L1 k3 32->32', rb1, 27, 32, 0, 32), ('L0 up 96->96', rbu, 8, 96, 0, 96),
+                               ('L0 k5 6->32', rb5, 125, 6, 0, 32), ('L0 1x1 128->96', None, 1, 128, 0, 96)]:
+    n_out = rb.n_out if rb is not None else m.n(0)
+    n_in = rb.n_in if rb is not None else m.n(0)
+    x1 = torch.randn(n_in, c1, device='cuda'); x2 = torch.randn(n_in, c2, device='cuda') if c2 else None
+    w = torch.randn(K, c1 + c2, co, device='cuda') * 0.05
+    P = rb.pairs if rb is not None else n_out
+    fl = 2.0 * P * (c1 + c2) * co
+    ms = timeit(lambda: F_.conv_raw(x1, x2, w, None, rb, n_out, co))
+    dy = torch.randn(n_out, co, device='cuda'); dw = torch.zeros_like(w)
+    xs = x1 if c2 == 0 else torch.cat([x1, x2], 1)
+    msw = timeit(lambda: F_.wgrad_raw(xs, dy, rb, K, dw, 0))
+    print('%-24s fwd %8.3f ms %6.2f TF | wgrad %8.3f ms %6.2f TF | pairs %d' % (name, ms, fl / ms / 1e9, msw, fl / msw / 1e9, P))
