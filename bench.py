@@ -76,8 +76,15 @@ def main():
     ap.add_argument('--batch-size', type=int, default=8, help='scenes per GPU (configs/scannet.txt: 8)')
     ap.add_argument('--target-voxels', type=int, default=150_000)
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing')
-    ap.add_argument('--cpu-voxels', type=int, default=150_000, help='voxels of the CPU baseline sample scene')
+    ap.add_argument('--cpu-voxels', type=int, default=40_000, help='voxels per scene of the CPU baseline sample')
+    ap.add_argument('--cpu-scenes', type=int, default=2, help='scenes in the CPU baseline sample')
+    ap.add_argument('--cpu-timeout', type=int, default=240, help='seconds after which the CPU baseline is abandoned')
     args = ap.parse_args()
+
+    # The CPU baseline runs FIRST, before this process touches the GPU (pure torch-CPU oracle, rank 0, N=1 only).
+    cpu_result = None
+    if args.cpu_baseline and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        cpu_result = cpu_baseline(args.cpu_scenes, args.cpu_voxels, args.cpu_timeout, args.target_voxels)
 
     from box2mask_amd import _lib, synth
     from box2mask_amd import sparse as sparse_mod
@@ -198,37 +205,66 @@ def main():
     }
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
-    if args.cpu_baseline and world == 1:
-        result['cpu_baseline'] = cpu_baseline(cfg, args.cpu_voxels)
+    if cpu_result is not None:
+        result['cpu_baseline'] = cpu_result
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
 
 
-def cpu_baseline(cfg, voxels):
-    """fwd + losses-equivalent scalar + bwd of ONE synthetic scene on the CPU oracle (torch CPU,
-    per-offset index_select -> mm -> index_add_, all host cores)."""
+def cpu_baseline(n_scenes, voxels, timeout_s, ref_voxels):
+    """Coordinate/kernel-map build + forward + backward of a small synthetic batch on the CPU oracle
+    (torch CPU, per-offset index_select -> mm -> index_add_), scaled to 150k-voxel scenes per second.
+    Threads: min(16, cores available) -- the reference pins MinkowskiEngine's CPU path to
+    OMP_NUM_THREADS=16 (/root/reference/config_loader.py:3-4).  Abandoned after `timeout_s` seconds."""
+    import signal
     from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
     from box2mask_amd.detection_net import SelectionNet
     from oracle import unet_ref
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
     torch.set_num_threads(cores)
+    cfg = scannet_config()
     valid, _, _, is_fg = synth.scannet_tables()
     torch.manual_seed(0)
     net = SelectionNet(cfg, 'cpu', valid, is_fg, out_channels=[96, 96, 6])
     p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
          for k, v in net.state_dict().items()}
-    b = synth.make_batch(1, seed0=0, target_voxels=voxels)
+    b = synth.make_batch(n_scenes, seed0=0, target_voxels=voxels)
+    nvox = int(b['vox_coords'].shape[0])
+
+    class _Timeout(Exception):
+        pass
+
+    def _alarm(signum, frame):
+        raise _Timeout()
+
+    old = signal.signal(signal.SIGALRM, _alarm)
+    signal.alarm(int(timeout_s))
     t0 = time.perf_counter()
-    out = unet_ref.forward(p, b['vox_coords'].numpy(), b['vox_features'], b['pooling_ids'], cfg, training=True,
-                           n_segments=b['input_location'].shape[0])
-    loss = sum(v.abs().mean() for k, v in out.items())
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return {'value': round(1.0 / dt, 5), 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 synthetic scene of %d voxels (seed 0), coordinate/kernel-map build + forward + backward '
-                      'on the CPU oracle (oracle/unet_ref.py, torch %s, %d threads): %.1f s'
-                      % (b['vox_coords'].shape[0], torch.__version__, cores, dt)}
+    try:
+        out = unet_ref.forward(p, b['vox_coords'].numpy(), b['vox_features'], b['pooling_ids'], cfg, training=True,
+                               n_segments=b['input_location'].shape[0])
+        loss = sum(v.abs().mean() for k, v in out.items())
+        loss.backward()
+        dt = time.perf_counter() - t0
+        value = round((nvox / float(ref_voxels)) / dt, 5)
+        note = '%.1f s' % dt
+    except _Timeout:
+        value, note = None, 'abandoned after %d s' % timeout_s
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+    return {'value': value, 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d synthetic scenes of ~%d voxels (%d voxels in all, seeds 0..%d): coordinate/kernel-map build + '
+                      'forward + backward on the CPU oracle (oracle/unet_ref.py, torch %s, %d threads): %s; value = '
+                      '(voxels / %d) / seconds, i.e. scaled to %dk-voxel scenes'
+                      % (n_scenes, voxels, nvox, n_scenes - 1, torch.__version__, cores, note, ref_voxels,
+                         ref_voxels // 1000)}
 
 
 if __name__ == '__main__':

@@ -201,17 +201,20 @@ __global__ void kernel_map_kernel(const int32_t* __restrict__ coords, int64_t n,
                                   int32_t* __restrict__ nbr, int64_t ld) {
     int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n) return;
-    const int K = ksize * ksize * ksize, h = ksize / 2;
+    const int h = ksize / 2;
+    // blockIdx.y selects one (dy,dz) line of the kernel: ksize independent probes per thread
+    const int dy = ((int)blockIdx.y % ksize - h) * ts, dz = ((int)blockIdx.y / ksize - h) * ts;
     i32x4 c = *(const i32x4*)(coords + o * 4);
-    for (int k = 0; k < K; ++k) {
-        int dx = (k % ksize - h) * ts, dy = ((k / ksize) % ksize - h) * ts, dz = (k / (ksize * ksize) - h) * ts;
-        int x = c.y + dx, y = c.z + dy, z = c.w + dz;
+    const int y = c.z + dy, z = c.w + dz;
+    const bool yz = (unsigned)y < 65536u && (unsigned)z < 65536u;
+    for (int kx = 0; kx < ksize; ++kx) {
+        const int x = c.y + (kx - h) * ts;
         int r = -1;
-        if ((unsigned)x < 65536u && (unsigned)y < 65536u && (unsigned)z < 65536u) {
+        if (yz && (unsigned)x < 65536u) {
             int64_t s = b2m_find(keys, mask, b2m_pack(c.x, x, y, z));
             if (s >= 0) r = vals[s];
         }
-        nbr[(int64_t)k * ld + o] = r;
+        nbr[(int64_t)((int)blockIdx.y * ksize + kx) * ld + o] = r;
     }
 }
 extern "C" int b2m_kernel_map(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts, const uint64_t* keys,
@@ -220,7 +223,8 @@ extern "C" int b2m_kernel_map(const int32_t* coords, int64_t n, int32_t ksize, i
     B2M_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7, "ksize must be odd (1,3,5,7)");
     B2M_CHECK_ARG(ld >= n && is_pow2(cap), "ld < n or cap not pow2");
     if (n == 0) return B2M_OK;
-    kernel_map_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(coords, n, ksize, ts, keys, vals, cap - 1, nbr, ld);
+    kernel_map_kernel<<<dim3((unsigned)cdiv64(n, 256), (unsigned)(ksize * ksize)), 256, 0, st>>>(coords, n, ksize, ts, keys,
+                                                                                               vals, cap - 1, nbr, ld);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -250,24 +254,24 @@ extern "C" int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int
 // one wave per tile of B2M_TILE (= 64) output rows: lane = row; per offset one ballot compacts the valid
 // pairs in row order
 static_assert(B2M_TILE == 64, "the rulebook kernel maps one lane to one tile row");
-__global__ __launch_bounds__(64) void rulebook_kernel(const int32_t* __restrict__ nbr, int64_t ld, int32_t K,
-                                                      int64_t n_out, int64_t ntiles, int32_t* __restrict__ rb_in,
-                                                      uint8_t* __restrict__ rb_out, int32_t* __restrict__ rb_cnt,
-                                                      int32_t* __restrict__ pair_total) {
+__global__ __launch_bounds__(256) void rulebook_kernel(const int32_t* __restrict__ nbr, int64_t ld, int32_t K,
+                                                       int64_t n_out, int64_t ntiles, int32_t* __restrict__ rb_in,
+                                                       uint8_t* __restrict__ rb_out, int32_t* __restrict__ rb_cnt,
+                                                       int32_t* __restrict__ pair_total) {
     const int64_t t = blockIdx.x;
+    const int k = blockIdx.y * 4 + (threadIdx.x >> 6);      // one wave per (tile, offset)
+    if (k >= K) return;
     const int lane = lane_id();
     const int64_t ldr = ntiles * B2M_TILE;
     const int64_t o = t * B2M_TILE + lane;
-    for (int k = 0; k < K; ++k) {
-        const int v = o < n_out ? nbr[(int64_t)k * ld + o] : -1;
-        const uint64_t b = __ballot(v >= 0);
-        const int c = __popcll(b);
-        const int64_t base = (int64_t)k * ldr + t * B2M_TILE;
-        if (v >= 0) { const int p = prefix_popc(b); rb_in[base + p] = v; rb_out[base + p] = (uint8_t)lane; }
-        if (lane == 0) {
-            rb_cnt[(int64_t)k * ntiles + t] = c;
-            if (pair_total && c) atomicAdd(&pair_total[k], c);
-        }
+    const int v = o < n_out ? nbr[(int64_t)k * ld + o] : -1;
+    const uint64_t b = __ballot(v >= 0);
+    const int c = __popcll(b);
+    const int64_t base = (int64_t)k * ldr + t * B2M_TILE;
+    if (v >= 0) { const int p = prefix_popc(b); rb_in[base + p] = v; rb_out[base + p] = (uint8_t)lane; }
+    if (lane == 0) {
+        rb_cnt[(int64_t)k * ntiles + t] = c;
+        if (pair_total && c) atomicAdd(&pair_total[k], c);
     }
 }
 extern "C" int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out, int32_t* rb_in, uint8_t* rb_out,
@@ -279,7 +283,8 @@ extern "C" int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n
     if (ntiles == 0) return B2M_OK;
     B2M_HIP(hipMemsetAsync(rb_in, 0xFF, (size_t)K * ntiles * B2M_TILE * sizeof(int32_t), st));
     B2M_HIP(hipMemsetAsync(rb_out, 0, (size_t)K * ntiles * B2M_TILE, st));
-    rulebook_kernel<<<(unsigned)ntiles, 64, 0, st>>>(nbr, ld, K, n_out, ntiles, rb_in, rb_out, rb_cnt, pair_total);
+    rulebook_kernel<<<dim3((unsigned)ntiles, (unsigned)((K + 3) / 4)), 256, 0, st>>>(nbr, ld, K, n_out, ntiles, rb_in,
+                                                                                   rb_out, rb_cnt, pair_total);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -40,12 +40,15 @@ __device__ __forceinline__ void column_reduce(int64_t n, int c, double* __restri
         for (int u = 0; u < 4; ++u) { o[cg * 4 + u] = da[u]; o[c + cg * 4 + u] = db[u]; }
     }
 }
-__global__ void reduce_final_kernel(const double* __restrict__ partial, int nblk, int c2, double* __restrict__ out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= c2) return;
+// one wave per output column: lanes sum strided partials, then a fixed-order shuffle tree (deterministic)
+__global__ __launch_bounds__(64) void reduce_final_kernel(const double* __restrict__ partial, int nblk, int c2,
+                                                          double* __restrict__ out) {
+    const int j = blockIdx.x;
     double s = 0;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * c2 + j];
-    out[j] = s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * c2 + j];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if (threadIdx.x == 0) out[j] = s;
 }
 static int reduce_blocks(int64_t n) {
     int64_t b = (n + 511) / 512;
@@ -71,7 +74,7 @@ extern "C" int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, d
     const int nblk = reduce_blocks(n);
     const int c4 = c / 4, nslots = 256 / c4;
     bn_stats_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(x, ldx, n, c, partial);
-    reduce_final_kernel<<<(2 * c + 255) / 256, 256, 0, st>>>(partial, nblk, 2 * c, stats);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, stats);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -183,7 +186,7 @@ extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, 
     const int c4 = c / 4, nslots = 256 / c4;
     bn_bwd_reduce_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(dy, lddy, y, ldy, x, ldx, n, c,
                                                                                    mean, invstd, relu, partial);
-    reduce_final_kernel<<<(2 * c + 255) / 256, 256, 0, st>>>(partial, nblk, 2 * c, sums);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -120,6 +120,9 @@ class MinkowskiBatchNorm(nn.Module):
     def apply_bn(self, feats, residual=None, relu=False):
         bn = self.bn
         training = self.training or not bn.track_running_stats
+        if training and feats.shape[0] == 1:   # torch.nn.functional.batch_norm raises the same (BatchNorm1d)
+            raise ValueError('Expected more than 1 value per channel when training, got input size %s'
+                             % (tuple(feats.shape),))
         if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         return F_.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,

@@ -36,10 +36,9 @@ class Rulebook:
         self.rb_in = torch.empty(max(K * ldr, 1), dtype=torch.int32, device=dev)
         self.rb_out = torch.empty(max(K * ldr, 1), dtype=torch.uint8, device=dev)
         self.rb_cnt = torch.empty(max(K * self.ntiles, 1), dtype=torch.int32, device=dev)
-        self.pair_total = torch.zeros(K, dtype=torch.int32, device=dev)
         ld = nbr.shape[1] if nbr.dim() == 2 else n_out
         _lib.call('b2m_rulebook', nbr.data_ptr(), ld, K, n_out, self.rb_in.data_ptr(), self.rb_out.data_ptr(),
-                  self.rb_cnt.data_ptr(), self.pair_total.data_ptr())
+                  self.rb_cnt.data_ptr(), None)
         self.nbr = nbr if keep_table else None
         self._pairs = None
 
@@ -47,7 +46,7 @@ class Rulebook:
     def pairs(self) -> int:
         """Total number of (in,out) pairs (syncs once; used for FLOP accounting only)."""
         if self._pairs is None:
-            self._pairs = int(self.pair_total.sum().item())
+            self._pairs = int(self.rb_cnt[:self.K * self.ntiles].sum().item())
         return self._pairs
 
 

@@ -1,0 +1,112 @@
+"""N>1 host logic on the CPU with gloo, world_size 2: scene sharding, bucketed gradient all-reduce
+(with and without backward overlap) and the SyncBN statistics merge."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from box2mask_amd.parallel import GradAllReduce, init_distributed, shard_scenes
+    from box2mask_amd.functional import merge_bn_sums
+    r, w = init_distributed('gloo')
+    assert (r, w) == (rank, world)
+    out = {}
+    # --- scene sharding: disjoint, complete
+    out['shard'] = shard_scenes(16, rank, world)
+    # --- gradient all-reduce, overlap via hooks, several buckets
+    torch.manual_seed(0)                                  # same weights on all ranks
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    dp = GradAllReduce(list(net.parameters()), bucket_bytes=256, overlap=True)
+    dp.broadcast_parameters()
+    assert len(dp.buckets) >= 2
+    torch.manual_seed(100 + rank)                         # different data per rank
+    x = torch.randn(5, 8)
+    for it in range(2):                                   # two steps: the hook state must reset
+        net.zero_grad(set_to_none=(it == 1))
+        net(x).pow(2).sum().backward()
+        dp.all_reduce_mean()
+    out['grads'] = [p.grad.clone() for p in net.parameters()]
+    out['x'] = x
+    # --- no-overlap path gives the same result
+    net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    net2.load_state_dict(net.state_dict())
+    dp2 = GradAllReduce(list(net2.parameters()), bucket_bytes=1 << 20, overlap=False)
+    net2(x).pow(2).sum().backward()
+    dp2.all_reduce_mean()
+    out['grads2'] = [p.grad.clone() for p in net2.parameters()]
+    # --- SyncBN statistics merge == statistics of the concatenated rows
+    torch.manual_seed(7 + rank)
+    feats = torch.randn(30 + 10 * rank, 6, dtype=torch.float64)
+    sums = torch.cat([feats.sum(0), (feats * feats).sum(0)])
+    gs, cnt = merge_bn_sums(sums, feats.shape[0], dist.group.WORLD)
+    out['bn'] = (gs, cnt, feats)
+    def plain(v):
+        if torch.is_tensor(v):
+            return v.detach().numpy().copy()
+        if isinstance(v, (list, tuple)):
+            return [plain(u) for u in v]
+        return v
+    q.put((rank, {k: plain(v) for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    def back(v):
+        import numpy as np
+        if isinstance(v, np.ndarray):
+            return torch.from_numpy(v)
+        if isinstance(v, list):
+            return [back(u) for u in v]
+        return v
+    a, b = ({k: back(v) for k, v in res[r].items()} for r in (0, 1))
+    assert sorted(a['shard'] + b['shard']) == list(range(16)) and not set(a['shard']) & set(b['shard'])
+    # reference: mean of the two ranks' gradients computed in one process
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    gs = []
+    for x in (a['x'], b['x']):
+        net.zero_grad()
+        net(x).pow(2).sum().backward()
+        gs.append([p.grad.clone() for p in net.parameters()])
+    for i in range(len(gs[0])):
+        ref = (gs[0][i] + gs[1][i]) / 2
+        for r in (a, b):
+            assert torch.allclose(r['grads'][i], ref, atol=1e-6)
+            assert torch.allclose(r['grads2'][i], ref, atol=1e-6)
+    feats = torch.cat([a['bn'][2], b['bn'][2]])
+    for r in (a, b):
+        s, cnt, _ = r['bn']
+        assert cnt == feats.shape[0]
+        mean = s[:6] / cnt; var = s[6:] / cnt - mean * mean
+        assert torch.allclose(mean, feats.mean(0), atol=1e-12) and torch.allclose(var, feats.var(0, unbiased=False), atol=1e-12)
+
+
+def test_single_process_is_a_noop():
+    from box2mask_amd.parallel import GradAllReduce, shard_scenes
+    net = torch.nn.Linear(3, 2)
+    dp = GradAllReduce(list(net.parameters()))
+    net(torch.ones(1, 3)).sum().backward()
+    g = net.weight.grad.clone()
+    dp.all_reduce_mean()
+    assert torch.equal(net.weight.grad, g)
+    assert shard_scenes(5, 0, 1) == [0, 1, 2, 3, 4]
