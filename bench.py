@@ -78,6 +78,7 @@ def main():
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing')
     ap.add_argument('--cpu-voxels', type=int, default=40_000, help='voxels per scene of the CPU baseline sample')
     ap.add_argument('--cpu-scenes', type=int, default=2, help='scenes in the CPU baseline sample')
+    ap.add_argument('--detail', type=int, default=0, help='1 prints a per-layer-shape table of the conv launches to stderr')
     ap.add_argument('--cpu-timeout', type=int, default=240, help='seconds after which the CPU baseline is abandoned')
     args = ap.parse_args()
 
@@ -172,6 +173,16 @@ def main():
         flops = 2.0 * P * meta['cin'] * meta['cout']
         a = agg.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
         a['ms'] += ms; a['flops'] += flops; a['launches'] += 1
+
+    if args.detail:
+        shapes = {}
+        for name, s_, e_, meta in timer.records:
+            key = (name[4:], meta['K'], meta['cin'], meta['cout'], meta['n_out'])
+            d = shapes.setdefault(key, [0.0, 0.0, 0])
+            d[0] += s_.elapsed_time(e_); d[1] += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']; d[2] += 1
+        print('%-11s %4s %4s %4s %9s %6s %9s %8s' % ('kernel', 'K', 'cin', 'cout', 'n_out', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)
+        for key, d in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+            print('%-11s %4d %4d %4d %9d %6d %9.3f %8.2f' % (key + (d[2] // args.steps, d[0] / args.steps, d[1] / d[0] / 1e9 if d[0] else 0)), file=sys.stderr)
 
     def roof(a):
         tf = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] > 0 else 0.0
