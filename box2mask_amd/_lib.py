@@ -28,8 +28,8 @@ PROTOTYPES = {
     'b2m_kernel_map': [P, I64, I32, I32, P, P, I64, P, I64, P],
     'b2m_stride_tables': [P, P, I64, I64, P, I64, P, I64, P],
     'b2m_rulebook': [P, I64, I32, I64, P, P, P, P, P],
-    'b2m_conv_fwd': [P, I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, I64, P, I64, I32, I32, P],
-    'b2m_weight_transpose': [P, I64, I32, I32, I32, P, I64, I32, P],
+    'b2m_conv_fwd': [P, I64, I32, P, I64, I32, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],
+    'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
     'b2m_conv_wgrad': [P, I64, I32, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P],
     'b2m_bn_stats': [P, I64, I64, I32, P, P, P],
     'b2m_bn_finalize': [P, F64, I32, P, P, F32, F32, P, P, P, P, P, P, P],
@@ -49,7 +49,8 @@ PROTOTYPES = {
     'b2m_mask_pack': [P, I32, I64, P, I64, P],
     'b2m_set_ious': [P, P, I64, P, P],
 }
-PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_device_ok': (C.c_int, [])}
+PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_device_ok': (C.c_int, []),
+         'b2m_weight_pack_size': (C.c_int64, [I32, I32, I32])}
 
 _lib = None
 

@@ -17,14 +17,15 @@
 struct ConvArgs {
     const float* x1; int64_t ldx1; int c1;
     const float* x2; int64_t ldx2; int c2;
-    const float* w; int64_t ldw; int K;
+    const float* wp; int K;
     const float* bias;
     const int32_t* rb_in; const uint8_t* rb_out; const int32_t* rb_cnt;
     int64_t n_out, ntiles;
-    float* y; int64_t ldy; int cout; int accumulate; int nstrips; int vec_store; int a_scalar;
+    float* y; int64_t ldy; int cout; int accumulate; int nstrips; int vec_store;
+    int nslice;      // >1: the tile's active offsets are dealt to nslice waves which add their strips atomically
 };
 
-// loads of padded / out-of-range operands are redirected here (pointer select, no select on the loaded value)
+// loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
 __device__ float g_zeros[64];
 
 static_assert(B2M_TILE == 64, "conv kernels assume 64-row tiles (4 row groups of 16)");
@@ -32,19 +33,26 @@ static_assert(B2M_TILE == 64, "conv kernels assume 64-row tiles (4 row groups of
 
 __device__ __forceinline__ int cs_index(int row, int col) { return row * 32 + (col ^ ((row & 1) << 4)); }
 
-template <int KC, bool IDENT, bool ASCALAR, bool PAIR>
-__global__ __launch_bounds__(256, PAIR ? 3 : 4) void conv_fwd_kernel(ConvArgs a) {
+// Packed weight image (b2m_weight_pack): blocks of 64 lanes x 2*KS floats, ordered [k][strip][chunk]; lane
+// (q,i) of a block holds B[chunk*KC + KS*q + s][strip*32 + 16*t + i] at float 2*s + t.  One or two 16-byte
+// loads per lane per chunk, contiguous over the wave, zero padded: no predicates, no address arithmetic.
+template <int KC, bool IDENT, bool ASCALAR>
+__global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
     constexpr int KS = KC / 4;                // k-steps per chunk == floats per lane per gathered row
+    constexpr int LW = 64 * 2 * KS;           // floats per packed weight block
     __shared__ float smem[4 * B2M_TILE * 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t witem = (int64_t)blockIdx.x * 4 + wave;
+    const int slice = (int)(witem % a.nslice);
+    const int64_t item = witem / a.nslice;
     const int64_t tile = item / a.nstrips;
     const int strip = (int)(item % a.nstrips);
     if (tile >= a.ntiles) return;             // whole wave leaves; no barriers below
     const int col0 = strip * 32;
     const int cin = a.c1 + a.c2;
     const int nchunk = (cin + KC - 1) / KC;
+    const int nch1 = (a.c1 + KC - 1) / KC;    // chunks served by the first source (c1 % KC == 0 when c2 > 0)
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int64_t row0 = tile * B2M_TILE;
     float* Cs = smem + wave * (B2M_TILE * 32);
@@ -58,8 +66,8 @@ __global__ __launch_bounds__(256, PAIR ? 3 : 4) void conv_fwd_kernel(ConvArgs a)
         for (int u = 0; u < 4; ++u) {
             const int col = col0 + c4 + u;
             if (col < a.cout) {
-                float t = a.bias ? a.bias[col] : 0.f;
-                if (a.accumulate && grow < a.n_out) t += a.y[grow * a.ldy + col];
+                float t = (a.bias && slice == 0) ? a.bias[col] : 0.f;
+                if (a.accumulate && a.nslice == 1 && grow < a.n_out) t += a.y[grow * a.ldy + col];
                 v[u] = t;
             }
         }
@@ -77,61 +85,30 @@ __global__ __launch_bounds__(256, PAIR ? 3 : 4) void conv_fwd_kernel(ConvArgs a)
     }
     uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
 
-    // one chunk of operands: B = weights of (offset, chunk), A = gathered rows of the 4 row groups.
-    // All loads are unconditional (pointer select to a zero buffer), so their number is static.
-    auto load_chunk = [&](float (&av)[NG][KS], float (&bv)[KS][2], const int (&idx)[NG], int k, int c) {
-        const int cb = c * KC;
-        const bool cv = c < nchunk;            // wave-uniform: the second chunk of the last pair may not exist
-        const float* src; int64_t ld; int cl, climit;
-        if (cb < a.c1) { src = a.x1; ld = a.ldx1; cl = cb + KS * q; climit = a.c1; }
-        else { src = a.x2; ld = a.ldx2; cl = cb - a.c1 + KS * q; climit = a.c2; }
-        const bool vc = cv && cl < climit;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int ci = cb + KS * q + s;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int col = col0 + 16 * t + i;
-                const float* p = a.w + ((int64_t)k * cin + ci) * a.ldw + col;
-                bv[s][t] = *((cv && ci < cin && col < a.cout) ? p : g_zeros);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int r = idx[g];
-            const float* p = src + (int64_t)r * ld + cl;
-            if constexpr (ASCALAR) {           // odd channel counts (head gradients): per-element
-#pragma unroll
-                for (int s = 0; s < KS; ++s) av[g][s] = *((r >= 0 && cv && cl + s < climit) ? p + s : g_zeros);
-            } else if constexpr (KS == 4) {
-                const f32x4 v = *(const f32x4*)((r >= 0 && vc) ? p : g_zeros);
-                av[g][0] = v[0]; av[g][1] = v[1]; av[g][2] = v[2]; av[g][3] = v[3];
-            } else {
-                const f32x2 v = *(const f32x2*)((r >= 0 && vc) ? p : g_zeros);
-                av[g][0] = v[0]; av[g][1] = v[1];
-            }
-        }
-    };
-
+    int ord = 0;
     for (;;) {
         int k;
         if (m0) { k = __builtin_ctzll(m0); m0 &= m0 - 1; }
         else if (m1) { k = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
         else break;
+        if ((ord++) % a.nslice != slice) continue;      // split-K: active offsets dealt round-robin to the slices
         const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
         const int G = (n + 15) >> 4;           // 1..4 dense row groups
-        // pair lists: lane (i,q) gathers input row idx[g] and later flushes the 4 output rows packed in out[g]
+        // pair lists: lane (i,q) gathers input row idx[g] and later flushes the 4 output rows packed in out[g].
+        // Rows of padded pairs (idx < 0) are clamped to row 0: an MFMA output row depends only on its own A row,
+        // and the flush below skips padded pairs, so whatever they compute is never used.
         int idx[NG]; uint32_t out[NG];
         const int64_t base = (int64_t)k * ldr + row0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (IDENT) {
                 int64_t r = row0 + 16 * g + i;
-                idx[g] = r < a.n_out ? (int)r : -1;
+                idx[g] = r < a.n_out ? (int)r : 0;
                 const int p = 16 * g + 4 * q;
                 out[g] = (uint32_t)p | ((uint32_t)(p + 1) << 8) | ((uint32_t)(p + 2) << 16) | ((uint32_t)(p + 3) << 24);
             } else {                           // slots beyond the pair count hold -1 / 0 by construction
-                idx[g] = a.rb_in[base + 16 * g + i];
+                const int r = a.rb_in[base + 16 * g + i];
+                idx[g] = r < 0 ? 0 : r;
                 out[g] = *(const uint32_t*)(a.rb_out + base + 16 * g + 4 * q);
             }
         }
@@ -139,53 +116,58 @@ __global__ __launch_bounds__(256, PAIR ? 3 : 4) void conv_fwd_kernel(ConvArgs a)
 #pragma unroll
         for (int g = 0; g < NG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-        if constexpr (PAIR) {
-            // two chunks of loads in flight before the first MFMA block (<=168 VGPRs, 3 waves per SIMD)
-            for (int c = 0; c < nchunk; c += 2) {
-                float av0[NG][KS], bv0[KS][2], av1[NG][KS], bv1[KS][2];
-                load_chunk(av0, bv0, idx, k, c);
-                load_chunk(av1, bv1, idx, k, c + 1);
+        const float* wlane = a.wp + ((int64_t)k * a.nstrips + strip) * nchunk * LW + lane * (2 * KS);
+
+        // one source tensor: chunks [c_lo, c_hi) of the concatenated input channels
+        auto run_source = [&](const float* src, int64_t ld, int csrc, int c_lo, int c_hi) {
+            const float* pa[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) pa[g] = src + (int64_t)idx[g] * ld + KS * q;
+            for (int c = c_lo; c < c_hi; ++c) {
+                const int cb = (c - c_lo) * KC;            // channel offset inside this source
+                float bv[KS][2];
+                if constexpr (KS == 4) {
+                    const f32x4 w0 = *(const f32x4*)(wlane + (int64_t)c * LW);
+                    const f32x4 w1 = *(const f32x4*)(wlane + (int64_t)c * LW + 4);
+                    bv[0][0] = w0[0]; bv[0][1] = w0[1]; bv[1][0] = w0[2]; bv[1][1] = w0[3];
+                    bv[2][0] = w1[0]; bv[2][1] = w1[1]; bv[3][0] = w1[2]; bv[3][1] = w1[3];
+                } else {
+                    const f32x4 w0 = *(const f32x4*)(wlane + (int64_t)c * LW);
+                    bv[0][0] = w0[0]; bv[0][1] = w0[1]; bv[1][0] = w0[2]; bv[1][1] = w0[3];
+                }
+                float av[NG][KS];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float* p = pa[g] + cb;
+                    if constexpr (ASCALAR) {       // odd channel counts (head gradients): per-element, predicated
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) av[g][s] = *((cb + KS * q + s < csrc) ? p + s : g_zeros);
+                    } else if constexpr (KS == 4) {
+                        const f32x4 v = *(const f32x4*)p;
+                        av[g][0] = v[0]; av[g][1] = v[1]; av[g][2] = v[2]; av[g][3] = v[3];
+                    } else {
+                        const f32x2 v = *(const f32x2*)p;
+                        av[g][0] = v[0]; av[g][1] = v[1];
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if (g < G) {                        // wave-uniform
 #pragma unroll
                         for (int s = 0; s < KS; ++s) {
-                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g][s], bv0[s][0], acc[g][0], 0, 0, 0);
-                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g][s], bv0[s][1], acc[g][1], 0, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g < G) {
-#pragma unroll
-                        for (int s = 0; s < KS; ++s) {
-                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[g][s], bv1[s][0], acc[g][0], 0, 0, 0);
-                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[g][s], bv1[s][1], acc[g][1], 0, 0, 0);
+                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][s], bv[s][0], acc[g][0], 0, 0, 0);
+                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][s], bv[s][1], acc[g][1], 0, 0, 0);
                         }
                     }
                 }
             }
-        } else {
-            // one chunk at a time (<=128 VGPRs, 4 waves per SIMD)
-            for (int c = 0; c < nchunk; ++c) {
-                float av0[NG][KS], bv0[KS][2];
-                load_chunk(av0, bv0, idx, k, c);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g < G) {
-#pragma unroll
-                        for (int s = 0; s < KS; ++s) {
-                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g][s], bv0[s][0], acc[g][0], 0, 0, 0);
-                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[g][s], bv0[s][1], acc[g][1], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
+        };
+        run_source(a.x1, a.ldx1, a.c1, 0, nch1);
+        if (a.c2 > 0) run_source(a.x2, a.ldx2, a.c2, nch1, nchunk);
+
         // ---- add the offset's result into the strip.  D[row = 4q + r][col = i]; the pairs of one offset have
-        // distinct output rows, and padded pairs (A == 0 -> acc == 0) are skipped, so no two lanes of an
-        // instruction touch the same address: plain read-modify-write is race free inside the wave.
+        // distinct output rows and padded pairs are skipped, so no two lanes of an instruction touch the same
+        // address: plain read-modify-write is race free inside the wave.
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g < G) {
@@ -211,7 +193,10 @@ __global__ __launch_bounds__(256, PAIR ? 3 : 4) void conv_fwd_kernel(ConvArgs a)
         const f32x4 v = *(const f32x4*)&Cs[cs_index(row, c4)];
         const int col = col0 + c4;
         float* dst = a.y + grow * a.ldy + col;
-        if (a.vec_store && col + 3 < a.cout) {
+        if (a.nslice > 1) {                      // small maps: slices combine with fp32 atomics (Y pre-zeroed)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (col + u < a.cout && v[u] != 0.f) atomicAdd(dst + u, v[u]);
+        } else if (a.vec_store && col + 3 < a.cout) {
             *(f32x4*)dst = v;
         } else {
 #pragma unroll
@@ -220,78 +205,106 @@ __global__ __launch_bounds__(256, PAIR ? 3 : 4) void conv_fwd_kernel(ConvArgs a)
     }
 }
 
+static inline int conv_kc(int cin) { return cin >= 16 ? 16 : 8; }
+
+extern "C" int64_t b2m_weight_pack_size(int32_t K, int32_t cin, int32_t cout) {
+    const int KC = conv_kc(cin);
+    const int64_t nchunk = (cin + KC - 1) / KC, nstrip = (cout + 31) / 32;
+    return (int64_t)K * nstrip * nchunk * (64 * 2 * (KC / 4));
+}
+
+// logical B[k][ci][co]:  transpose == 0:  w[k][ci][co]          (CI = rows, CO = cols)
+//                        transpose == 1:  w[src(k)][sb + co][ci] (CI = cols, CO = sc), src(k) = mirror ? K-1-k : k
+__global__ void weight_pack_kernel(const float* __restrict__ w, int64_t ldw, int K, int rows, int cols, int transpose,
+                                   int mirror, int sb, int CI, int CO, int KC, float* __restrict__ wp) {
+    const int KS = KC / 4, LW = 64 * 2 * KS;
+    const int nchunk = (CI + KC - 1) / KC, nstrip = (CO + 31) / 32;
+    const int64_t total = (int64_t)K * nstrip * nchunk * LW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(e % (2 * KS)); const int64_t e1 = e / (2 * KS);
+        const int lane = (int)(e1 % 64); const int64_t blk = e1 / 64;
+        const int chunk = (int)(blk % nchunk); const int64_t b2 = blk / nchunk;
+        const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
+        const int s = f >> 1, t = f & 1, q = lane >> 4, i = lane & 15;
+        const int ci = chunk * KC + KS * q + s, co = strip * 32 + 16 * t + i;
+        float v = 0.f;
+        if (ci < CI && co < CO) {
+            if (!transpose) v = w[((int64_t)k * rows + ci) * ldw + co];
+            else v = w[((int64_t)(mirror ? K - 1 - k : k) * rows + sb + co) * ldw + ci];
+        }
+        wp[e] = v;
+    }
+}
+extern "C" int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t cout, int32_t transpose,
+                               int32_t mirror, int32_t slice_begin, int32_t slice_count, float* wp, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(w && wp && K >= 1 && cin > 0 && cout > 0 && ldw >= cout, "bad arguments");
+    int CI, CO;
+    if (!transpose) { CI = cin; CO = cout; }
+    else {
+        B2M_CHECK_ARG(slice_begin >= 0 && slice_count > 0 && slice_begin + slice_count <= cin, "bad channel slice");
+        CI = cout; CO = slice_count;
+    }
+    const int64_t total = b2m_weight_pack_size(K, CI, CO);
+    int64_t grid = (total + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    weight_pack_kernel<<<(unsigned)grid, 256, 0, st>>>(w, ldw, K, cin, cout, transpose, mirror, slice_begin, CI, CO,
+                                                       conv_kc(CI), wp);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
-                            const float* w, int64_t ldw, int32_t K, const float* bias, const int32_t* rb_in,
+                            const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
                             const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
                             int32_t cout, int32_t accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(x1 && w && y && c1 > 0 && c2 >= 0 && cout > 0 && K >= 1 && K <= 128, "bad pointers/sizes (K<=128)");
+    B2M_CHECK_ARG(x1 && wp && y && c1 > 0 && c2 >= 0 && cout > 0 && K >= 1 && K <= 128, "bad pointers/sizes (K<=128)");
     B2M_CHECK_ARG((rb_in == nullptr) == (rb_out == nullptr) && (rb_in == nullptr) == (rb_cnt == nullptr),
                   "rulebook pointers must be all set or all NULL");
     B2M_CHECK_ARG(rb_in != nullptr || K == 1, "identity rulebook needs K == 1");
     B2M_CHECK_ARG(c2 == 0 || x2 != nullptr, "x2 is NULL");
-    B2M_CHECK_ARG(ldw >= cout && ldy >= cout && ldx1 >= c1 && (c2 == 0 || ldx2 >= c2), "leading dimension too small");
+    B2M_CHECK_ARG(ldy >= cout && ldx1 >= c1 && (c2 == 0 || ldx2 >= c2), "leading dimension too small");
+    B2M_CHECK_ARG(((uintptr_t)wp % 16) == 0, "packed weights must be 16-byte aligned");
     const int cin = c1 + c2;
-    const int KC = cin >= 16 ? 16 : 8;
+    const int KC = conv_kc(cin);
     const int KS = KC / 4;
     B2M_CHECK_ARG(c2 == 0 || c1 % KC == 0, "with two sources c1 must be a multiple of 16");
-    const bool aligned = c1 % KS == 0 && c2 % KS == 0 && ldx1 % KS == 0 && (c2 == 0 || ldx2 % KS == 0) &&
-                         ((uintptr_t)x1 % (4 * KS)) == 0 && ((uintptr_t)x2 % (4 * KS)) == 0;
+    // fast path: every chunk is complete and every gathered segment is aligned; otherwise per-element loads
+    const bool fast = c1 % KC == 0 && c2 % KC == 0 && ldx1 % KS == 0 && (c2 == 0 || ldx2 % KS == 0) &&
+                      ((uintptr_t)x1 % (4 * KS)) == 0 && ((uintptr_t)x2 % (4 * KS)) == 0;
     if (n_out == 0) return B2M_OK;
     ConvArgs a;
     a.x1 = x1; a.ldx1 = ldx1; a.c1 = c1; a.x2 = x2; a.ldx2 = ldx2; a.c2 = c2;
-    a.w = w; a.ldw = ldw; a.K = K; a.bias = bias;
+    a.wp = wp; a.K = K; a.bias = bias;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
     a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
     a.nstrips = (cout + 31) / 32;
     a.vec_store = (ldy % 4 == 0 && ((uintptr_t)y % 16) == 0) ? 1 : 0;
-    a.a_scalar = aligned ? 0 : 1;
-    const int64_t items = a.ntiles * a.nstrips;
+    // Small maps (deep U-Net levels: a few hundred rows, 256 channels) have too few (tile, strip) items to
+    // fill 1024 SIMDs and each item walks K*cin/16 dependent steps: split the offsets over up to 16 waves.
+    const int64_t items0 = a.ntiles * a.nstrips;
+    int nslice = 1;
+    if (items0 < 4096 && K > 1) {
+        nslice = (int)cdiv64(4096, items0);
+        if (nslice > 16) nslice = 16;
+        if (nslice > K) nslice = K;
+    }
+    a.nslice = nslice;
+    if (nslice > 1 && !accumulate)
+        B2M_HIP(hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)cout * sizeof(float), (size_t)n_out, st));
+    const int64_t items = items0 * nslice;
     const unsigned grid = (unsigned)cdiv64(items, 4);
     const bool ident = rb_in == nullptr;
-    const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (a.a_scalar ? 1 : 0);
-    static int pair = -1;                       // B2M_CONV_PAIR=0/1 selects the chunk pipelining variant
-    if (pair < 0) { const char* e = getenv("B2M_CONV_PAIR"); pair = e ? (atoi(e) != 0) : 0; }
-#define B2M_CONV_CASE(V, KCV, ID, AS)                                             \
-    case V:                                                                       \
-        if (pair) conv_fwd_kernel<KCV, ID, AS, true><<<grid, 256, 0, st>>>(a);    \
-        else conv_fwd_kernel<KCV, ID, AS, false><<<grid, 256, 0, st>>>(a);        \
-        break;
+    const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (fast ? 0 : 1);
+#define B2M_CONV_CASE(V, KCV, ID, AS) case V: conv_fwd_kernel<KCV, ID, AS><<<grid, 256, 0, st>>>(a); break;
     switch (variant) {
         B2M_CONV_CASE(0, 8, false, false) B2M_CONV_CASE(1, 8, false, true) B2M_CONV_CASE(2, 8, true, false)
         B2M_CONV_CASE(3, 8, true, true) B2M_CONV_CASE(4, 16, false, false) B2M_CONV_CASE(5, 16, false, true)
         B2M_CONV_CASE(6, 16, true, false) B2M_CONV_CASE(7, 16, true, true)
     }
 #undef B2M_CONV_CASE
-    B2M_LAUNCH_CHECK();
-    return B2M_OK;
-}
-
-// ------------------------------------------------------------------ weight transpose (+ mirror)
-__global__ void weight_transpose_kernel(const float* __restrict__ w, int64_t ldw, int K, int cin, int cout,
-                                        float* __restrict__ wt, int64_t ldwt, int mirror) {
-    // 32x32 tiles through LDS so both the read (along co) and the write (along ci) are coalesced
-    __shared__ float t[32][33];
-    const int kk = blockIdx.z, src = mirror ? K - 1 - kk : kk;
-    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 8 rows per pass
-    for (int r = ty; r < 32; r += 8) {
-        int ci = ci0 + r, co = co0 + tx;
-        t[r][tx] = (ci < cin && co < cout) ? w[((int64_t)src * cin + ci) * ldw + co] : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        int co = co0 + r, ci = ci0 + tx;
-        if (co < cout && ci < cin) wt[((int64_t)kk * cout + co) * ldwt + ci] = t[tx][r];
-    }
-}
-extern "C" int b2m_weight_transpose(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t cout, float* wt,
-                                    int64_t ldwt, int32_t mirror, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(w && wt && K >= 1 && cin > 0 && cout > 0 && ldw >= cout && ldwt >= cin, "bad arguments");
-    dim3 grid((cout + 31) / 32, (cin + 31) / 32, K);
-    weight_transpose_kernel<<<grid, 256, 0, st>>>(w, ldw, K, cin, cout, wt, ldwt, mirror);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

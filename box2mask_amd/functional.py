@@ -22,13 +22,24 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def conv_raw(x1, x2, w3, bias, rb: Rulebook | None, n_out: int, cout: int, w_col0: int = 0, out=None,
-             accumulate=False):
-    """Y = sum_k [x1|x2][in_k] @ w3[k][:, w_col0:w_col0+cout]  (w3: (K, Cin, ldw) contiguous)."""
-    K, cin, ldw = w3.shape
+def weight_pack(w3, transpose: bool = False, mirror: bool = False, slice_begin: int = 0, slice_count: int | None = None):
+    """(K,Cin,Cout) weights -> packed MFMA B-fragment image (include/b2m.h: b2m_weight_pack).
+    transpose=True packs the data-gradient operand for input channels [slice_begin, slice_begin+slice_count)."""
+    K, cin, cout = w3.shape
+    if slice_count is None:
+        slice_count = cin
+    ci, co = (cout, slice_count) if transpose else (cin, cout)
+    size = _lib.load().b2m_weight_pack_size(K, ci, co)
+    wp = torch.empty(size, dtype=torch.float32, device=w3.device)
+    _call('b2m_weight_pack', w3.data_ptr(), w3.stride(1), K, cin, cout, 1 if transpose else 0, 1 if mirror else 0,
+          slice_begin, slice_count, wp.data_ptr())
+    return wp
+
+
+def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: int, out=None, accumulate=False):
+    """Y = sum_k [x1|x2][in_k] @ B[k] with B given as a packed image for (K, c1+c2, cout)."""
     c1 = x1.shape[1]
     c2 = x2.shape[1] if x2 is not None else 0
-    assert c1 + c2 == cin, (c1, c2, cin)
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=x1.device)
     if rb is None:
@@ -38,28 +49,21 @@ def conv_raw(x1, x2, w3, bias, rb: Rulebook | None, n_out: int, cout: int, w_col
         assert rb.K == K and rb.n_out == n_out
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
     _call('b2m_conv_fwd', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
-          w3.data_ptr() + 4 * w_col0, ldw, K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
+          wp.data_ptr(), K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
           1 if accumulate else 0)
     return out
 
 
-def weight_transpose(w3, mirror: bool):
-    """(K,Cin,Cout) -> (K,Cout,Cin) with optional offset mirroring (data-gradient weights)."""
-    K, cin, cout = w3.shape
-    wt = torch.empty((K, cout, cin), dtype=torch.float32, device=w3.device)
-    _call('b2m_weight_transpose', w3.data_ptr(), cout, K, cin, cout, wt.data_ptr(), cin, 1 if mirror else 0)
-    return wt
-
-
-def wgrad_raw(x, dy, rb: Rulebook | None, K: int, dw3, ci0: int):
-    """dw3[:, ci0:ci0+x.shape[1], :] += sum_pairs x[in]^T dy[out]."""
+def wgrad_raw(x, dy, rb: Rulebook | None, K: int, dw3, ci0: int, cin: int | None = None):
+    """dw3[:, ci0:ci0+cin, :] += sum_pairs x[in, :cin]^T dy[out]   (cin defaults to x.shape[1])."""
     cin_total, cout = dw3.shape[1], dw3.shape[2]
+    cin = x.shape[1] if cin is None else cin
     n_out = dy.shape[0]
     if rb is None:
         rbi = rbo = rbc = None
     else:
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
-    _call('b2m_conv_wgrad', x.data_ptr(), x.stride(0), x.shape[1], dy.data_ptr(), dy.stride(0), cout, rbi, rbo, rbc,
+    _call('b2m_conv_wgrad', x.data_ptr(), x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, rbi, rbo, rbc,
           n_out, K, dw3.data_ptr() + 4 * ci0 * cout, cout, cin_total * cout)
 
 
@@ -73,11 +77,18 @@ class _SparseConv(torch.autograd.Function):
     def forward(ctx, x1, x2, weight, bias, rb_f, rb_b, mirror, n_out):
         x1 = _f32c(x1)
         x2 = _f32c(x2) if x2 is not None else None
+        c1 = x1.shape[1]
+        if x2 is None and c1 % 4 != 0 and c1 < 16:
+            # few, odd input channels (the 6-channel network input): zero-pad to a multiple of 4 so that the
+            # gather uses aligned vector loads; the packed weights are zero there as well
+            x1 = torch.nn.functional.pad(x1, (0, (-c1) % 4))
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         w3 = _f32c(w3)
-        y = conv_raw(x1, x2, w3, bias, rb_f, n_out, w3.shape[2])
+        K, cin, cout = w3.shape
+        wp = weight_pack(w3)
+        y = conv_raw(x1, x2, wp, K, bias, rb_f, n_out, cout)
         ctx.save_for_backward(x1, x2, weight, bias)
-        ctx.rb_f, ctx.rb_b, ctx.mirror = rb_f, rb_b, mirror
+        ctx.rb_f, ctx.rb_b, ctx.mirror, ctx.c1 = rb_f, rb_b, mirror, c1
         return y
 
     @staticmethod
@@ -87,20 +98,19 @@ class _SparseConv(torch.autograd.Function):
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         w3 = _f32c(w3)
         K, cin, cout = w3.shape
+        c1 = ctx.c1
         dx1 = dx2 = dw = db = None
-        need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
-        if need1 or need2:
-            wt = weight_transpose(w3, ctx.mirror)          # (K, cout, cin)
-            c1 = x1.shape[1]
-            if need1:
-                dx1 = conv_raw(dy, None, wt, None, ctx.rb_b, x1.shape[0], c1, w_col0=0)
-            if need2:
-                dx2 = conv_raw(dy, None, wt, None, ctx.rb_b, x2.shape[0], x2.shape[1], w_col0=c1)
+        if ctx.needs_input_grad[0]:
+            wt = weight_pack(w3, True, ctx.mirror, 0, c1)
+            dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1)
+        if x2 is not None and ctx.needs_input_grad[1]:
+            wt = weight_pack(w3, True, ctx.mirror, c1, x2.shape[1])
+            dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1])
         if ctx.needs_input_grad[2]:
             dw3 = torch.zeros_like(w3)
-            wgrad_raw(x1, dy, ctx.rb_f, K, dw3, 0)
+            wgrad_raw(x1, dy, ctx.rb_f, K, dw3, 0, c1)
             if x2 is not None:
-                wgrad_raw(x2, dy, ctx.rb_f, K, dw3, x1.shape[1])
+                wgrad_raw(x2, dy, ctx.rb_f, K, dw3, c1, x2.shape[1])
             dw = dw3 if weight.dim() == 3 else dw3[0]
         if bias is not None and ctx.needs_input_grad[3]:
             db = dy.sum(0, keepdim=True).reshape(bias.shape)

@@ -83,26 +83,34 @@ int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out,
 
 /* ---------------------------------------------------------------- sparse convolution (fp32, MFMA) */
 
-/* Y[o, 0:cout] (+)= sum_k [X1|X2][in_k(o), :] @ W[k]  (+ bias)
+/* Packed weight image read by b2m_conv_fwd.  The logical operand is B[k][ci][co]:
+ *   transpose == 0 : B = w                                   (ci < cin, co < cout)      forward weights
+ *   transpose == 1 : B[k][ci][co] = w[src(k)][slice_begin + co][ci], src(k) = mirror ? K-1-k : k
+ *                    (ci < cout, co < slice_count)            weights of the data gradient w.r.t. the
+ *                    input channels [slice_begin, slice_begin + slice_count) (mirror: stride-1 odd kernels)
+ * w is [K][cin][ldw].  Layout: blocks of 64 lanes x 2*KS floats ordered [k][strip of 32 co][chunk of KC ci],
+ * KC = 16 if the operand has >= 16 input channels else 8, KS = KC/4; lane (q = lane/16, i = lane%16) holds
+ * B[chunk*KC + KS*q + s][strip*32 + 16*t + i] at float 2*s + t; zero padded.  Size: b2m_weight_pack_size. */
+int64_t b2m_weight_pack_size(int32_t K, int32_t cin, int32_t cout);
+int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t cout, int32_t transpose,
+                    int32_t mirror, int32_t slice_begin, int32_t slice_count, float* wp, void* stream);
+
+/* Y[o, 0:cout] (+)= sum_k [X1|X2][in_k(o), :] @ B[k]  (+ bias)
  * Replaces [ME] ConvolutionForward / ConvolutionTransposeForward (resnet.py:61-65,
  * detection_net.py:37-135) and, with an identity rulebook (rb_in == NULL, K == 1), the 1x1
  * `mm` fast path (resnet.py:151-158, detection_net.py:172-193).  Two sources implement
  * ME.cat (detection_net.py:286-336) without materialising the concatenation: input channel
- * c < c1 comes from x1, the rest from x2 (c2 may be 0, x2 NULL).
- *   w     [K][c1+c2][ldw]   (ldw >= cout)
+ * c < c1 comes from x1, the rest from x2 (c2 may be 0, x2 NULL; c1 % 16 == 0 when c2 > 0).
+ *   wp    packed B for (K, c1+c2, cout), see b2m_weight_pack
  *   bias  [cout] or NULL
  *   accumulate != 0: add to the existing Y instead of overwriting
- * The same entry computes the data gradient when called with the transposed/mirrored weights
- * produced by b2m_weight_transpose. */
+ * The same entry computes the data gradient when given the transposed/mirrored image.
+ * Maps with fewer than 4096 (tile, 32-channel strip) items split the kernel offsets over several waves
+ * that combine with fp32 atomics (sum order then varies in the last bits). */
 int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
-                 const float* w, int64_t ldw, int32_t K, const float* bias,
+                 const float* wp, int32_t K, const float* bias,
                  const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                  int64_t n_out, float* y, int64_t ldy, int32_t cout, int32_t accumulate, void* stream);
-
-/* wt[kk][co][ci] = w[src(kk)][ci][co], src(kk) = mirror ? K-1-kk : kk.
- * w: [K][cin][ldw], wt: [K][cout][ldwt]. */
-int b2m_weight_transpose(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t cout,
-                         float* wt, int64_t ldwt, int32_t mirror, void* stream);
 
 /* dW[k][ci][co] += sum over pairs (i,o) of offset k:  X[i, ci] * dY[o, co]     (fp32 atomics)
  * Replaces [ME] ConvolutionBackward (weight part).  x: rows indexed by rb_in (ldx, cin columns used),

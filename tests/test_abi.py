@@ -15,7 +15,7 @@ def _header_decls():
     src = open(os.path.join(ROOT, 'include', 'b2m.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     decls = {}
-    for m in re.finditer(r'\b(int|const char\*)\s+(b2m_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+    for m in re.finditer(r'\b(int64_t|int|const char\*)\s+(b2m_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
         args = [a.strip() for a in m.group(3).replace('\n', ' ').split(',')]
         if args == ['void']:
             args = []

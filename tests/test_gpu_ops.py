@@ -103,7 +103,7 @@ def test_conv_accumulate_and_empty_tiles(maps):
     y0 = torch.randn(len(c), 64)
     ref = S.conv_nbr(x, w, S.kernel_map_same(c, 3, 1)) + y0
     out = y0.cuda().clone()
-    F_.conv_raw(x.cuda(), None, w.cuda(), None, rb, len(c), 64, out=out, accumulate=True)
+    F_.conv_raw(x.cuda(), None, F_.weight_pack(w.cuda()), 27, None, rb, len(c), 64, out=out, accumulate=True)
     _close(out, ref, 'accumulate')
 
 

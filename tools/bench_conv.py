@@ -29,7 +29,8 @@ for name, rb, K, c1, c2, co in [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 12
     w = torch.randn(K, c1 + c2, co, device='cuda') * 0.05
     P = rb.pairs if rb is not None else n_out
     fl = 2.0 * P * (c1 + c2) * co
-    ms = timeit(lambda: F_.conv_raw(x1, x2, w, None, rb, n_out, co))
+    wp = F_.weight_pack(w)
+    ms = timeit(lambda: F_.conv_raw(x1, x2, wp, K, None, rb, n_out, co))
     dy = torch.randn(n_out, co, device='cuda'); dw = torch.zeros_like(w)
     xs = x1 if c2 == 0 else torch.cat([x1, x2], 1)
     msw = timeit(lambda: F_.wgrad_raw(xs, dy, rb, K, dw, 0))

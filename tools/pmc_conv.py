@@ -1,0 +1,16 @@
+"""One L0 conv forward for PMC collection (rocprofv3 --pmc ...)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from box2mask_amd import synth, functional as F_
+from box2mask_amd.sparse import CoordinateManager
+b = synth.make_batch(4, seed0=0)
+m = CoordinateManager(b['vox_coords'])
+rb = m.rulebook_same(0, 3)
+x = torch.randn(rb.n_in, 96, device='cuda'); w = torch.randn(27, 96, 96, device='cuda') * 0.05
+for _ in range(3):
+    F_.conv_raw(x, None, F_.weight_pack(w), 27, None, rb, rb.n_out, 96)
+dy = torch.randn(rb.n_out, 96, device='cuda'); dw = torch.zeros_like(w)
+for _ in range(2):
+    F_.wgrad_raw(x, dy, rb, 27, dw, 0)
+torch.cuda.synchronize()
