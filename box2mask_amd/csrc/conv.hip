@@ -23,6 +23,7 @@ struct ConvArgs {
     int64_t n_out, ntiles;
     float* y; int64_t ldy; int cout; int accumulate; int nstrips; int vec_store;
     int nslice;      // >1: the tile's active offsets are dealt to nslice waves which add their strips atomically
+    const float* zeros;   // address of g_zeros passed as data (a select of addresses, not a branch around the load)
 };
 
 // loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
@@ -36,7 +37,7 @@ __device__ __forceinline__ int cs_index(int row, int col) { return row * 32 + (c
 // Packed weight image (b2m_weight_pack): blocks of 64 lanes x 2*KS floats, ordered [k][strip][chunk]; lane
 // (q,i) of a block holds B[chunk*KC + KS*q + s][strip*32 + 16*t + i] at float 2*s + t.  One or two 16-byte
 // loads per lane per chunk, contiguous over the wave, zero padded: no predicates, no address arithmetic.
-template <int KC, bool IDENT, bool ASCALAR>
+template <int KC, bool IDENT, bool ASCALAR, bool PREF>
 __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
     constexpr int KS = KC / 4;                // k-steps per chunk == floats per lane per gathered row
     constexpr int LW = 64 * 2 * KS;           // floats per packed weight block
@@ -86,18 +87,20 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
     uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
 
     int ord = 0;
-    for (;;) {
-        int k;
-        if (m0) { k = __builtin_ctzll(m0); m0 &= m0 - 1; }
-        else if (m1) { k = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
-        else break;
-        if ((ord++) % a.nslice != slice) continue;      // split-K: active offsets dealt round-robin to the slices
-        const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
-        const int G = (n + 15) >> 4;           // 1..4 dense row groups
-        // pair lists: lane (i,q) gathers input row idx[g] and later flushes the 4 output rows packed in out[g].
-        // Rows of padded pairs (idx < 0) are clamped to row 0: an MFMA output row depends only on its own A row,
-        // and the flush below skips padded pairs, so whatever they compute is never used.
-        int idx[NG]; uint32_t out[NG];
+    // next active offset of this wave (split-K: active offsets are dealt round-robin to the slices)
+    auto advance = [&]() -> int {
+        for (;;) {
+            int k;
+            if (m0) { k = __builtin_ctzll(m0); m0 &= m0 - 1; }
+            else if (m1) { k = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+            else return -1;
+            if ((ord++) % a.nslice == slice) return k;
+        }
+    };
+    // pair lists of one offset: lane (i,q) gathers input row idx[g] and later flushes the 4 output rows packed
+    // in out[g].  Rows of padded pairs (idx < 0) are clamped to row 0: an MFMA output row depends only on its own
+    // A row, and the flush skips padded pairs, so whatever they compute is never used.
+    auto load_lists = [&](int k, int (&idx)[NG], uint32_t (&out)[NG]) {
         const int64_t base = (int64_t)k * ldr + row0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -111,6 +114,27 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
                 idx[g] = r < 0 ? 0 : r;
                 out[g] = *(const uint32_t*)(a.rb_out + base + 16 * g + 4 * q);
             }
+        }
+    };
+    int k = advance();
+    int idxN[NG]; uint32_t outN[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { idxN[g] = 0; outN[g] = 0; }
+    if (PREF && k >= 0) load_lists(k, idxN, outN);
+    while (k >= 0) {
+        const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
+        const int G = (n + 15) >> 4;           // 1..4 dense row groups
+        int idx[NG]; uint32_t out[NG];
+        int k2;
+        if constexpr (PREF) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { idx[g] = idxN[g]; out[g] = outN[g]; }
+            // the lists of the NEXT offset are requested now and land while this offset computes
+            k2 = advance();
+            if (k2 >= 0) load_lists(k2, idxN, outN);
+        } else {
+            load_lists(k, idx, out);
+            k2 = advance();
         }
         f32x4 acc[NG][2];
 #pragma unroll
@@ -141,7 +165,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
                     const float* p = pa[g] + cb;
                     if constexpr (ASCALAR) {       // odd channel counts (head gradients): per-element, predicated
 #pragma unroll
-                        for (int s = 0; s < KS; ++s) av[g][s] = *((cb + KS * q + s < csrc) ? p + s : g_zeros);
+                        for (int s = 0; s < KS; ++s) av[g][s] = *((cb + KS * q + s < csrc) ? p + s : a.zeros);
                     } else if constexpr (KS == 4) {
                         const f32x4 v = *(const f32x4*)p;
                         av[g][0] = v[0]; av[g][1] = v[1]; av[g][2] = v[2]; av[g][3] = v[3];
@@ -182,6 +206,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
                 }
             }
         }
+        k = k2;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
@@ -205,6 +230,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
     }
 }
 
+static int env_flag(const char* name, int dflt);
 static inline int conv_kc(int cin) { return cin >= 16 ? 16 : 8; }
 
 extern "C" int64_t b2m_weight_pack_size(int32_t K, int32_t cin, int32_t cout) {
@@ -292,13 +318,21 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
         if (nslice > K) nslice = K;
     }
     a.nslice = nslice;
+    static const float* zeros_addr = nullptr;
+    if (!zeros_addr) B2M_HIP(hipGetSymbolAddress((void**)&zeros_addr, HIP_SYMBOL(g_zeros)));
+    a.zeros = zeros_addr;
     if (nslice > 1 && !accumulate)
         B2M_HIP(hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)cout * sizeof(float), (size_t)n_out, st));
     const int64_t items = items0 * nslice;
     const unsigned grid = (unsigned)cdiv64(items, 4);
     const bool ident = rb_in == nullptr;
     const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (fast ? 0 : 1);
-#define B2M_CONV_CASE(V, KCV, ID, AS) case V: conv_fwd_kernel<KCV, ID, AS><<<grid, 256, 0, st>>>(a); break;
+    const bool pref = env_flag("B2M_CONV_PREF", 0) != 0;
+#define B2M_CONV_CASE(V, KCV, ID, AS)                                                  \
+    case V:                                                                            \
+        if (pref) conv_fwd_kernel<KCV, ID, AS, true><<<grid, 256, 0, st>>>(a);         \
+        else conv_fwd_kernel<KCV, ID, AS, false><<<grid, 256, 0, st>>>(a);             \
+        break;
     switch (variant) {
         B2M_CONV_CASE(0, 8, false, false) B2M_CONV_CASE(1, 8, false, true) B2M_CONV_CASE(2, 8, true, false)
         B2M_CONV_CASE(3, 8, true, true) B2M_CONV_CASE(4, 16, false, false) B2M_CONV_CASE(5, 16, false, true)
@@ -320,9 +354,24 @@ struct WgradArgs {
     int64_t n_out, ntiles; int K;
     float* dw; int64_t lddw, dw_kstride;
     int tiles_per_chunk, nmb, nnb;
+    const float* zeros;      // address of g_zeros passed as data: a select of ADDRESSES, not a branch around the load
 };
 
-template <int MI, int NJ>
+template <int N> struct vecf;
+template <> struct vecf<1> { typedef float type; };
+template <> struct vecf<2> { typedef float type __attribute__((ext_vector_type(2))); };
+struct __attribute__((packed, aligned(4))) f32x3p { float a, b, c; };    // 12 bytes, 4-byte aligned
+template <> struct vecf<3> { typedef f32x3p type; };
+template <> struct vecf<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int N> __device__ __forceinline__ float vget(const typename vecf<N>::type& v, int j) { return v[j]; }
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float vget<3>(const f32x3p& v, int j) { return j == 0 ? v.a : (j == 1 ? v.b : v.c); }
+
+// VEC (off by default: measured 35 vs 45 TFLOP/s for the scalar map on 96->96, A/B in tools/bench_conv.py):
+// every block is complete and aligned.  The channel <-> (sub-tile, lane) map is then chosen so that a lane
+// owns MI (NJ) CONSECUTIVE channels: ci = ci0 + MI*i + m, co = co0 + NJ*i + n -- one 4..16-byte load per lane
+// and pair instead of MI (NJ) scalar loads; the wave reads 64*MI contiguous bytes of a gathered row.
+template <int MI, int NJ, bool VEC, bool FLAT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -341,33 +390,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int64_t t0 = (int64_t)blockIdx.y * a.tiles_per_chunk;
     int64_t t1 = t0 + a.tiles_per_chunk;
     if (t1 > a.ntiles) t1 = a.ntiles;
-    for (int64_t tile = t0; tile < t1; ++tile) {
-        const int64_t row0 = tile * B2M_TILE;
-        int n;
-        if (identity) { int64_t rem = a.n_out - row0; n = rem < B2M_TILE ? (int)rem : B2M_TILE; }
-        else n = __builtin_amdgcn_readfirstlane(a.rb_cnt[(int64_t)k * a.ntiles + tile]);
-        const int G = (n + 15) >> 4;
-        for (int g = 0; g < G; ++g) {
-            int rin[4]; uint32_t o4;
-            if (identity) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    int64_t r = row0 + 16 * g + 4 * q + s;
-                    rin[s] = r < a.n_out ? (int)r : -1;
-                }
-                const int p = 16 * g + 4 * q;
-                o4 = (uint32_t)p | ((uint32_t)(p + 1) << 8) | ((uint32_t)(p + 2) << 16) | ((uint32_t)(p + 3) << 24);
-            } else {
-                const int64_t base = (int64_t)k * ldr + row0 + 16 * g + 4 * q;
-                i32x4 v = *(const i32x4*)(a.rb_in + base);
-                rin[0] = v[0]; rin[1] = v[1]; rin[2] = v[2]; rin[3] = v[3];
-                o4 = *(const uint32_t*)(a.rb_out + base);
-            }
-            float av[4][MI], bv[4][NJ];
+    // The chunk is walked as a flat sequence of group SLOTS (4 per tile, 16 pairs each).  The pair list of slot
+    // s+1 is requested before the data of slot s (independent loads in flight together instead of one
+    // dependent chain per group); ping-pong registers, no copies.  Empty slots (all -1) skip loads and MFMAs.
+    const int64_t s_begin = t0 * NG, s_end = t1 * NG;
+    const int64_t kbase = (int64_t)k * ldr;
+    auto load_slot = [&](int64_t slot, int (&rin)[4], uint32_t& o4) {
+        if (slot >= s_end) slot = s_end - 1;
+        if (identity) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int r = rin[s];
-                const int64_t ro = row0 + ((o4 >> (8 * s)) & 255);
+                int64_t r = slot * 16 + 4 * q + s;
+                rin[s] = r < a.n_out ? (int)r : -1;
+            }
+            const int p = (int)(slot & 3) * 16 + 4 * q;
+            o4 = (uint32_t)p | ((uint32_t)(p + 1) << 8) | ((uint32_t)(p + 2) << 16) | ((uint32_t)(p + 3) << 24);
+        } else {
+            const int64_t base = kbase + slot * 16 + 4 * q;
+            i32x4 v = *(const i32x4*)(a.rb_in + base);
+            rin[0] = v[0]; rin[1] = v[1]; rin[2] = v[2]; rin[3] = v[3];
+            o4 = *(const uint32_t*)(a.rb_out + base);
+        }
+    };
+    auto process = [&](int64_t slot, const int (&rin)[4], uint32_t o4) {
+        if (__ballot(rin[0] >= 0) == 0) return;        // wave-uniform: empty slot
+        const int64_t row0 = (slot >> 2) * B2M_TILE;
+        float av[4][MI], bv[4][NJ];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = rin[s];
+            const int64_t ro = row0 + ((o4 >> (8 * s)) & 255);
+            if constexpr (VEC) {
+                // padded pairs (r < 0) must contribute zero to the sum over pairs: read the zero buffer
+                typedef typename vecf<MI>::type VA;
+                typedef typename vecf<NJ>::type VB;
+                const VA va = *(const VA*)(r >= 0 ? a.x + (int64_t)r * a.ldx + ci0 + MI * i : a.zeros);
+                const VB vb = *(const VB*)(r >= 0 ? a.dy + ro * a.lddy + co0 + NJ * i : a.zeros);
+#pragma unroll
+                for (int m = 0; m < MI; ++m) av[s][m] = vget<MI>(va, m);
+#pragma unroll
+                for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = vget<NJ>(vb, nn);
+            } else {
 #pragma unroll
                 for (int m = 0; m < MI; ++m) {
                     const int ci = ci0 + 16 * m + i;
@@ -379,23 +442,49 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                     bv[s][nn] = (r >= 0 && co < a.cout) ? a.dy[ro * a.lddy + co] : 0.f;
                 }
             }
+        }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int m = 0; m < MI; ++m)
+            for (int m = 0; m < MI; ++m)
 #pragma unroll
-                    for (int nn = 0; nn < NJ; ++nn)
-                        acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][m], bv[s][nn], acc[m][nn], 0, 0, 0);
+                for (int nn = 0; nn < NJ; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][m], bv[s][nn], acc[m][nn], 0, 0, 0);
+    };
+    if constexpr (FLAT) {
+        if (s_begin < s_end) {
+            int rinA[4], rinB[4]; uint32_t oA, oB;
+            load_slot(s_begin, rinA, oA);
+            for (int64_t slot = s_begin; slot < s_end; slot += 2) {
+                load_slot(slot + 1, rinB, oB);
+                process(slot, rinA, oA);
+                load_slot(slot + 2, rinA, oA);
+                if (slot + 1 < s_end) process(slot + 1, rinB, oB);
+            }
+        }
+    } else {
+        // plain nested walk: only the non-empty groups of every tile, list then data (dependent loads)
+        for (int64_t tile = t0; tile < t1; ++tile) {
+            int n;
+            if (identity) { int64_t rem = a.n_out - tile * B2M_TILE; n = rem < B2M_TILE ? (int)rem : B2M_TILE; }
+            else n = __builtin_amdgcn_readfirstlane(a.rb_cnt[(int64_t)k * a.ntiles + tile]);
+            const int G = (n + 15) >> 4;
+            for (int g = 0; g < G; ++g) {
+                int rin[4]; uint32_t o4;
+                load_slot(tile * NG + g, rin, o4);
+                process(tile * NG + g, rin, o4);
+            }
         }
     }
-    // D[row = 4q + r (ci), col = i (co)]
+    // D[row = 4q + r (A's lane index), col = i (B's lane index)]
 #pragma unroll
     for (int m = 0; m < MI; ++m)
 #pragma unroll
         for (int nn = 0; nn < NJ; ++nn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ci = ci0 + 16 * m + 4 * q + r, co = co0 + 16 * nn + i;
+                const int ci = VEC ? ci0 + MI * (4 * q + r) + m : ci0 + 16 * m + 4 * q + r;
+                const int co = VEC ? co0 + NJ * i + nn : co0 + 16 * nn + i;
                 if (ci < a.cin && co < a.cout) {
                     const float v = acc[m][nn][r];
                     if (v != 0.f) atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)ci * a.lddw + co], v);
@@ -403,15 +492,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
 }
 
-template <int MI>
+template <int MI, bool VEC, bool FLAT>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
     switch (NJ) {
-        case 1: conv_wgrad_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
-        case 2: conv_wgrad_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
-        case 3: conv_wgrad_kernel<MI, 3><<<grid, 256, 0, st>>>(a); break;
-        default: conv_wgrad_kernel<MI, 4><<<grid, 256, 0, st>>>(a); break;
+        case 1: conv_wgrad_kernel<MI, 1, VEC, FLAT><<<grid, 256, 0, st>>>(a); break;
+        case 2: conv_wgrad_kernel<MI, 2, VEC, FLAT><<<grid, 256, 0, st>>>(a); break;
+        case 3: conv_wgrad_kernel<MI, 3, VEC, FLAT><<<grid, 256, 0, st>>>(a); break;
+        default: conv_wgrad_kernel<MI, 4, VEC, FLAT><<<grid, 256, 0, st>>>(a); break;
     }
 }
+template <bool VEC, bool FLAT>
+static void launch_wgrad(int MI, int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
+    switch (MI) {
+        case 1: launch_wgrad_nj<1, VEC, FLAT>(NJ, grid, st, a); break;
+        case 2: launch_wgrad_nj<2, VEC, FLAT>(NJ, grid, st, a); break;
+        case 3: launch_wgrad_nj<3, VEC, FLAT>(NJ, grid, st, a); break;
+        default: launch_wgrad_nj<4, VEC, FLAT>(NJ, grid, st, a); break;
+    }
+}
+// tuning switches (A/B inside one process: tools/bench_conv.py); read at every call
+static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int pick_blk(int c) {      // 16-column sub-tiles per wave block
     if (c % 64 == 0) return 4;
     if (c % 48 == 0) return 3;
@@ -437,6 +537,9 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const fl
     a.x = x; a.ldx = ldx; a.cin = cin; a.dy = dy; a.lddy = lddy; a.cout = cout;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE); a.K = K; a.dw = dw; a.lddw = lddw; a.dw_kstride = dw_kstride;
+    static const float* zeros_addr = nullptr;
+    if (!zeros_addr) B2M_HIP(hipGetSymbolAddress((void**)&zeros_addr, HIP_SYMBOL(g_zeros)));
+    a.zeros = zeros_addr;
     const int MI = pick_blk(cin), NJ = pick_blk(cout);
     a.nmb = (cin + 16 * MI - 1) / (16 * MI);
     a.nnb = (cout + 16 * NJ - 1) / (16 * NJ);
@@ -450,12 +553,12 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const fl
     if (cdiv64(a.ntiles, tpc) > 65535) tpc = cdiv64(a.ntiles, 65535);
     a.tiles_per_chunk = (int)tpc;
     dim3 grid((unsigned)K, (unsigned)cdiv64(a.ntiles, tpc), (unsigned)((a.nmb * a.nnb + 3) / 4));
-    switch (MI) {
-        case 1: launch_wgrad_nj<1>(NJ, grid, st, a); break;
-        case 2: launch_wgrad_nj<2>(NJ, grid, st, a); break;
-        case 3: launch_wgrad_nj<3>(NJ, grid, st, a); break;
-        default: launch_wgrad_nj<4>(NJ, grid, st, a); break;
-    }
+    // vector path: complete, aligned blocks (every trunk layer: channel counts are multiples of 32)
+    const bool vec = cin % (16 * MI) == 0 && cout % (16 * NJ) == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
+                     ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && env_flag("B2M_WGRAD_VEC", 0) != 0;
+    const bool flat = env_flag("B2M_WGRAD_FLAT", 0) != 0;
+    if (vec) { if (flat) launch_wgrad<true, true>(MI, NJ, grid, st, a); else launch_wgrad<true, false>(MI, NJ, grid, st, a); }
+    else launch_wgrad<false, false>(MI, NJ, grid, st, a);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -1,4 +1,5 @@
-"""Micro-benchmark of the sparse-conv kernels on one synthetic scene batch (GPU box)."""
+"""Micro-benchmark of the sparse-conv kernels on one synthetic scene batch, with interleaved A/B rounds of
+the tuning switches (B2M_CONV_PREF, B2M_WGRAD_FLAT) inside one process (same device, same clocks)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,21 +9,22 @@ from box2mask_amd.sparse import CoordinateManager
 bs = int(os.environ.get('BS', '4'))
 b = synth.make_batch(bs, seed0=0)
 m = CoordinateManager(b['vox_coords'])
+rb0 = m.rulebook_same(0, 3); m.ensure_level(2); rb1 = m.rulebook_same(1, 3); rbu = m.rulebook_up(0); rb5 = m.rulebook_same(0, 5)
 torch.cuda.synchronize()
-t = time.time(); rb0 = m.rulebook_same(0, 3); m.ensure_level(2); rb1 = m.rulebook_same(1, 3); rbu = m.rulebook_up(0); rbd = m.rulebook_down(0); rb5 = m.rulebook_same(0, 5)
-torch.cuda.synchronize(); print('maps %.1f ms' % ((time.time() - t) * 1e3), 'N0', m.n(0), 'pairs k3', rb0.pairs, 'k5', rb5.pairs)
+print('N0', m.n(0), 'pairs k3', rb0.pairs, 'k5', rb5.pairs)
 
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=4):
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 
-for name, rb, K, c1, c2, co in [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
-                               ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L1 k3 32->32', rb1, 27, 32, 0, 32), ('L0 up 96->96', rbu, 8, 96, 0, 96),
-                               ('L0 k5 6->32', rb5, 125, 6, 0, 32), ('L0 1x1 128->96', None, 1, 128, 0, 96)]:
+VARIANTS = [('base', {}), ('scalar', {'B2M_WGRAD_VEC': '0'}), ('flat', {'B2M_WGRAD_FLAT': '1'})]
+cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
+         ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
+         ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64)]
+for name, rb, K, c1, c2, co in cases:
     n_out = rb.n_out if rb is not None else m.n(0)
     n_in = rb.n_in if rb is not None else m.n(0)
     x1 = torch.randn(n_in, c1, device='cuda'); x2 = torch.randn(n_in, c2, device='cuda') if c2 else None
@@ -30,8 +32,18 @@ for name, rb, K, c1, c2, co in [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 12
     P = rb.pairs if rb is not None else n_out
     fl = 2.0 * P * (c1 + c2) * co
     wp = F_.weight_pack(w)
-    ms = timeit(lambda: F_.conv_raw(x1, x2, wp, K, None, rb, n_out, co))
     dy = torch.randn(n_out, co, device='cuda'); dw = torch.zeros_like(w)
     xs = x1 if c2 == 0 else torch.cat([x1, x2], 1)
-    msw = timeit(lambda: F_.wgrad_raw(xs, dy, rb, K, dw, 0))
-    print('%-24s fwd %8.3f ms %6.2f TF | wgrad %8.3f ms %6.2f TF | pairs %d' % (name, ms, fl / ms / 1e9, msw, fl / msw / 1e9, P))
+    f_fwd = lambda: F_.conv_raw(x1, x2, wp, K, None, rb, n_out, co)
+    f_wg = lambda: F_.wgrad_raw(xs, dy, rb, K, dw, 0)
+    res = {v: [[], []] for v, _ in VARIANTS}
+    for rnd in range(4):
+        for v, env in VARIANTS:
+            for k_ in ('B2M_CONV_PREF', 'B2M_WGRAD_FLAT', 'B2M_WGRAD_VEC'): os.environ.pop(k_, None)
+            os.environ.update(env)
+            if rnd == 0: f_fwd(); f_wg(); torch.cuda.synchronize()
+            res[v][0].append(timeit(f_fwd)); res[v][1].append(timeit(f_wg))
+    line = '%-22s' % name
+    for v, _ in VARIANTS:
+        line += ' | %s fwd %6.2f TF wg %6.2f TF' % (v, fl / min(res[v][0]) / 1e9, fl / min(res[v][1]) / 1e9)
+    print(line)
