@@ -122,7 +122,7 @@ class SelectionNet(ResNetBase):
     @staticmethod
     def _cbr(conv, bn, x):
         out = conv(x)
-        return out.new(bn.apply_bn(out.F, relu=True))
+        return out.new(bn.apply_bn(out.F, relu=True, count_key=ME.count_key_of(out)))
 
     def forward(self, x, pooling_ids=None, n_segments=None):
         """x: SparseTensor at tensor stride 1 -> dict head-name -> tensor holder with `.F`

@@ -129,16 +129,38 @@ def _sync_group():
     return dist.group.WORLD if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
-def merge_bn_sums(local_sums: torch.Tensor, local_count: float, group=None):
-    """SyncBN statistics exchange: all-reduce (sum x, sum x^2, count) over the data-parallel group.
+def merge_bn_sums(local_sums: torch.Tensor, local_count: float, group=None, global_count: float | None = None):
+    """SyncBN statistics exchange: all-reduce (sum x, sum x^2[, count]) over the data-parallel group.
     Device-agnostic (used by the world_size-2 gloo tests).  Replaces the per-layer collectives of
     torch.nn.SyncBatchNorm that ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm installs
-    (/root/reference/models/model.py:25)."""
+    (/root/reference/models/model.py:25).  When the caller already knows the global row count (it is the
+    same for every BN layer of a level, see `global_rows`) only the sums travel and no host sync is needed."""
     if group is None:
         return local_sums, float(local_count)
+    if global_count is not None:
+        dist.all_reduce(local_sums, op=dist.ReduceOp.SUM, group=group)
+        return local_sums, float(global_count)
     packed = torch.cat([local_sums, local_sums.new_tensor([float(local_count)])])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return packed[:-1], float(packed[-1].item())
+
+
+_global_rows_cache = {}
+
+
+def global_rows(n_local: int, key, group):
+    """Number of rows over all ranks for a tensor family identified by `key` (e.g. (manager id, level)):
+    one small all-reduce + host read per key instead of one per BatchNorm layer."""
+    if group is None:
+        return float(n_local)
+    if key not in _global_rows_cache:
+        if len(_global_rows_cache) > 64:
+            _global_rows_cache.clear()
+        t = torch.tensor([float(n_local)], dtype=torch.float64,
+                         device='cuda' if torch.cuda.is_available() and dist.get_backend(group) == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _global_rows_cache[key] = float(t.item())
+    return _global_rows_cache[key]
 
 
 class _BatchNorm(torch.autograd.Function):
@@ -146,7 +168,8 @@ class _BatchNorm(torch.autograd.Function):
     (/root/reference/models/resnet.py:63,66,73-82); residual add + ReLU fused as the epilogue."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync,
+                count_key=None):
         x = _f32c(x)
         n, c = x.shape
         dev = x.device
@@ -160,7 +183,8 @@ class _BatchNorm(torch.autograd.Function):
             _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), stats.data_ptr())
             group = _sync_group() if sync else None
             if group is not None:
-                stats, count = merge_bn_sums(stats, count, group)
+                gcount = global_rows(n, count_key, group) if count_key is not None else None
+                stats, count = merge_bn_sums(stats, count, group, gcount)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             invstd = torch.empty(c, dtype=torch.float32, device=dev)
             _call('b2m_bn_finalize', stats.data_ptr(), count, c, _ptr(gamma), _ptr(beta), eps, momentum,
@@ -195,7 +219,7 @@ class _BatchNorm(torch.autograd.Function):
             # eval-mode BN is an affine map: dx = scale * g (mean holds `scale` here)
             g = dy if not relu else dy * (y > 0)
             dx = g * mean.reshape(1, -1)
-            return dx, None, None, None, None, None, None, None, (g if dres is not None else None), None, None
+            return dx, None, None, None, None, None, None, None, (g if dres is not None else None), None, None, None
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
@@ -212,12 +236,13 @@ class _BatchNorm(torch.autograd.Function):
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), gsums.data_ptr(),
               count, relu, dx.data_ptr(), dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, dres, None, None)
+                None, None, None, None, None, dres, None, None, None)
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None,
-               relu=False, sync=False):
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync)
+               relu=False, sync=False, count_key=None):
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync,
+                            count_key)
 
 
 class _ReLU(torch.autograd.Function):

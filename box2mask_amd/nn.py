@@ -117,7 +117,7 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
         self.sync = False
 
-    def apply_bn(self, feats, residual=None, relu=False):
+    def apply_bn(self, feats, residual=None, relu=False, count_key=None):
         bn = self.bn
         training = self.training or not bn.track_running_stats
         if training and feats.shape[0] == 1:   # torch.nn.functional.batch_norm raises the same (BatchNorm1d)
@@ -126,10 +126,17 @@ class MinkowskiBatchNorm(nn.Module):
         if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         return F_.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                             bn.momentum, bn.eps, residual, relu, self.sync)
+                             bn.momentum, bn.eps, residual, relu, self.sync, count_key)
 
     def forward(self, x: SparseTensor) -> SparseTensor:
-        return x.new(self.apply_bn(x.F))
+        return x.new(self.apply_bn(x.F, count_key=count_key_of(x)))
+
+
+def count_key_of(x):
+    """Key under which the global (all ranks) row count of x's rows is cached for SyncBN."""
+    if getattr(x, 'manager', None) is not None:
+        return ('level', x.manager.serial, x.level)
+    return ('pooled', x.serial)
 
 
 class MinkowskiSyncBatchNorm:
@@ -152,12 +159,14 @@ class MinkowskiReLU(nn.Module):
 class PooledTensor:
     """Dense per-segment features after segment pooling (row r <-> pooling id r)."""
 
-    def __init__(self, F):
+    def __init__(self, F, serial=None):
+        from .sparse import _serial
         self.F = F
         self.manager, self.level = None, None
+        self.serial = next(_serial) if serial is None else serial     # row family (same rows -> same SyncBN count)
 
     def new(self, F, level=None):
-        return PooledTensor(F)
+        return PooledTensor(F, self.serial)
 
 
 def segment_pool(x: SparseTensor, pooling_ids, mode='avg') -> PooledTensor:

@@ -29,14 +29,15 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out = self.conv1(x)
-        out = out.new(self.norm1.apply_bn(out.F, relu=True))
+        ck = ME.count_key_of(out)
+        out = out.new(self.norm1.apply_bn(out.F, relu=True, count_key=ck))
         out = self.conv2(out)
         if self.downsample is not None:
             res = self.downsample[0](x)
-            residual = self.downsample[1].apply_bn(res.F)
+            residual = self.downsample[1].apply_bn(res.F, count_key=ck)
         else:
             residual = x.F
-        return out.new(self.norm2.apply_bn(out.F, residual=residual, relu=True))
+        return out.new(self.norm2.apply_bn(out.F, residual=residual, relu=True, count_key=ck))
 
 
 class ResNetBase(nn.Module):

@@ -9,12 +9,14 @@ Host-side mirror of what the reference gets from MinkowskiEngine's coordinate ma
 from __future__ import annotations
 
 import ctypes
+import itertools
 
 import torch
 
 from . import _lib
 
 TILE = 64       # B2M_TILE of include/b2m.h
+_serial = itertools.count(1)     # unique ids for coordinate managers (cache keys must not be recycled like id())
 
 
 def _pow2_at_least(n: int) -> int:
@@ -63,6 +65,7 @@ class CoordinateManager:
         dev = torch.device('cuda', torch.cuda.current_device())
         c0 = coords.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous()
         self.device = dev
+        self.serial = next(_serial)
         self.keep_tables = keep_tables
         self.coords = [c0]                 # level -> (n,4) int32
         self.tables = []                   # level -> (keys, vals, cap)

@@ -172,6 +172,41 @@ def gen_detection2mask():
             out['d2m_%s_vox2point%d' % (case, si)] = np.asarray(batch['vox2point'][si])
         out['d2m_%s_names' % case] = np.asarray([s['name'] for s in batch['scene']])
         out['d2m_%s_ths' % case] = np.asarray(ths)
+    # ---- S3DIS flow (detection_net.py:398-415,449-451): per-voxel semantics head, majority vote per segment,
+    # no mask NMS; batch of ONE scene (the reference indexes the whole batch's voxels there)
+    s3_valid = torch.Tensor(np.arange(13))
+    cfg3 = SimpleNamespace(mlp_per_vox_semantics='mlp_per_vox_semantics', mlp_semantics='mlp_semantics',
+                           network_heads=['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_per_vox_semantics'],
+                           do_segment_pooling=True)
+    ns3 = SimpleNamespace(requires_voxel_outputs=True, semantic_valid_class_ids=s3_valid, is_foreground=lambda s: s > 2)
+    batch, pred = _scene_inputs(31, n_scenes=1, target_voxels=15000)
+    rng = np.random.default_rng(31)
+    n_vox = batch['vox_coords'].shape[0]
+    seg2vox = np.asarray(batch['seg2vox'][0])
+    # per-voxel logits: the segment's class (scannet id mapped into 0..12) + noise, so that votes are not unanimous
+    seg_cls = (batch['gt_semantics'].numpy() % 13)
+    vox_logits = rng.normal(0, 1, (n_vox, 13)).astype(np.float32)
+    vox_logits[np.arange(n_vox), seg_cls[seg2vox]] += 2.0
+    pred3 = {k: v for k, v in pred.items() if k != 'mlp_semantics'}
+    pred3['mlp_per_vox_semantics'] = torch.from_numpy(vox_logits)
+    ths3 = [0.5, 0.03, 0.3, 0.6]
+    for mode in ('eval', 'train'):
+        res = dn.SelectionNet.detection2mask(ns3, batch, {k: v.clone() for k, v in pred3.items()}, cfg3, mode, True, *ths3)
+        r = res[batch['scene'][0]['name']]
+        pre = 'd2m_s3_%s_s0_' % mode
+        out[pre + 'conf'] = r['conf'].numpy()
+        out[pre + 'label_id'] = np.asarray(r['label_id'])
+        out[pre + 'mask'] = np.packbits(r['mask'].numpy(), axis=1)
+        out[pre + 'mask_shape'] = np.asarray(r['mask'].shape)
+    for k, v in pred3.items():
+        out['d2m_s3_pred_%s' % k] = v.numpy()
+    out['d2m_s3_input_location'] = batch['input_location'].numpy()
+    out['d2m_s3_batch_ids'] = batch['batch_ids'].numpy()
+    out['d2m_s3_seg2vox0'] = seg2vox
+    out['d2m_s3_vox2point0'] = np.asarray(batch['vox2point'][0])
+    out['d2m_s3_vox_segments0'] = np.asarray(batch['vox_segments'][0])
+    out['d2m_s3_names'] = np.asarray([batch['scene'][0]['name']])
+    out['d2m_s3_ths'] = np.asarray(ths3)
     np.savez_compressed(os.path.join(OUT, 'detection2mask.npz'), **out)
     print('detection2mask.npz: %d arrays' % len(out))
 
