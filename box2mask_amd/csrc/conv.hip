@@ -32,16 +32,23 @@ __device__ float g_zeros[64];
 static_assert(B2M_TILE == 64, "conv kernels assume 64-row tiles (4 row groups of 16)");
 #define NG 4     // row groups per tile
 
-__device__ __forceinline__ int cs_index(int row, int col) { return row * 32 + (col ^ ((row & 1) << 4)); }
+// LDS strip addressing.  A flush instruction touches 4 rows x 16 columns: with a row stride of 32 floats all rows
+// alias to the same banks, so odd rows are XOR-swizzled by 16 columns; a stride of 48 floats alternates by itself.
+template <int TW>
+__device__ __forceinline__ int cs_index(int row, int col) {
+    return TW == 2 ? row * 32 + (col ^ ((row & 1) << 4)) : row * (16 * TW) + col;
+}
 
 // Packed weight image (b2m_weight_pack): blocks of 64 lanes x 2*KS floats, ordered [k][strip][chunk]; lane
-// (q,i) of a block holds B[chunk*KC + KS*q + s][strip*32 + 16*t + i] at float 2*s + t.  One or two 16-byte
-// loads per lane per chunk, contiguous over the wave, zero padded: no predicates, no address arithmetic.
-template <int KC, bool IDENT, bool ASCALAR, bool PREF>
-__global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
+// (q,i) of a block holds B[chunk*KC + KS*q + s][strip*SW + 16*t + i] at float TW*s + t (SW = 16*TW columns per
+// strip, TW = 3 when cout is a multiple of 48, else 2).  One to three 16-byte loads per lane per chunk, contiguous
+// over the wave, zero padded: no predicates, no address arithmetic.
+template <int KC, bool IDENT, bool ASCALAR, int NPF, int TW>
+__global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_kernel(ConvArgs a) {
     constexpr int KS = KC / 4;                // k-steps per chunk == floats per lane per gathered row
-    constexpr int LW = 64 * 2 * KS;           // floats per packed weight block
-    __shared__ float smem[4 * B2M_TILE * 32];
+    constexpr int SW = 16 * TW;               // output channels per strip
+    constexpr int LW = 64 * TW * KS;          // floats per packed weight block
+    __shared__ float smem[4 * B2M_TILE * SW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t witem = (int64_t)blockIdx.x * 4 + wave;
@@ -50,17 +57,17 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
     const int64_t tile = item / a.nstrips;
     const int strip = (int)(item % a.nstrips);
     if (tile >= a.ntiles) return;             // whole wave leaves; no barriers below
-    const int col0 = strip * 32;
+    const int col0 = strip * SW;
     const int cin = a.c1 + a.c2;
     const int nchunk = (cin + KC - 1) / KC;
     const int nch1 = (a.c1 + KC - 1) / KC;    // chunks served by the first source (c1 % KC == 0 when c2 > 0)
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int64_t row0 = tile * B2M_TILE;
-    float* Cs = smem + wave * (B2M_TILE * 32);
+    float* Cs = smem + wave * (B2M_TILE * SW);
 
     // ---- init the strip: 0 | Y (accumulate) | + bias
-    for (int e = lane; e < B2M_TILE * 8; e += 64) {
-        const int row = e >> 3, c4 = (e & 7) * 4;
+    for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+        const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int64_t grow = row0 + row;
 #pragma unroll
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
                 v[u] = t;
             }
         }
-        *(f32x4*)&Cs[cs_index(row, c4)] = v;
+        *(f32x4*)&Cs[cs_index<TW>(row, c4)] = v;
     }
 
     // ---- active offsets of this tile (K <= 128): lane k holds the pair count of offset k / k+64
@@ -84,103 +91,105 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
         if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
         if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
     }
-    uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
 
-    int ord = 0;
-    // next active offset of this wave (split-K: active offsets are dealt round-robin to the slices)
-    auto advance = [&]() -> int {
-        for (;;) {
-            int k;
-            if (m0) { k = __builtin_ctzll(m0); m0 &= m0 - 1; }
-            else if (m1) { k = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
-            else return -1;
-            if ((ord++) % a.nslice == slice) return k;
-        }
-    };
-    // pair lists of one offset: lane (i,q) gathers input row idx[g] and later flushes the 4 output rows packed
-    // in out[g].  Rows of padded pairs (idx < 0) are clamped to row 0: an MFMA output row depends only on its own
-    // A row, and the flush skips padded pairs, so whatever they compute is never used.
-    auto load_lists = [&](int k, int (&idx)[NG], uint32_t (&out)[NG]) {
-        const int64_t base = (int64_t)k * ldr + row0;
+    // Walk the kernel offsets with purely scalar control flow: the pair count of offset k is read from lane k
+    // (k is wave-uniform), empty offsets are skipped, and with split-K the active offsets are dealt round-robin
+    // to the slices by a running phase counter.
+    int phase = 0;
+    for (int k = 0; k < a.K; ++k) {
+        const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
+        if (n == 0) continue;
+        const bool mine = phase == slice;
+        phase = phase + 1 == a.nslice ? 0 : phase + 1;
+        if (!mine) continue;
+        const int G = (n + 15) >> 4;           // 1..4 dense row groups
+        // pair lists: lane (i,q) gathers input row idx[g] and later flushes the 4 output rows packed in out[g].
+        // Rows of padded pairs (idx < 0) are clamped to row 0: an MFMA output row depends only on its own A row,
+        // and the flush below skips padded pairs, so whatever they compute is never used.
+        int idx[NG]; uint32_t out[NG];
+        {
+            const int64_t base = (int64_t)k * ldr + row0;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (IDENT) {
-                int64_t r = row0 + 16 * g + i;
-                idx[g] = r < a.n_out ? (int)r : 0;
-                const int p = 16 * g + 4 * q;
-                out[g] = (uint32_t)p | ((uint32_t)(p + 1) << 8) | ((uint32_t)(p + 2) << 16) | ((uint32_t)(p + 3) << 24);
-            } else {                           // slots beyond the pair count hold -1 / 0 by construction
-                const int r = a.rb_in[base + 16 * g + i];
-                idx[g] = r < 0 ? 0 : r;
-                out[g] = *(const uint32_t*)(a.rb_out + base + 16 * g + 4 * q);
+            for (int g = 0; g < NG; ++g) {
+                if (IDENT) {
+                    int64_t r = row0 + 16 * g + i;
+                    idx[g] = r < a.n_out ? (int)r : 0;
+                    const int p = 16 * g + 4 * q;
+                    out[g] = (uint32_t)p | ((uint32_t)(p + 1) << 8) | ((uint32_t)(p + 2) << 16) | ((uint32_t)(p + 3) << 24);
+                } else {                       // slots beyond the pair count hold -1 / 0 by construction
+                    const int r = a.rb_in[base + 16 * g + i];
+                    idx[g] = r < 0 ? 0 : r;
+                    out[g] = *(const uint32_t*)(a.rb_out + base + 16 * g + 4 * q);
+                }
             }
         }
-    };
-    int k = advance();
-    int idxN[NG]; uint32_t outN[NG];
+        f32x4 acc[NG][TW];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) { idxN[g] = 0; outN[g] = 0; }
-    if (PREF && k >= 0) load_lists(k, idxN, outN);
-    while (k >= 0) {
-        const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
-        const int G = (n + 15) >> 4;           // 1..4 dense row groups
-        int idx[NG]; uint32_t out[NG];
-        int k2;
-        if constexpr (PREF) {
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int g = 0; g < NG; ++g) { idx[g] = idxN[g]; out[g] = outN[g]; }
-            // the lists of the NEXT offset are requested now and land while this offset computes
-            k2 = advance();
-            if (k2 >= 0) load_lists(k2, idxN, outN);
-        } else {
-            load_lists(k, idx, out);
-            k2 = advance();
-        }
-        f32x4 acc[NG][2];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int t = 0; t < TW; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        const float* wlane = a.wp + ((int64_t)k * a.nstrips + strip) * nchunk * LW + lane * (2 * KS);
+        const float* wlane = a.wp + ((int64_t)k * a.nstrips + strip) * nchunk * LW + lane * (TW * KS);
 
-        // one source tensor: chunks [c_lo, c_hi) of the concatenated input channels
+        // one source tensor: chunks [c_lo, c_hi) of the concatenated input channels.  NPF chunks of loads are
+        // issued back to back before the first MFMA block (memory-level parallelism per wave); the loads are
+        // unconditional -- a chunk index past the end is clamped and only its MFMAs are skipped -- so that the
+        // number of loads in flight is static and the compiler emits counted waits.
         auto run_source = [&](const float* src, int64_t ld, int csrc, int c_lo, int c_hi) {
             const float* pa[NG];
 #pragma unroll
             for (int g = 0; g < NG; ++g) pa[g] = src + (int64_t)idx[g] * ld + KS * q;
-            for (int c = c_lo; c < c_hi; ++c) {
-                const int cb = (c - c_lo) * KC;            // channel offset inside this source
-                float bv[KS][2];
-                if constexpr (KS == 4) {
-                    const f32x4 w0 = *(const f32x4*)(wlane + (int64_t)c * LW);
-                    const f32x4 w1 = *(const f32x4*)(wlane + (int64_t)c * LW + 4);
-                    bv[0][0] = w0[0]; bv[0][1] = w0[1]; bv[1][0] = w0[2]; bv[1][1] = w0[3];
-                    bv[2][0] = w1[0]; bv[2][1] = w1[1]; bv[3][0] = w1[2]; bv[3][1] = w1[3];
-                } else {
-                    const f32x4 w0 = *(const f32x4*)(wlane + (int64_t)c * LW);
-                    bv[0][0] = w0[0]; bv[0][1] = w0[1]; bv[1][0] = w0[2]; bv[1][1] = w0[3];
-                }
-                float av[NG][KS];
+            for (int c0 = c_lo; c0 < c_hi; c0 += NPF) {
+                float bv[NPF][KS][TW], av[NPF][NG][KS];
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const float* p = pa[g] + cb;
-                    if constexpr (ASCALAR) {       // odd channel counts (head gradients): per-element, predicated
+                for (int j = 0; j < NPF; ++j) {
+                    const int c = (c0 + j < c_hi) ? c0 + j : c_hi - 1;
+                    const int cb = (c - c_lo) * KC;        // channel offset inside this source
+                    {
+                        // TW*KS contiguous floats per lane, ordered [s][t]
+                        float wv[TW * KS];
 #pragma unroll
-                        for (int s = 0; s < KS; ++s) av[g][s] = *((cb + KS * q + s < csrc) ? p + s : a.zeros);
-                    } else if constexpr (KS == 4) {
-                        const f32x4 v = *(const f32x4*)p;
-                        av[g][0] = v[0]; av[g][1] = v[1]; av[g][2] = v[2]; av[g][3] = v[3];
-                    } else {
-                        const f32x2 v = *(const f32x2*)p;
-                        av[g][0] = v[0]; av[g][1] = v[1];
+                        for (int u = 0; u < TW * KS / 4; ++u) {
+                            const f32x4 w4 = *(const f32x4*)(wlane + (int64_t)c * LW + 4 * u);
+                            wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
+                        }
+                        if constexpr ((TW * KS) % 4 != 0) {         // TW == 3, KS == 2: 6 floats = 4 + 2
+                            const f32x2 w2 = *(const f32x2*)(wlane + (int64_t)c * LW + 4 * (TW * KS / 4));
+                            wv[4 * (TW * KS / 4)] = w2[0]; wv[4 * (TW * KS / 4) + 1] = w2[1];
+                        }
+#pragma unroll
+                        for (int s = 0; s < KS; ++s)
+#pragma unroll
+                            for (int t = 0; t < TW; ++t) bv[j][s][t] = wv[TW * s + t];
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const float* p = pa[g] + cb;
+                        if constexpr (ASCALAR) {   // odd channel counts (head gradients): per-element, predicated
+#pragma unroll
+                            for (int s = 0; s < KS; ++s) av[j][g][s] = *((cb + KS * q + s < csrc) ? p + s : a.zeros);
+                        } else if constexpr (KS == 4) {
+                            const f32x4 v = *(const f32x4*)p;
+                            av[j][g][0] = v[0]; av[j][g][1] = v[1]; av[j][g][2] = v[2]; av[j][g][3] = v[3];
+                        } else {
+                            const f32x2 v = *(const f32x2*)p;
+                            av[j][g][0] = v[0]; av[j][g][1] = v[1];
+                        }
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g < G) {                        // wave-uniform
+                for (int j = 0; j < NPF; ++j) {
+                    if (c0 + j < c_hi) {                    // wave-uniform
 #pragma unroll
-                        for (int s = 0; s < KS; ++s) {
-                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][s], bv[s][0], acc[g][0], 0, 0, 0);
-                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][s], bv[s][1], acc[g][1], 0, 0, 0);
+                        for (int g = 0; g < NG; ++g) {
+                            if (g < G) {                    // wave-uniform
+#pragma unroll
+                                for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                                    for (int t = 0; t < TW; ++t)
+                                        acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][g][s], bv[j][s][t], acc[g][t], 0, 0, 0);
+                                }
+                            }
                         }
                     }
                 }
@@ -200,22 +209,21 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     if (16 * g + 4 * q + r < n) {
                         const int row = (o4 >> (8 * r)) & 255;
-                        Cs[cs_index(row, i)] += acc[g][0][r];
-                        Cs[cs_index(row, 16 + i)] += acc[g][1][r];
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) Cs[cs_index<TW>(row, 16 * t + i)] += acc[g][t][r];
                     }
                 }
             }
         }
-        k = k2;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
     // ---- write the strip
-    for (int e = lane; e < B2M_TILE * 8; e += 64) {
-        const int row = e >> 3, c4 = (e & 7) * 4;
+    for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+        const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
         if (grow >= a.n_out) continue;
-        const f32x4 v = *(const f32x4*)&Cs[cs_index(row, c4)];
+        const f32x4 v = *(const f32x4*)&Cs[cs_index<TW>(row, c4)];
         const int col = col0 + c4;
         float* dst = a.y + grow * a.ldy + col;
         if (a.nslice > 1) {                      // small maps: slices combine with fp32 atomics (Y pre-zeroed)
@@ -232,27 +240,31 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_kernel(ConvArgs a) {
 
 static int env_flag(const char* name, int dflt);
 static inline int conv_kc(int cin) { return cin >= 16 ? 16 : 8; }
+// strip width in 16-column tiles: 48-column strips for the 96-channel spatial layers (A fragments reused 3x:
+// +7 % in the A/B of tools/bench_conv.py), else 32 (1x1 layers measured faster with 32)
+static inline int conv_tw(int cout, int K) { return (cout % 48 == 0 && K > 1 && env_flag("B2M_CONV_TW3", 1)) ? 3 : 2; }
 
 extern "C" int64_t b2m_weight_pack_size(int32_t K, int32_t cin, int32_t cout) {
     const int KC = conv_kc(cin);
-    const int64_t nchunk = (cin + KC - 1) / KC, nstrip = (cout + 31) / 32;
-    return (int64_t)K * nstrip * nchunk * (64 * 2 * (KC / 4));
+    const int TW = conv_tw(cout, K);
+    const int64_t nchunk = (cin + KC - 1) / KC, nstrip = (cout + 16 * TW - 1) / (16 * TW);
+    return (int64_t)K * nstrip * nchunk * (64 * TW * (KC / 4));
 }
 
 // logical B[k][ci][co]:  transpose == 0:  w[k][ci][co]          (CI = rows, CO = cols)
 //                        transpose == 1:  w[src(k)][sb + co][ci] (CI = cols, CO = sc), src(k) = mirror ? K-1-k : k
 __global__ void weight_pack_kernel(const float* __restrict__ w, int64_t ldw, int K, int rows, int cols, int transpose,
-                                   int mirror, int sb, int CI, int CO, int KC, float* __restrict__ wp) {
-    const int KS = KC / 4, LW = 64 * 2 * KS;
-    const int nchunk = (CI + KC - 1) / KC, nstrip = (CO + 31) / 32;
+                                   int mirror, int sb, int CI, int CO, int KC, int TW, float* __restrict__ wp) {
+    const int KS = KC / 4, LW = 64 * TW * KS, SW = 16 * TW;
+    const int nchunk = (CI + KC - 1) / KC, nstrip = (CO + SW - 1) / SW;
     const int64_t total = (int64_t)K * nstrip * nchunk * LW;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(e % (2 * KS)); const int64_t e1 = e / (2 * KS);
+        const int f = (int)(e % (TW * KS)); const int64_t e1 = e / (TW * KS);
         const int lane = (int)(e1 % 64); const int64_t blk = e1 / 64;
         const int chunk = (int)(blk % nchunk); const int64_t b2 = blk / nchunk;
         const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
-        const int s = f >> 1, t = f & 1, q = lane >> 4, i = lane & 15;
-        const int ci = chunk * KC + KS * q + s, co = strip * 32 + 16 * t + i;
+        const int s = f / TW, t = f % TW, q = lane >> 4, i = lane & 15;
+        const int ci = chunk * KC + KS * q + s, co = strip * SW + 16 * t + i;
         float v = 0.f;
         if (ci < CI && co < CO) {
             if (!transpose) v = w[((int64_t)k * rows + ci) * ldw + co];
@@ -275,7 +287,7 @@ extern "C" int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t c
     int64_t grid = (total + 255) / 256;
     if (grid > 65536) grid = 65536;
     weight_pack_kernel<<<(unsigned)grid, 256, 0, st>>>(w, ldw, K, cin, cout, transpose, mirror, slice_begin, CI, CO,
-                                                       conv_kc(CI), wp);
+                                                       conv_kc(CI), conv_tw(CO, K), wp);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -306,7 +318,8 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
     a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
-    a.nstrips = (cout + 31) / 32;
+    const int TW = conv_tw(cout, K);
+    a.nstrips = (cout + 16 * TW - 1) / (16 * TW);
     a.vec_store = (ldy % 4 == 0 && ((uintptr_t)y % 16) == 0) ? 1 : 0;
     // Small maps (deep U-Net levels: a few hundred rows, 256 channels) have too few (tile, strip) items to
     // fill 1024 SIMDs and each item walks K*cin/16 dependent steps: split the offsets over up to 16 waves.
@@ -327,11 +340,16 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     const unsigned grid = (unsigned)cdiv64(items, 4);
     const bool ident = rb_in == nullptr;
     const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (fast ? 0 : 1);
-    const bool pref = env_flag("B2M_CONV_PREF", 0) != 0;
-#define B2M_CONV_CASE(V, KCV, ID, AS)                                                  \
-    case V:                                                                            \
-        if (pref) conv_fwd_kernel<KCV, ID, AS, true><<<grid, 256, 0, st>>>(a);         \
-        else conv_fwd_kernel<KCV, ID, AS, false><<<grid, 256, 0, st>>>(a);             \
+    const int npf = env_flag("B2M_CONV_NPF", 1);      // chunks of loads in flight per wave: 1 or 2 (A/B: no gain)
+#define B2M_CONV_LAUNCH(KCV, ID, AS, NPFV)                                                                 \
+    do {                                                                                                   \
+        if (TW == 3) conv_fwd_kernel<KCV, ID, AS, NPFV, 3><<<grid, 256, 0, st>>>(a);                       \
+        else conv_fwd_kernel<KCV, ID, AS, NPFV, 2><<<grid, 256, 0, st>>>(a);                               \
+    } while (0)
+#define B2M_CONV_CASE(V, KCV, ID, AS)                                                          \
+    case V:                                                                                    \
+        if (npf >= 2) B2M_CONV_LAUNCH(KCV, ID, AS, 2);                                         \
+        else B2M_CONV_LAUNCH(KCV, ID, AS, 1);                                                  \
         break;
     switch (variant) {
         B2M_CONV_CASE(0, 8, false, false) B2M_CONV_CASE(1, 8, false, true) B2M_CONV_CASE(2, 8, true, false)
@@ -339,6 +357,7 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
         B2M_CONV_CASE(6, 16, true, false) B2M_CONV_CASE(7, 16, true, true)
     }
 #undef B2M_CONV_CASE
+#undef B2M_CONV_LAUNCH
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -88,9 +88,10 @@ int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out,
  *   transpose == 1 : B[k][ci][co] = w[src(k)][slice_begin + co][ci], src(k) = mirror ? K-1-k : k
  *                    (ci < cout, co < slice_count)            weights of the data gradient w.r.t. the
  *                    input channels [slice_begin, slice_begin + slice_count) (mirror: stride-1 odd kernels)
- * w is [K][cin][ldw].  Layout: blocks of 64 lanes x 2*KS floats ordered [k][strip of 32 co][chunk of KC ci],
- * KC = 16 if the operand has >= 16 input channels else 8, KS = KC/4; lane (q = lane/16, i = lane%16) holds
- * B[chunk*KC + KS*q + s][strip*32 + 16*t + i] at float 2*s + t; zero padded.  Size: b2m_weight_pack_size. */
+ * w is [K][cin][ldw].  Layout: blocks of 64 lanes x TW*KS floats ordered [k][strip of 16*TW co][chunk of KC ci],
+ * KC = 16 if the operand has >= 16 input channels else 8, KS = KC/4, TW = 3 if the operand's output channel count
+ * is a multiple of 48 and K > 1, else 2; lane (q = lane/16, i = lane%16) holds B[chunk*KC + KS*q + s][strip*16*TW + 16*t + i]
+ * at float TW*s + t; zero padded.  Size: b2m_weight_pack_size (the image is opaque to callers). */
 int64_t b2m_weight_pack_size(int32_t K, int32_t cin, int32_t cout);
 int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t cout, int32_t transpose,
                     int32_t mirror, int32_t slice_begin, int32_t slice_count, float* wp, void* stream);

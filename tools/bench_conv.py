@@ -20,7 +20,7 @@ def timeit(fn, n=4):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 
-VARIANTS = [('base', {}), ('scalar', {'B2M_WGRAD_VEC': '0'}), ('flat', {'B2M_WGRAD_FLAT': '1'})]
+VARIANTS = [('tw2', {'B2M_CONV_TW3': '0'}), ('tw3', {'B2M_CONV_TW3': '1'})]
 cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
          ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
          ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64)]
@@ -31,7 +31,6 @@ for name, rb, K, c1, c2, co in cases:
     w = torch.randn(K, c1 + c2, co, device='cuda') * 0.05
     P = rb.pairs if rb is not None else n_out
     fl = 2.0 * P * (c1 + c2) * co
-    wp = F_.weight_pack(w)
     dy = torch.randn(n_out, co, device='cuda'); dw = torch.zeros_like(w)
     xs = x1 if c2 == 0 else torch.cat([x1, x2], 1)
     f_fwd = lambda: F_.conv_raw(x1, x2, wp, K, None, rb, n_out, co)
@@ -39,8 +38,9 @@ for name, rb, K, c1, c2, co in cases:
     res = {v: [[], []] for v, _ in VARIANTS}
     for rnd in range(4):
         for v, env in VARIANTS:
-            for k_ in ('B2M_CONV_PREF', 'B2M_WGRAD_FLAT', 'B2M_WGRAD_VEC'): os.environ.pop(k_, None)
+            for k_ in ('B2M_CONV_PREF', 'B2M_WGRAD_FLAT', 'B2M_WGRAD_VEC', 'B2M_CONV_NPF', 'B2M_CONV_TW3'): os.environ.pop(k_, None)
             os.environ.update(env)
+            wp = F_.weight_pack(w)          # the packed layout depends on the strip-width switch
             if rnd == 0: f_fwd(); f_wg(); torch.cuda.synchronize()
             res[v][0].append(timeit(f_fwd)); res[v][1].append(timeit(f_wg))
     line = '%-22s' % name
