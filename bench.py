@@ -129,7 +129,7 @@ def main():
     _lib.set_hook(timer.hook)
 
     def step():
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad()                 # torch default (set_to_none=True), as the reference's train_step
         losses = model.compute_loss(batch, 150)
         losses['optimization_loss'].backward()
         model.sync_gradients()

@@ -577,7 +577,7 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const fl
                      ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && env_flag("B2M_WGRAD_VEC", 0) != 0;
     const bool flat = env_flag("B2M_WGRAD_FLAT", 0) != 0;
     if (vec) { if (flat) launch_wgrad<true, true>(MI, NJ, grid, st, a); else launch_wgrad<true, false>(MI, NJ, grid, st, a); }
-    else launch_wgrad<false, false>(MI, NJ, grid, st, a);
+    else { if (flat) launch_wgrad<false, true>(MI, NJ, grid, st, a); else launch_wgrad<false, false>(MI, NJ, grid, st, a); }
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

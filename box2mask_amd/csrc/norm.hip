@@ -42,13 +42,13 @@ __device__ __forceinline__ void column_reduce(int64_t n, int c, double* __restri
 }
 // one wave per output column: lanes sum strided partials, then a fixed-order shuffle tree (deterministic)
 __global__ __launch_bounds__(64) void reduce_final_kernel(const double* __restrict__ partial, int nblk, int c2,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, float* __restrict__ out_f32) {
     const int j = blockIdx.x;
     double s = 0;
     for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * c2 + j];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-    if (threadIdx.x == 0) out[j] = s;
+    if (threadIdx.x == 0) { out[j] = s; if (out_f32) out_f32[j] = (float)s; }
 }
 static int reduce_blocks(int64_t n) {
     int64_t b = (n + 511) / 512;
@@ -74,7 +74,7 @@ extern "C" int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, d
     const int nblk = reduce_blocks(n);
     const int c4 = c / 4, nslots = 256 / c4;
     bn_stats_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(x, ldx, n, c, partial);
-    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, stats);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, stats, nullptr);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -107,6 +107,56 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
     scale[j] = (float)(g * is);
     shift[j] = (float)(b - m * g * is);
 }
+// final reduction of the partial column sums fused with the finalize math: one wave per channel
+__global__ __launch_bounds__(64) void bn_final_finalize_kernel(const double* __restrict__ partial, int nblk, double count,
+                                                               int c, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float* __restrict__ mean,
+                                                               float* __restrict__ invstd, float* __restrict__ scale,
+                                                               float* __restrict__ shift, double* __restrict__ stats) {
+    const int j = blockIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int b = threadIdx.x; b < nblk; b += 64) {
+        s1 += partial[(size_t)b * 2 * c + j];
+        s2 += partial[(size_t)b * 2 * c + c + j];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { s1 += __shfl_down(s1, d, 64); s2 += __shfl_down(s2, d, 64); }
+    if (threadIdx.x != 0) return;
+    if (stats) { stats[j] = s1; stats[c + j] = s2; }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0) var = 0;
+    if (running_mean) {
+        const double unb = count > 1 ? var * count / (count - 1) : var;
+        running_mean[j] = (float)((1.0 - momentum) * (double)running_mean[j] + momentum * m);
+        running_var[j] = (float)((1.0 - momentum) * (double)running_var[j] + momentum * unb);
+    }
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[j] : 1.0, b = beta ? (double)beta[j] : 0.0;
+    if (mean) mean[j] = (float)m;
+    if (invstd) invstd[j] = (float)is;
+    scale[j] = (float)(g * is);
+    shift[j] = (float)(b - m * g * is);
+}
+extern "C" int b2m_bn_stats_finalize(const float* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats,
+                                     const float* gamma, const float* beta, float eps, float momentum,
+                                     float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                     float* shift, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(x && partial && scale && shift && c > 0 && c % 4 == 0 && c <= 1024 && ldx % 4 == 0 && ldx >= c,
+                  "c and ldx must be multiples of 4, c <= 1024");
+    B2M_CHECK_ARG(((uintptr_t)x % 16) == 0 && n >= 1, "x must be 16-byte aligned, n >= 1");
+    const int nblk = reduce_blocks(n);
+    const int c4 = c / 4, nslots = 256 / c4;
+    bn_stats_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(x, ldx, n, c, partial);
+    bn_final_finalize_kernel<<<c, 64, 0, st>>>(partial, nblk, (double)n, c, gamma, beta, eps, momentum, running_mean,
+                                               running_var, mean, invstd, scale, shift, stats);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 extern "C" int b2m_bn_finalize(const double* stats, double count, int32_t c, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var, float* mean,
                                float* invstd, float* scale, float* shift, void* stream) {
@@ -177,7 +227,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
                                  int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd,
-                                 int32_t relu, double* partial, double* sums, void* stream) {
+                                 int32_t relu, double* partial, double* sums, float* sums_f32, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(dy && x && mean && invstd && partial && sums && (!relu || y), "NULL argument");
     B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && (!relu || ldy % 4 == 0),
@@ -186,7 +236,7 @@ extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, 
     const int c4 = c / 4, nslots = 256 / c4;
     bn_bwd_reduce_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(dy, lddy, y, ldy, x, ldx, n, c,
                                                                                    mean, invstd, relu, partial);
-    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, sums_f32);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

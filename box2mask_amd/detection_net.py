@@ -122,7 +122,7 @@ class SelectionNet(ResNetBase):
     @staticmethod
     def _cbr(conv, bn, x):
         out = conv(x)
-        return out.new(bn.apply_bn(out.F, relu=True, count_key=ME.count_key_of(out)))
+        return out.new(bn.apply_bn(out.F, relu=True, count_key=ME.count_key_of(out), defer_counter=True))
 
     def forward(self, x, pooling_ids=None, n_segments=None):
         """x: SparseTensor at tensor stride 1 -> dict head-name -> tensor holder with `.F`
@@ -169,6 +169,7 @@ class SelectionNet(ResNetBase):
                 outputs[network_head] = self.network_heads[network_head](out)
             if self.cfg.mlp_bounds_relu and network_head == self.cfg.mlp_bounds:
                 outputs[network_head] = self.relu(outputs[network_head])
+        ME.flush_batch_counters()
         return outputs
 
     # ------------------------------------------------------------------ votes -> instance masks

@@ -179,17 +179,21 @@ class _BatchNorm(torch.autograd.Function):
         count = float(n)
         if training:
             partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
-            stats = torch.empty(2 * c, dtype=torch.float64, device=dev)
-            _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), stats.data_ptr())
-            group = _sync_group() if sync else None
-            if group is not None:
-                gcount = global_rows(n, count_key, group) if count_key is not None else None
-                stats, count = merge_bn_sums(stats, count, group, gcount)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             invstd = torch.empty(c, dtype=torch.float32, device=dev)
-            _call('b2m_bn_finalize', stats.data_ptr(), count, c, _ptr(gamma), _ptr(beta), eps, momentum,
-                  _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
-                  shift.data_ptr())
+            group = _sync_group() if sync else None
+            if group is None:
+                _call('b2m_bn_stats_finalize', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), None, _ptr(gamma),
+                      _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
+                      invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+            else:
+                stats = torch.empty(2 * c, dtype=torch.float64, device=dev)
+                _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), stats.data_ptr())
+                gcount = global_rows(n, count_key, group) if count_key is not None else None
+                stats, count = merge_bn_sums(stats, count, group, gcount)
+                _call('b2m_bn_finalize', stats.data_ptr(), count, c, _ptr(gamma), _ptr(beta), eps, momentum,
+                      _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                      shift.data_ptr())
         else:
             _call('b2m_bn_finalize', None, 1.0, c, _ptr(gamma), _ptr(beta), eps, momentum, running_mean.data_ptr(),
                   running_var.data_ptr(), None, None, scale.data_ptr(), shift.data_ptr())
@@ -222,11 +226,12 @@ class _BatchNorm(torch.autograd.Function):
             return dx, None, None, None, None, None, None, None, (g if dres is not None else None), None, None, None
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+        sums32 = torch.empty(2 * c, dtype=torch.float32, device=dev)
         _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, partial.data_ptr(),
-              sums.data_ptr())
-        dbeta = sums[:c].float()
-        dgamma = sums[c:].float()
+              sums.data_ptr(), sums32.data_ptr())
+        dbeta = sums32[:c]
+        dgamma = sums32[c:]
         gsums, count = sums, ctx.count
         group = _sync_group() if ctx.sync else None
         if group is not None:

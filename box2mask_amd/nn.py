@@ -117,19 +117,32 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
         self.sync = False
 
-    def apply_bn(self, feats, residual=None, relu=False, count_key=None):
+    def apply_bn(self, feats, residual=None, relu=False, count_key=None, defer_counter=False):
         bn = self.bn
         training = self.training or not bn.track_running_stats
         if training and feats.shape[0] == 1:   # torch.nn.functional.batch_norm raises the same (BatchNorm1d)
             raise ValueError('Expected more than 1 value per channel when training, got input size %s'
                              % (tuple(feats.shape),))
         if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            if defer_counter:              # one foreach launch per forward pass instead of one add per layer
+                _pending_counters.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
         return F_.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                              bn.momentum, bn.eps, residual, relu, self.sync, count_key)
 
     def forward(self, x: SparseTensor) -> SparseTensor:
         return x.new(self.apply_bn(x.F, count_key=count_key_of(x)))
+
+
+_pending_counters = []
+
+
+def flush_batch_counters():
+    """num_batches_tracked += 1 for every BN layer that ran with defer_counter=True since the last flush."""
+    if _pending_counters:
+        torch._foreach_add_(list(_pending_counters), 1)
+        _pending_counters.clear()
 
 
 def count_key_of(x):

@@ -30,14 +30,14 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         out = self.conv1(x)
         ck = ME.count_key_of(out)
-        out = out.new(self.norm1.apply_bn(out.F, relu=True, count_key=ck))
+        out = out.new(self.norm1.apply_bn(out.F, relu=True, count_key=ck, defer_counter=True))
         out = self.conv2(out)
         if self.downsample is not None:
             res = self.downsample[0](x)
-            residual = self.downsample[1].apply_bn(res.F, count_key=ck)
+            residual = self.downsample[1].apply_bn(res.F, count_key=ck, defer_counter=True)
         else:
             residual = x.F
-        return out.new(self.norm2.apply_bn(out.F, residual=residual, relu=True, count_key=ck))
+        return out.new(self.norm2.apply_bn(out.F, residual=residual, relu=True, count_key=ck, defer_counter=True))
 
 
 class ResNetBase(nn.Module):

@@ -129,6 +129,13 @@ int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const float* dy, in
  * (resnet.py:63,66; detection_net.py:40-135). */
 int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats, void* stream);
 
+/* b2m_bn_stats followed by b2m_bn_finalize for the single-process case (count = n): the final reduction and the
+ * finalize math share one launch.  stats may be NULL. */
+int b2m_bn_stats_finalize(const float* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats,
+                          const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, float* mean, float* invstd,
+                          float* scale, float* shift, void* stream);
+
 /* From (possibly all-reduced) sums: scale/shift for the apply kernel, saved mean/invstd, and the
  * running-statistics update (momentum, unbiased variance), all on device.
  * count = number of rows the sums cover (global count under SyncBN). */
@@ -140,10 +147,11 @@ int b2m_bn_finalize(const double* stats, double count, int32_t c, const float* g
 int b2m_bn_apply(const float* x, int64_t ldx, int64_t n, int32_t c, const float* scale, const float* shift,
                  const float* residual, int64_t ldr, int32_t relu, float* y, int64_t ldy, void* stream);
 
-/* Backward reduction: g = dy * (relu ? y>0 : 1);  sums[0:c] = sum g, sums[c:2c] = sum g*xhat. */
+/* Backward reduction: g = dy * (relu ? y>0 : 1);  sums[0:c] = sum g (= dbeta), sums[c:2c] = sum g*xhat (= dgamma);
+ * sums_f32 (2c floats, may be NULL) receives the same values rounded to fp32. */
 int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
                       int64_t n, int32_t c, const float* mean, const float* invstd, int32_t relu,
-                      double* partial, double* sums, void* stream);
+                      double* partial, double* sums, float* sums_f32, void* stream);
 
 /* dx = gamma*invstd*(g - sum_g/count - xhat*sum_gxhat/count); optionally dres = g. */
 int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
