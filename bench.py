@@ -47,10 +47,10 @@ class LaunchTimer:
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         if name == 'b2m_conv_fwd':
-            # x1, ldx1, c1, x2, ldx2, c2, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
-            meta = dict(cin=args[2] + args[5], cout=args[15], K=args[7], n_out=args[12], rb_cnt=args[11])
-        else:   # b2m_conv_wgrad: x, ldx, cin, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
-            meta = dict(cin=args[2], cout=args[5], K=args[10], n_out=args[9], rb_cnt=args[8])
+            # x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
+            meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12])
+        else:   # b2m_conv_wgrad: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
+            meta = dict(cin=args[2], cout=args[6], K=args[11], n_out=args[10], rb_cnt=args[9])
 
         def done():
             e.record()

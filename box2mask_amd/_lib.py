@@ -28,9 +28,9 @@ PROTOTYPES = {
     'b2m_kernel_map': [P, I64, I32, I32, P, P, I64, P, I64, P],
     'b2m_stride_tables': [P, P, I64, I64, P, I64, P, I64, P],
     'b2m_rulebook': [P, I64, I32, I64, P, P, P, P, P],
-    'b2m_conv_fwd': [P, I64, I32, P, I64, I32, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],
+    'b2m_conv_fwd': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],
     'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
-    'b2m_conv_wgrad': [P, I64, I32, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P],
+    'b2m_conv_wgrad': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P],
     'b2m_bn_stats': [P, I64, I64, I32, P, P, P],
     'b2m_bn_finalize': [P, F64, I32, P, P, F32, F32, P, P, P, P, P, P, P],
     'b2m_bn_apply': [P, I64, I64, I32, P, P, P, I64, I32, P, I64, P],

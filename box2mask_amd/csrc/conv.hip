@@ -23,6 +23,8 @@ struct ConvArgs {
     int64_t n_out, ntiles;
     float* y; int64_t ldy; int cout; int accumulate; int nstrips; int vec_store;
     int nslice;      // >1: the tile's active offsets are dealt to nslice waves which add their strips atomically
+    int fast32;      // rows < 2^24, pitches < 2^22 floats, tensors < 4 GiB: 24-bit multiply + 32-bit byte offsets
+    int diag;        // diagnostics (B2M_DIAG): 1 = no A loads, 2 = no B loads, 3 = neither, 4 = no LDS flush
     const float* zeros;   // address of g_zeros passed as data (a select of addresses, not a branch around the load)
 };
 
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 #pragma unroll
             for (int t = 0; t < TW; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        const float* wlane = a.wp + ((int64_t)k * a.nstrips + strip) * nchunk * LW + lane * (TW * KS);
+        // packed weights of (k, strip): wave-uniform base (scalar registers) + a 32-bit lane offset
+        const char* wbase = (const char*)(a.wp + ((int64_t)k * a.nstrips + strip) * nchunk * LW);
+        const uint32_t wlo = (uint32_t)lane * (TW * KS * 4);
 
         // one source tensor: chunks [c_lo, c_hi) of the concatenated input channels.  NPF chunks of loads are
         // issued back to back before the first MFMA block (memory-level parallelism per wave); the loads are
@@ -137,8 +141,12 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
         // number of loads in flight is static and the compiler emits counted waits.
         auto run_source = [&](const float* src, int64_t ld, int csrc, int c_lo, int c_hi) {
             const float* pa[NG];
+            uint32_t bo[NG];               // fast32: byte offset of lane's first channel in its gathered row
 #pragma unroll
-            for (int g = 0; g < NG; ++g) pa[g] = src + (int64_t)idx[g] * ld + KS * q;
+            for (int g = 0; g < NG; ++g) {
+                pa[g] = src + (int64_t)idx[g] * ld + KS * q;
+                bo[g] = __umul24((uint32_t)idx[g], (uint32_t)ld * 4u) + (uint32_t)(KS * q * 4);
+            }
             for (int c0 = c_lo; c0 < c_hi; c0 += NPF) {
                 float bv[NPF][KS][TW], av[NPF][NG][KS];
 #pragma unroll
@@ -150,11 +158,13 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
                         float wv[TW * KS];
 #pragma unroll
                         for (int u = 0; u < TW * KS / 4; ++u) {
-                            const f32x4 w4 = *(const f32x4*)(wlane + (int64_t)c * LW + 4 * u);
+                            f32x4 w4;
+                            if (a.diag & 2) { w4 = f32x4{(float)c, 1.f, (float)lane, 2.f}; }
+                            else w4 = *(const f32x4*)(wbase + (size_t)c * (LW * 4) + (wlo + 16 * u));
                             wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
                         }
                         if constexpr ((TW * KS) % 4 != 0) {         // TW == 3, KS == 2: 6 floats = 4 + 2
-                            const f32x2 w2 = *(const f32x2*)(wlane + (int64_t)c * LW + 4 * (TW * KS / 4));
+                            const f32x2 w2 = *(const f32x2*)(wbase + (size_t)c * (LW * 4) + (wlo + 16 * (TW * KS / 4)));
                             wv[4 * (TW * KS / 4)] = w2[0]; wv[4 * (TW * KS / 4) + 1] = w2[1];
                         }
 #pragma unroll
@@ -164,12 +174,16 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
                     }
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        const float* p = pa[g] + cb;
+                        // fast32: wave-uniform base (source + chunk, scalar) + 32-bit per-lane offset -> no vector
+                        // address arithmetic per chunk
+                        const float* p = (!ASCALAR && a.fast32) ? (const float*)((const char*)(src + cb) + bo[g]) : pa[g] + cb;
                         if constexpr (ASCALAR) {   // odd channel counts (head gradients): per-element, predicated
 #pragma unroll
                             for (int s = 0; s < KS; ++s) av[j][g][s] = *((cb + KS * q + s < csrc) ? p + s : a.zeros);
                         } else if constexpr (KS == 4) {
-                            const f32x4 v = *(const f32x4*)p;
+                            f32x4 v;
+                            if (a.diag & 1) { v = f32x4{(float)bo[g], 1.f, (float)c0, 3.f}; }
+                            else v = *(const f32x4*)p;
                             av[j][g][0] = v[0]; av[j][g][1] = v[1]; av[j][g][2] = v[2]; av[j][g][3] = v[3];
                         } else {
                             const f32x2 v = *(const f32x2*)p;
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
                 const uint32_t o4 = out[g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (16 * g + 4 * q + r < n) {
+                    if (16 * g + 4 * q + r < n && !(a.diag & 4)) {
                         const int row = (o4 >> (8 * r)) & 255;
 #pragma unroll
                         for (int t = 0; t < TW; ++t) Cs[cs_index<TW>(row, 16 * t + i)] += acc[g][t][r];
@@ -293,7 +307,7 @@ extern "C" int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t c
 }
 
 extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
-                            const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
+                            int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
                             const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
                             int32_t cout, int32_t accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -302,6 +316,7 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
                   "rulebook pointers must be all set or all NULL");
     B2M_CHECK_ARG(rb_in != nullptr || K == 1, "identity rulebook needs K == 1");
     B2M_CHECK_ARG(c2 == 0 || x2 != nullptr, "x2 is NULL");
+    B2M_CHECK_ARG(n_in >= 1, "n_in (rows of x1/x2) must be >= 1");
     B2M_CHECK_ARG(ldy >= cout && ldx1 >= c1 && (c2 == 0 || ldx2 >= c2), "leading dimension too small");
     B2M_CHECK_ARG(((uintptr_t)wp % 16) == 0, "packed weights must be 16-byte aligned");
     const int cin = c1 + c2;
@@ -331,6 +346,9 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
         if (nslice > K) nslice = K;
     }
     a.nslice = nslice;
+    a.diag = env_flag("B2M_DIAG", 0);
+    a.fast32 = (n_in < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_in * ldx1 * 4 < (1ll << 32) &&
+                n_in * ldx2 * 4 < (1ll << 32) && env_flag("B2M_CONV_FAST32", 1)) ? 1 : 0;
     static const float* zeros_addr = nullptr;
     if (!zeros_addr) B2M_HIP(hipGetSymbolAddress((void**)&zeros_addr, HIP_SYMBOL(g_zeros)));
     a.zeros = zeros_addr;
@@ -374,6 +392,7 @@ struct WgradArgs {
     float* dw; int64_t lddw, dw_kstride;
     int tiles_per_chunk, nmb, nnb;
     const float* zeros;      // address of g_zeros passed as data: a select of ADDRESSES, not a branch around the load
+    int fast32;              // complete blocks and 24/32-bit addressable tensors: cheap address arithmetic
 };
 
 template <int N> struct vecf;
@@ -431,6 +450,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             o4 = *(const uint32_t*)(a.rb_out + base);
         }
     };
+    const uint32_t ldx4 = (uint32_t)a.ldx * 4u, lddy4 = (uint32_t)a.lddy * 4u;
+    const uint32_t cxb = (uint32_t)(ci0 + i) * 4u, cyb = (uint32_t)(co0 + i) * 4u;
     auto process = [&](int64_t slot, const int (&rin)[4], uint32_t o4) {
         if (__ballot(rin[0] >= 0) == 0) return;        // wave-uniform: empty slot
         const int64_t row0 = (slot >> 2) * B2M_TILE;
@@ -449,6 +470,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 for (int m = 0; m < MI; ++m) av[s][m] = vget<MI>(va, m);
 #pragma unroll
                 for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = vget<NJ>(vb, nn);
+            } else if (a.fast32) {
+                // complete blocks, tensors below 2^31 bytes: ONE full-rate 24-bit multiply-add per gathered row gives
+                // the byte offset, the sub-tile offsets (64 B apart) become immediates of the loads
+                const uint32_t bx = __umul24((uint32_t)(r < 0 ? 0 : r), ldx4) + cxb;
+                const uint32_t by = __umul24((uint32_t)ro, lddy4) + cyb;
+                const char* px = (const char*)a.x + bx;
+                const char* py = (const char*)a.dy + by;
+                if (r >= 0) {
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) av[s][m] = *(const float*)(px + 64 * m);
+#pragma unroll
+                    for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = *(const float*)(py + 64 * nn);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) av[s][m] = 0.f;
+#pragma unroll
+                    for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = 0.f;
+                }
             } else {
 #pragma unroll
                 for (int m = 0; m < MI; ++m) {
@@ -541,11 +580,11 @@ static int pick_blk(int c) {      // 16-column sub-tiles per wave block
     return 4;
 }
 
-extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const float* dy, int64_t lddy, int32_t cout,
-                              const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out,
-                              int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, void* stream) {
+extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
+                              int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                              int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(x && dy && dw && cin > 0 && cout > 0 && K >= 1 && K <= 65535, "bad pointers/sizes");
+    B2M_CHECK_ARG(x && dy && dw && cin > 0 && cout > 0 && K >= 1 && K <= 65535 && n_in >= 0, "bad pointers/sizes");
     B2M_CHECK_ARG((rb_in == nullptr) == (rb_out == nullptr) && (rb_in == nullptr) == (rb_cnt == nullptr),
                   "rulebook pointers must be all set or all NULL");
     B2M_CHECK_ARG(rb_in != nullptr || K == 1, "identity rulebook needs K == 1");
@@ -575,6 +614,10 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const fl
     // vector path: complete, aligned blocks (every trunk layer: channel counts are multiples of 32)
     const bool vec = cin % (16 * MI) == 0 && cout % (16 * NJ) == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
                      ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && env_flag("B2M_WGRAD_VEC", 0) != 0;
+    // 24-bit multiply operands and 32-bit byte offsets: rows < 2^24, row pitch < 2^22 floats, tensors < 4 GiB
+    a.fast32 = (cin % (16 * MI) == 0 && cout % (16 * NJ) == 0 && n_out < (1 << 24) && n_in < (1 << 24) &&
+                ldx < (1 << 22) && lddy < (1 << 22) && n_out * lddy * 4 < (1ll << 32) && n_in * ldx * 4 < (1ll << 32) &&
+                env_flag("B2M_WGRAD_FAST32", 1)) ? 1 : 0;
     const bool flat = env_flag("B2M_WGRAD_FLAT", 0) != 0;
     if (vec) { if (flat) launch_wgrad<true, true>(MI, NJ, grid, st, a); else launch_wgrad<true, false>(MI, NJ, grid, st, a); }
     else { if (flat) launch_wgrad<false, true>(MI, NJ, grid, st, a); else launch_wgrad<false, false>(MI, NJ, grid, st, a); }

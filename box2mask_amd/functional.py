@@ -49,7 +49,7 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
         assert rb.K == K and rb.n_out == n_out
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
     _call('b2m_conv_fwd', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
-          wp.data_ptr(), K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
+          x1.shape[0], wp.data_ptr(), K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
           1 if accumulate else 0)
     return out
 
@@ -63,7 +63,7 @@ def wgrad_raw(x, dy, rb: Rulebook | None, K: int, dw3, ci0: int, cin: int | None
         rbi = rbo = rbc = None
     else:
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
-    _call('b2m_conv_wgrad', x.data_ptr(), x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, rbi, rbo, rbc,
+    _call('b2m_conv_wgrad', x.data_ptr(), x.stride(0), cin, x.shape[0], dy.data_ptr(), dy.stride(0), cout, rbi, rbo, rbc,
           n_out, K, dw3.data_ptr() + 4 * ci0 * cout, cout, cin_total * cout)
 
 

@@ -101,7 +101,7 @@ int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t
  * detection_net.py:37-135) and, with an identity rulebook (rb_in == NULL, K == 1), the 1x1
  * `mm` fast path (resnet.py:151-158, detection_net.py:172-193).  Two sources implement
  * ME.cat (detection_net.py:286-336) without materialising the concatenation: input channel
- * c < c1 comes from x1, the rest from x2 (c2 may be 0, x2 NULL; c1 % 16 == 0 when c2 > 0).
+ * c < c1 comes from x1, the rest from x2 (c2 may be 0, x2 NULL; c1 % 16 == 0 when c2 > 0); both have n_in rows.
  *   wp    packed B for (K, c1+c2, cout), see b2m_weight_pack
  *   bias  [cout] or NULL
  *   accumulate != 0: add to the existing Y instead of overwriting
@@ -109,15 +109,15 @@ int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t
  * Maps with fewer than 4096 (tile, 32-channel strip) items split the kernel offsets over several waves
  * that combine with fp32 atomics (sum order then varies in the last bits). */
 int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
-                 const float* wp, int32_t K, const float* bias,
+                 int64_t n_in, const float* wp, int32_t K, const float* bias,
                  const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                  int64_t n_out, float* y, int64_t ldy, int32_t cout, int32_t accumulate, void* stream);
 
 /* dW[k][ci][co] += sum over pairs (i,o) of offset k:  X[i, ci] * dY[o, co]     (fp32 atomics)
- * Replaces [ME] ConvolutionBackward (weight part).  x: rows indexed by rb_in (ldx, cin columns used),
+ * Replaces [ME] ConvolutionBackward (weight part).  x: n_in rows indexed by rb_in (ldx, cin columns used),
  * dy: rows indexed by tile*TILE+rb_out.  dw element (k,ci,co) lives at dw[k*dw_kstride + ci*lddw + co]
  * (so a channel sub-block of a wider weight tensor can be targeted); the caller zeroes it. */
-int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, const float* dy, int64_t lddy, int32_t cout,
+int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy, int32_t cout,
                    const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                    int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, void* stream);
 
