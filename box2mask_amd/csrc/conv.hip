@@ -24,7 +24,6 @@ struct ConvArgs {
     float* y; int64_t ldy; int cout; int accumulate; int nstrips; int vec_store;
     int nslice;      // >1: the tile's active offsets are dealt to nslice waves which add their strips atomically
     int fast32;      // rows < 2^24, pitches < 2^22 floats, tensors < 4 GiB: 24-bit multiply + 32-bit byte offsets
-    int diag;        // diagnostics (B2M_DIAG): 1 = no A loads, 2 = no B loads, 3 = neither, 4 = no LDS flush
     const float* zeros;   // address of g_zeros passed as data (a select of addresses, not a branch around the load)
 };
 
@@ -158,9 +157,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
                         float wv[TW * KS];
 #pragma unroll
                         for (int u = 0; u < TW * KS / 4; ++u) {
-                            f32x4 w4;
-                            if (a.diag & 2) { w4 = f32x4{(float)c, 1.f, (float)lane, 2.f}; }
-                            else w4 = *(const f32x4*)(wbase + (size_t)c * (LW * 4) + (wlo + 16 * u));
+                            const f32x4 w4 = *(const f32x4*)(wbase + (size_t)c * (LW * 4) + (wlo + 16 * u));
                             wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
                         }
                         if constexpr ((TW * KS) % 4 != 0) {         // TW == 3, KS == 2: 6 floats = 4 + 2
@@ -181,9 +178,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 #pragma unroll
                             for (int s = 0; s < KS; ++s) av[j][g][s] = *((cb + KS * q + s < csrc) ? p + s : a.zeros);
                         } else if constexpr (KS == 4) {
-                            f32x4 v;
-                            if (a.diag & 1) { v = f32x4{(float)bo[g], 1.f, (float)c0, 3.f}; }
-                            else v = *(const f32x4*)p;
+                            const f32x4 v = *(const f32x4*)p;
                             av[j][g][0] = v[0]; av[j][g][1] = v[1]; av[j][g][2] = v[2]; av[j][g][3] = v[3];
                         } else {
                             const f32x2 v = *(const f32x2*)p;
@@ -221,7 +216,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
                 const uint32_t o4 = out[g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (16 * g + 4 * q + r < n && !(a.diag & 4)) {
+                    if (16 * g + 4 * q + r < n) {
                         const int row = (o4 >> (8 * r)) & 255;
 #pragma unroll
                         for (int t = 0; t < TW; ++t) Cs[cs_index<TW>(row, 16 * t + i)] += acc[g][t][r];
@@ -346,7 +341,6 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
         if (nslice > K) nslice = K;
     }
     a.nslice = nslice;
-    a.diag = env_flag("B2M_DIAG", 0);
     a.fast32 = (n_in < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_in * ldx1 * 4 < (1ll << 32) &&
                 n_in * ldx2 * 4 < (1ll << 32) && env_flag("B2M_CONV_FAST32", 1)) ? 1 : 0;
     static const float* zeros_addr = nullptr;
