@@ -189,11 +189,14 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 #pragma unroll
                 for (int j = 0; j < NPF; ++j) {
                     if (c0 + j < c_hi) {                    // wave-uniform
+                        // k-step outermost: consecutive MFMAs go to G*TW different accumulators.  The pipe needs
+                        // >= ~8 independent accumulators in flight to run at peak (tools/micro/mfma_peak.hip: 118
+                        // TFLOP/s with 4, 150 with 12); iterating s innermost left only TW = 2..3.
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) {
-                            if (g < G) {                    // wave-uniform
+                        for (int s = 0; s < KS; ++s) {
 #pragma unroll
-                                for (int s = 0; s < KS; ++s) {
+                            for (int g = 0; g < NG; ++g) {
+                                if (g < G) {                // wave-uniform
 #pragma unroll
                                     for (int t = 0; t < TW; ++t)
                                         acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][g][s], bv[j][s][t], acc[g][t], 0, 0, 0);
@@ -609,7 +612,9 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     const bool vec = cin % (16 * MI) == 0 && cout % (16 * NJ) == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
                      ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && env_flag("B2M_WGRAD_VEC", 0) != 0;
     // 24-bit multiply operands and 32-bit byte offsets: rows < 2^24, row pitch < 2^22 floats, tensors < 4 GiB
-    a.fast32 = (cin % (16 * MI) == 0 && cout % (16 * NJ) == 0 && n_out < (1 << 24) && n_in < (1 << 24) &&
+    // (blocks may overhang cin/cout as long as the row PITCH covers them: the extra columns only feed dW rows /
+    // columns that are never written)
+    a.fast32 = (ldx >= (int64_t)a.nmb * 16 * MI && lddy >= (int64_t)a.nnb * 16 * NJ && n_out < (1 << 24) && n_in < (1 << 24) &&
                 ldx < (1 << 22) && lddy < (1 << 22) && n_out * lddy * 4 < (1ll << 32) && n_in * ldx * 4 < (1ll << 32) &&
                 env_flag("B2M_WGRAD_FAST32", 1)) ? 1 : 0;
     const bool flat = env_flag("B2M_WGRAD_FLAT", 0) != 0;

@@ -79,9 +79,11 @@ class _SparseConv(torch.autograd.Function):
         x2 = _f32c(x2) if x2 is not None else None
         c1 = x1.shape[1]
         if x2 is None and c1 % 4 != 0 and c1 < 16:
-            # few, odd input channels (the 6-channel network input): zero-pad to a multiple of 4 so that the
-            # gather uses aligned vector loads; the packed weights are zero there as well
-            x1 = torch.nn.functional.pad(x1, (0, (-c1) % 4))
+            # few, odd input channels (the 6-channel network input): zero-pad the rows to a 16-float pitch.  The
+            # forward reads an 8-channel view of it (aligned vector gathers; the packed weights are zero there as
+            # well), the weight gradient reads whole 16-channel blocks of the padded rows.
+            xp = torch.nn.functional.pad(x1, (0, 16 - c1))
+            x1 = xp[:, :(c1 + 3) // 4 * 4]
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         w3 = _f32c(w3)
         K, cin, cout = w3.shape
