@@ -24,6 +24,7 @@ F64 = C.c_double
 # tests/test_abi.py cross-checks this table against the header.
 PROTOTYPES = {
     'b2m_coords_build': [P, I64, P, P, I64, P, P],
+    'b2m_morton_keys': [P, I64, P, P],
     'b2m_coords_stride': [P, I64, I32, P, P, P, P, P, I64, P, C.POINTER(I64), P],
     'b2m_kernel_map': [P, I64, I32, I32, P, P, I64, P, I64, P],
     'b2m_stride_tables': [P, P, I64, I64, P, I64, P, I64, P],

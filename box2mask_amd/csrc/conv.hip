@@ -355,7 +355,9 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     const unsigned grid = (unsigned)cdiv64(items, 4);
     const bool ident = rb_in == nullptr;
     const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (fast ? 0 : 1);
-    const int npf = env_flag("B2M_CONV_NPF", 1);      // chunks of loads in flight per wave: 1 or 2 (A/B: no gain)
+    // chunks of loads in flight per wave: 2 pays on the 48-column-strip layers with >= 4 chunks (+7 % in the A/B of
+    // tools/bench_conv.py), 1 elsewhere (narrow / 1x1 layers lose occupancy with 2)
+    const int npf = env_flag("B2M_CONV_NPF", (TW == 3 && cin >= 64) ? 2 : 1);
 #define B2M_CONV_LAUNCH(KCV, ID, AS, NPFV)                                                                 \
     do {                                                                                                   \
         if (TW == 3) conv_fwd_kernel<KCV, ID, AS, NPFV, 3><<<grid, 256, 0, st>>>(a);                       \

@@ -288,3 +288,30 @@ extern "C" int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
+
+// ------------------------------------------------------------------ Morton keys (spatial row order)
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {      // 16 bits -> every third bit
+    uint64_t x = v & 0xFFFFull;
+    x = (x | (x << 32)) & 0x00FF00000000FFFFull;
+    x = (x | (x << 16)) & 0x00FF0000FF0000FFull;
+    x = (x | (x << 8)) & 0xF00F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x30C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x9249249249249249ull;
+    return x;
+}
+__global__ void morton_keys_kernel(const int32_t* __restrict__ coords, int64_t n, int64_t* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    i32x4 c = *(const i32x4*)(coords + i * 4);
+    // batch index in the top 15 bits (keys stay non-negative as int64), 3 x 16 interleaved coordinate bits below
+    uint64_t k = ((uint64_t)(uint32_t)c.x << 48) | spread3((uint32_t)c.y) | (spread3((uint32_t)c.z) << 1) |
+                 (spread3((uint32_t)c.w) << 2);
+    keys[i] = (int64_t)k;
+}
+extern "C" int b2m_morton_keys(const int32_t* coords, int64_t n, int64_t* keys, void* stream) {
+    B2M_CHECK_ARG(n >= 0 && (n == 0 || (coords && keys)), "bad arguments");
+    if (n == 0) return B2M_OK;
+    morton_keys_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, (hipStream_t)stream>>>(coords, n, keys);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}

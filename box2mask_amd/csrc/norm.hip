@@ -2,7 +2,7 @@
 // All HBM-bound: float4 accesses, one pass per tensor, deterministic two-stage column reductions.
 #include "b2m_common.h"
 
-#define RED_MAX_BLOCKS 1024
+#define RED_MAX_BLOCKS 4096
 
 // Column reduction skeleton.  256 threads; thread -> (float4 column group cg, row slot rs).
 // F(row, cg) returns two float4 contributions (a, b); the block writes double partial sums
@@ -19,7 +19,14 @@ __device__ __forceinline__ void column_reduce(int64_t n, int c, double* __restri
     if (r1 > n) r1 = n;
     f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
     if (rs < nslots) {
-        for (int64_t r = r0 + rs; r < r1; r += nslots) {
+        int64_t r = r0 + rs;
+        for (; r + nslots < r1; r += 2 * nslots) {      // two independent rows per iteration (memory-level parallelism)
+            f32x4 a0, b0, a1, b1;
+            f(r, cg, a0, b0);
+            f(r + nslots, cg, a1, b1);
+            sa += a0; sb += b0; sa += a1; sb += b1;
+        }
+        for (; r < r1; r += nslots) {
             f32x4 a, b;
             f(r, cg, a, b);
             sa += a; sb += b;
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(64) void reduce_final_kernel(const double* __restri
     if (threadIdx.x == 0) { out[j] = s; if (out_f32) out_f32[j] = (float)s; }
 }
 static int reduce_blocks(int64_t n) {
-    int64_t b = (n + 511) / 512;
+    int64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
     if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
     return (int)b;
@@ -174,11 +181,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ res, int64_t ldr, int relu,
                                                        float* __restrict__ y, int64_t ldy) {
-    const int64_t total = n * c4;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / c4; const int cg = (int)(e - r * c4);
+    // thread -> (row slot, float4 column group); rows are walked with a constant stride: no per-element division
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    if (rs >= nslots) return;
+    const f32x4 s = *(const f32x4*)(scale + cg * 4), b = *(const f32x4*)(shift + cg * 4);
+    for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
         f32x4 v = *(const f32x4*)(x + r * ldx + cg * 4);
-        const f32x4 s = *(const f32x4*)(scale + cg * 4), b = *(const f32x4*)(shift + cg * 4);
         v = v * s + b;
         if (res) v += *(const f32x4*)(res + r * ldr + cg * 4);
         if (relu) {
@@ -187,6 +196,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         }
         *(f32x4*)(y + r * ldy + cg * 4) = v;
     }
+}
+// grid for the row-chunk elementwise kernels: blocks of (256/c4) rows, enough blocks to fill the chip
+static unsigned row_grid(int64_t n, int c4) {
+    const int nslots = 256 / c4;
+    int64_t g = (n + nslots - 1) / nslots;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (unsigned)g;
 }
 static unsigned ew_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
@@ -201,7 +218,8 @@ extern "C" int b2m_bn_apply(const float* x, int64_t ldx, int64_t n, int32_t c, c
                       (!residual || ldr % 4 == 0),
                   "c and leading dimensions must be multiples of 4");
     if (n == 0) return B2M_OK;
-    bn_apply_kernel<<<ew_grid(n * (c / 4)), 256, 0, st>>>(x, ldx, n, c / 4, scale, shift, residual, ldr, relu, y, ldy);
+    B2M_CHECK_ARG(c <= 1024, "c <= 1024");
+    bn_apply_kernel<<<row_grid(n, c / 4), 256, 0, st>>>(x, ldx, n, c / 4, scale, shift, residual, ldr, relu, y, ldy);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -251,10 +269,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, int64_t lddx,
                                                            float* __restrict__ dres, int64_t lddres) {
     const int c4 = c >> 2;
-    const int64_t total = n * c4;
     const float inv_n = (float)(1.0 / count);
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / c4; const int cg = (int)(e - r * c4);
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    if (rs >= nslots) return;
+    const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
+    f32x4 sg, sgx, ga;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        sg[u] = (float)sums[cg * 4 + u] * inv_n; sgx[u] = (float)sums[c + cg * 4 + u] * inv_n;
+        ga[u] = (gamma ? gamma[cg * 4 + u] : 1.f) * is[u];
+    }
+    for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
         f32x4 g = *(const f32x4*)(dy + r * lddy + cg * 4);
         if (relu) {
             const f32x4 yy = *(const f32x4*)(y + r * ldy + cg * 4);
@@ -262,14 +288,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
         }
         const f32x4 xx = *(const f32x4*)(x + r * ldx + cg * 4);
-        const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
         f32x4 out;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float xh = (xx[u] - m[u]) * is[u];
-            const float sg = (float)sums[cg * 4 + u] * inv_n, sgx = (float)sums[c + cg * 4 + u] * inv_n;
-            const float ga = gamma ? gamma[cg * 4 + u] : 1.f;
-            out[u] = ga * is[u] * (g[u] - sg - xh * sgx);
+            out[u] = ga[u] * (g[u] - sg[u] - xh * sgx[u]);
         }
         *(f32x4*)(dx + r * lddx + cg * 4) = out;
         if (dres) *(f32x4*)(dres + r * lddres + cg * 4) = g;
@@ -285,7 +308,8 @@ extern "C" int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, i
                       (!dres || lddres % 4 == 0) && count >= 1,
                   "c and leading dimensions must be multiples of 4");
     if (n == 0) return B2M_OK;
-    bn_bwd_apply_kernel<<<ew_grid(n * (c / 4)), 256, 0, st>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, sums,
+    B2M_CHECK_ARG(c <= 1024, "c <= 1024");
+    bn_bwd_apply_kernel<<<row_grid(n, c / 4), 256, 0, st>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, sums,
                                                              count, relu, dx, lddx, dres, lddres);
     B2M_LAUNCH_CHECK();
     return B2M_OK;

@@ -153,10 +153,13 @@ class SelectionNet(ResNetBase):
         out = T('block8', self.block8(ME.cat(T('up0', cbr(self.convtr7p2s2, self.bntr7, out)), out_p1)))
 
         outputs = {}
+        perm = x.manager.perm if getattr(x, 'manager', None) is not None else None
         if self.requires_voxel_outputs:
             outputs['vox_feats'] = out
         if self.cfg.do_segment_pooling:
             assert pooling_ids is not None
+            if perm is not None:                      # pooling ids arrive in input order, rows are in spatial order
+                pooling_ids = pooling_ids.to(perm.device)[perm]
             mode = 'max' if self.cfg.max_pool_segments_detection_net else 'avg'
             if n_segments is None:
                 n_segments = int(pooling_ids.max().item()) + 1
@@ -169,6 +172,11 @@ class SelectionNet(ResNetBase):
                 outputs[network_head] = self.network_heads[network_head](out)
             if self.cfg.mlp_bounds_relu and network_head == self.cfg.mlp_bounds:
                 outputs[network_head] = self.relu(outputs[network_head])
+        if perm is not None:
+            # per-voxel results leave in the row order of the input coordinates (detection_net.py:347 relies on it)
+            for name, t in outputs.items():
+                if t.F.shape[0] == perm.shape[0] and not isinstance(t, ME.PooledTensor):
+                    outputs[name] = ME.PooledTensor(t.features_in_input_order())
         ME.flush_batch_counters()
         return outputs
 

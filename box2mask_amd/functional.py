@@ -124,7 +124,7 @@ def sparse_conv(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out):
 
 
 # ----------------------------------------------------------------------------- batch norm
-_RED_BLOCKS = 1024
+_RED_BLOCKS = 4096
 
 
 def _sync_group():

@@ -16,6 +16,10 @@ import torch
 from . import _lib
 
 TILE = 64       # B2M_TILE of include/b2m.h
+# Spatial (Morton) row order for tensors built through SparseTensor(features, coordinates): an internal permutation,
+# undone at the boundary (per-voxel outputs) -- see CoordinateManager.perm.  tests switch it off to compare
+# intermediate levels row by row with the oracle.
+REORDER_DEFAULT = True
 _serial = itertools.count(1)     # unique ids for coordinate managers (cache keys must not be recycled like id())
 
 
@@ -55,7 +59,7 @@ class Rulebook:
 class CoordinateManager:
     """Coordinate maps of one batch at tensor strides 1,2,4,... and their kernel maps."""
 
-    def __init__(self, coords: torch.Tensor, keep_tables: bool = False, check: bool = True):
+    def __init__(self, coords: torch.Tensor, keep_tables: bool = False, check: bool = True, reorder: bool = False):
         _lib.require_gpu()
         assert coords.dim() == 2 and coords.shape[1] == 4, 'coords must be (N,4) [b,x,y,z]'
         if check and coords.numel():
@@ -64,6 +68,15 @@ class CoordinateManager:
                 raise ValueError('coordinates must lie in [0, 65534] (got %d..%d)' % (mn, mx))
         dev = torch.device('cuda', torch.cuda.current_device())
         c0 = coords.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous()
+        # optional spatial row order: level-0 rows sorted by Morton key; perm[i] = input row held by internal row i
+        self.perm = self.inv_perm = None
+        if reorder and c0.shape[0] > 1:
+            keys = torch.empty(c0.shape[0], dtype=torch.int64, device=dev)
+            _lib.call('b2m_morton_keys', c0.data_ptr(), c0.shape[0], keys.data_ptr())
+            self.perm = torch.argsort(keys)
+            self.inv_perm = torch.empty_like(self.perm)
+            self.inv_perm[self.perm] = torch.arange(c0.shape[0], device=dev)
+            c0 = c0[self.perm].contiguous()
         self.device = dev
         self.serial = next(_serial)
         self.keep_tables = keep_tables
@@ -154,20 +167,31 @@ class SparseTensor:
 
     def __init__(self, features, coordinates=None, device=None, coordinate_manager: CoordinateManager | None = None,
                  level: int = 0):
-        if coordinate_manager is None:
+        fresh = coordinate_manager is None
+        if fresh:
             assert coordinates is not None
-            coordinate_manager = CoordinateManager(coordinates)
+            coordinate_manager = CoordinateManager(coordinates, reorder=REORDER_DEFAULT)
         self.manager = coordinate_manager
         self.level = level
         dev = coordinate_manager.device
         self.F = features if features.device == dev else features.to(dev, non_blocking=True)
         if self.F.dtype != torch.float32:
             self.F = self.F.float()
+        if fresh and coordinate_manager.perm is not None:
+            self.F = self.F[coordinate_manager.perm]        # rows follow the manager's internal (spatial) order
         assert self.F.shape[0] == coordinate_manager.n(level), 'feature rows must match the coordinate map'
 
     @property
     def C(self):
+        """Coordinates row-aligned with F (internal row order)."""
         return self.manager.coords[self.level]
+
+    def features_in_input_order(self):
+        """Level-0 features in the row order of the coordinates the tensor was built from."""
+        m = self.manager
+        if self.level == 0 and m is not None and m.inv_perm is not None:
+            return self.F[m.inv_perm]
+        return self.F
 
     @property
     def tensor_stride(self):

@@ -44,6 +44,12 @@ int b2m_device_ok(void);
 int b2m_coords_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
                      int32_t* dup_count, void* stream);
 
+/* Morton (Z-order) key per coordinate row: batch index in bits 48.., x/y/z bits interleaved below.  Sorting the rows
+ * of a batch by this key before building the maps makes 64-row tiles spatially compact (denser rulebook groups,
+ * fewer active offsets per tile, better L2 locality of the gathers); row order is otherwise free ([ME] gives no
+ * order guarantee beyond input order, which the host restores at the boundary).  Requires b < 32768. */
+int b2m_morton_keys(const int32_t* coords, int64_t n, int64_t* keys, void* stream);
+
 /* Strided (kernel 2, stride 2) coordinate generation: out = floor(c / 2ts) * 2ts, unique, rows in
  * order of first occurrence.  Replaces [ME] stride() reached from the seven k=2,s=2 convolutions,
  * models/detection_net.py:42,48,54,61,68,74,81.
@@ -124,7 +130,7 @@ int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const
 /* ---------------------------------------------------------------- batch norm / elementwise (fp32, HBM-bound) */
 
 /* Column sums for BatchNorm: stats[0:c] = sum x, stats[c:2c] = sum x^2 (double), deterministic
- * two-stage reduction.  partial: double[2*c*nblk_max] scratch with nblk_max = 1024.
+ * two-stage reduction.  partial: double[2*c*nblk_max] scratch with nblk_max = 4096.
  * Replaces the reduction inside torch.nn.BatchNorm1d wrapped by ME.MinkowskiBatchNorm
  * (resnet.py:63,66; detection_net.py:40-135). */
 int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats, void* stream);

@@ -53,7 +53,12 @@ def test_network_forward_backward_matches_oracle():
     S_ = batch['input_location'].shape[0]
     p_cpu = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     # product
-    sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'])
+    from box2mask_amd import sparse as sparse_mod
+    sparse_mod.REORDER_DEFAULT = False          # keep input row order: intermediate levels are compared row by row
+    try:
+        sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'])
+    finally:
+        sparse_mod.REORDER_DEFAULT = True
     net._trace = {}
     out = net(sin, batch['pooling_ids'].cuda(), S_)
     heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
@@ -166,3 +171,43 @@ def test_model_train_step_and_prediction_roundtrip():
     model2.eval()
     pred2 = model2.get_prediction(batch)
     assert torch.allclose(pred['mlp_semantics'], pred2['mlp_semantics'], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_spatial_reorder_is_invisible_at_the_boundary():
+    """Morton row order inside, input row order outside: same head outputs with and without it, per-voxel outputs
+    in input order, and denser rulebooks (the reason it exists)."""
+    from box2mask_amd import nn as ME, sparse as sparse_mod
+    from box2mask_amd.detection_net import SelectionNet
+    cfg = scannet_config(network_heads=['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_per_vox_semantics'])
+    torch.manual_seed(5)
+    net = SelectionNet(cfg, 'cuda', torch.Tensor(np.arange(13)), lambda s: s > 2, out_channels=[96, 96, 6]).cuda().eval()
+    batch = synth.make_batch(8, seed0=60, target_voxels=2000, pts_per_m2=6000.0)
+    S_ = batch['input_location'].shape[0]
+    outs = {}
+    for flag in (False, True):
+        sparse_mod.REORDER_DEFAULT = flag
+        try:
+            with torch.no_grad():
+                sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'])
+                assert (sin.manager.perm is not None) == flag
+                o = net(sin, batch['pooling_ids'].cuda(), S_)
+                outs[flag] = {k: v.F.clone() for k, v in o.items()}
+                if flag:
+                    c = sin.C.cpu().numpy(); p = sin.manager.perm.cpu().numpy()
+                    assert np.array_equal(c, batch['vox_coords'].numpy()[p])         # C rows follow F rows
+        finally:
+            sparse_mod.REORDER_DEFAULT = True
+    for k in outs[False]:
+        assert outs[True][k].shape == outs[False][k].shape
+        assert _rel(outs[True][k], outs[False][k]) < 1e-4, k
+    big = synth.make_batch(1, seed0=0, target_voxels=60000)
+    pairs = {}
+    for flag in (False, True):
+        m = sparse_mod.CoordinateManager(big['vox_coords'], reorder=flag)
+        rb = m.rulebook_same(0, 3)
+        cnt = rb.rb_cnt[:rb.K * rb.ntiles].reshape(rb.K, rb.ntiles)
+        pairs[flag] = (rb.pairs, int((cnt > 0).sum()), int(((cnt + 15) // 16).sum()))
+    assert pairs[True][0] == pairs[False][0]                     # same kernel map, different tiling
+    assert pairs[True][1] < 0.9 * pairs[False][1]                # fewer active (tile, offset) slots
+    assert pairs[True][2] < 0.95 * pairs[False][2]               # fewer 16-pair MFMA row groups
