@@ -1,0 +1,79 @@
+"""Data-parallel path on real kernels: two processes (gloo rendezvous, both on cuda:0 -- the test box has one GPU)
+run SelectionNet with SyncBN on disjoint scene shards; the result must equal one process on the union batch
+(SURVEY §8e parity rule), and the bucketed gradient all-reduce must deliver the rank mean."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    import torch.distributed as dist
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    from box2mask_amd.parallel import init_distributed, shard_scenes
+    torch.cuda.set_device(0)
+    init_distributed('gloo')
+    cfg = scannet_config(multigpu=True)
+    torch.manual_seed(0)
+    model = Model(cfg, *synth.scannet_tables(), device='cuda:0')      # parameters broadcast from rank 0
+    mine = shard_scenes(8, rank, world)
+    batch = synth.collate([synth.make_scene(100 + s, target_voxels=2000, pts_per_m2=6000.0) for s in mine])
+    model.train()
+    losses, pred = model.compute_loss_detection(batch, 150)
+    losses['optimization_loss'].backward()
+    model.sync_gradients()
+    g = torch.cat([p.grad.reshape(-1)[:64].cpu() for p in list(model.parameters())[:6]])
+    q.put((rank, {'pred': {k: v.detach().cpu().numpy() for k, v in pred.items()}, 'grad': g.numpy(),
+                  'loss': float(losses['optimization_loss'].item()), 'scenes': mine,
+                  'rm': model.state_dict()['bn0.bn.running_mean'].cpu().numpy()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_syncbn_and_gradient_mean_two_ranks():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = dict(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # single process on the union batch, same weights
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    cfg = scannet_config()
+    torch.manual_seed(0)
+    model = Model(cfg, *synth.scannet_tables())
+    order = res[0]['scenes'] + res[1]['scenes']
+    batch = synth.collate([synth.make_scene(100 + s, target_voxels=2000, pts_per_m2=6000.0) for s in order])
+    model.train()
+    losses, pred = model.compute_loss_detection(batch, 150)
+    n0 = res[0]['pred']['mlp_offsets'].shape[0]
+    for h in ('mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics'):
+        full = pred[h].detach().cpu().numpy()
+        both = np.concatenate([res[0]['pred'][h], res[1]['pred'][h]], 0)
+        assert both.shape == full.shape
+        err = np.abs(both - full).max() / max(np.abs(full).max(), 1e-9)
+        assert err < 1e-3, (h, err)           # SyncBN over shards == BN over the union
+    assert np.allclose(res[0]['rm'], model.state_dict()['bn0.bn.running_mean'].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert np.allclose(res[0]['rm'], res[1]['rm'])
+    # both ranks hold the same (mean) gradients after the all-reduce
+    assert np.allclose(res[0]['grad'], res[1]['grad'], rtol=1e-5, atol=1e-7)
+    assert n0 > 0 and np.isfinite(res[0]['loss']) and np.isfinite(res[1]['loss'])
