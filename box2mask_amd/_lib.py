@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libb2m_hip.so')
+LIB_PATH = os.environ.get('B2M_LIB_PATH', os.path.join(_HERE, 'libb2m_hip.so'))   # override: A/B of two builds
 
 P = C.c_void_p
 I32 = C.c_int32

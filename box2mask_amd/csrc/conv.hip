@@ -394,21 +394,7 @@ struct WgradArgs {
     int fast32;              // complete blocks and 24/32-bit addressable tensors: cheap address arithmetic
 };
 
-template <int N> struct vecf;
-template <> struct vecf<1> { typedef float type; };
-template <> struct vecf<2> { typedef float type __attribute__((ext_vector_type(2))); };
-struct __attribute__((packed, aligned(4))) f32x3p { float a, b, c; };    // 12 bytes, 4-byte aligned
-template <> struct vecf<3> { typedef f32x3p type; };
-template <> struct vecf<4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <int N> __device__ __forceinline__ float vget(const typename vecf<N>::type& v, int j) { return v[j]; }
-template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
-template <> __device__ __forceinline__ float vget<3>(const f32x3p& v, int j) { return j == 0 ? v.a : (j == 1 ? v.b : v.c); }
-
-// VEC (off by default: measured 35 vs 45 TFLOP/s for the scalar map on 96->96, A/B in tools/bench_conv.py):
-// every block is complete and aligned.  The channel <-> (sub-tile, lane) map is then chosen so that a lane
-// owns MI (NJ) CONSECUTIVE channels: ci = ci0 + MI*i + m, co = co0 + NJ*i + n -- one 4..16-byte load per lane
-// and pair instead of MI (NJ) scalar loads; the wave reads 64*MI contiguous bytes of a gathered row.
-template <int MI, int NJ, bool VEC, bool FLAT>
+template <int MI, int NJ>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -427,13 +413,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int64_t t0 = (int64_t)blockIdx.y * a.tiles_per_chunk;
     int64_t t1 = t0 + a.tiles_per_chunk;
     if (t1 > a.ntiles) t1 = a.ntiles;
-    // The chunk is walked as a flat sequence of group SLOTS (4 per tile, 16 pairs each).  The pair list of slot
-    // s+1 is requested before the data of slot s (independent loads in flight together instead of one
-    // dependent chain per group); ping-pong registers, no copies.  Empty slots (all -1) skip loads and MFMAs.
-    const int64_t s_begin = t0 * NG, s_end = t1 * NG;
+    // a group SLOT = 16 pairs of one (tile, offset): slot = tile*4 + g
     const int64_t kbase = (int64_t)k * ldr;
     auto load_slot = [&](int64_t slot, int (&rin)[4], uint32_t& o4) {
-        if (slot >= s_end) slot = s_end - 1;
         if (identity) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -452,24 +434,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const uint32_t ldx4 = (uint32_t)a.ldx * 4u, lddy4 = (uint32_t)a.lddy * 4u;
     const uint32_t cxb = (uint32_t)(ci0 + i) * 4u, cyb = (uint32_t)(co0 + i) * 4u;
     auto process = [&](int64_t slot, const int (&rin)[4], uint32_t o4) {
-        if (__ballot(rin[0] >= 0) == 0) return;        // wave-uniform: empty slot
+        if (__ballot(rin[0] >= 0) == 0) return;        // wave-uniform; also makes the list wait explicit before the gathers
         const int64_t row0 = (slot >> 2) * B2M_TILE;
         float av[4][MI], bv[4][NJ];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int r = rin[s];
             const int64_t ro = row0 + ((o4 >> (8 * s)) & 255);
-            if constexpr (VEC) {
-                // padded pairs (r < 0) must contribute zero to the sum over pairs: read the zero buffer
-                typedef typename vecf<MI>::type VA;
-                typedef typename vecf<NJ>::type VB;
-                const VA va = *(const VA*)(r >= 0 ? a.x + (int64_t)r * a.ldx + ci0 + MI * i : a.zeros);
-                const VB vb = *(const VB*)(r >= 0 ? a.dy + ro * a.lddy + co0 + NJ * i : a.zeros);
-#pragma unroll
-                for (int m = 0; m < MI; ++m) av[s][m] = vget<MI>(va, m);
-#pragma unroll
-                for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = vget<NJ>(vb, nn);
-            } else if (a.fast32) {
+            if (a.fast32) {
                 // complete blocks, tensors below 2^31 bytes: ONE full-rate 24-bit multiply-add per gathered row gives
                 // the byte offset, the sub-tile offsets (64 B apart) become immediates of the loads
                 const uint32_t bx = __umul24((uint32_t)(r < 0 ? 0 : r), ldx4) + cxb;
@@ -508,29 +480,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 for (int nn = 0; nn < NJ; ++nn)
                     acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][m], bv[s][nn], acc[m][nn], 0, 0, 0);
     };
-    if constexpr (FLAT) {
-        if (s_begin < s_end) {
-            int rinA[4], rinB[4]; uint32_t oA, oB;
-            load_slot(s_begin, rinA, oA);
-            for (int64_t slot = s_begin; slot < s_end; slot += 2) {
-                load_slot(slot + 1, rinB, oB);
-                process(slot, rinA, oA);
-                load_slot(slot + 2, rinA, oA);
-                if (slot + 1 < s_end) process(slot + 1, rinB, oB);
-            }
-        }
-    } else {
-        // plain nested walk: only the non-empty groups of every tile, list then data (dependent loads)
-        for (int64_t tile = t0; tile < t1; ++tile) {
-            int n;
-            if (identity) { int64_t rem = a.n_out - tile * B2M_TILE; n = rem < B2M_TILE ? (int)rem : B2M_TILE; }
-            else n = __builtin_amdgcn_readfirstlane(a.rb_cnt[(int64_t)k * a.ntiles + tile]);
-            const int G = (n + 15) >> 4;
-            for (int g = 0; g < G; ++g) {
-                int rin[4]; uint32_t o4;
-                load_slot(tile * NG + g, rin, o4);
-                process(tile * NG + g, rin, o4);
-            }
+    // nested walk: only the non-empty groups of every tile (list, then data).  A flat slot walk with the next list
+    // prefetched and a vectorised channel map were both measured slower (tools/bench_conv.py A/B, round 1).
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        int n;
+        if (identity) { int64_t rem = a.n_out - tile * B2M_TILE; n = rem < B2M_TILE ? (int)rem : B2M_TILE; }
+        else n = __builtin_amdgcn_readfirstlane(a.rb_cnt[(int64_t)k * a.ntiles + tile]);
+        const int G = (n + 15) >> 4;
+        for (int g = 0; g < G; ++g) {
+            int rin[4]; uint32_t o4;
+            load_slot(tile * NG + g, rin, o4);
+            process(tile * NG + g, rin, o4);
         }
     }
     // D[row = 4q + r (A's lane index), col = i (B's lane index)]
@@ -540,8 +500,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         for (int nn = 0; nn < NJ; ++nn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ci = VEC ? ci0 + MI * (4 * q + r) + m : ci0 + 16 * m + 4 * q + r;
-                const int co = VEC ? co0 + NJ * i + nn : co0 + 16 * nn + i;
+                const int ci = ci0 + 16 * m + 4 * q + r, co = co0 + 16 * nn + i;
                 if (ci < a.cin && co < a.cout) {
                     const float v = acc[m][nn][r];
                     if (v != 0.f) atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)ci * a.lddw + co], v);
@@ -549,22 +508,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
 }
 
-template <int MI, bool VEC, bool FLAT>
+template <int MI>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
     switch (NJ) {
-        case 1: conv_wgrad_kernel<MI, 1, VEC, FLAT><<<grid, 256, 0, st>>>(a); break;
-        case 2: conv_wgrad_kernel<MI, 2, VEC, FLAT><<<grid, 256, 0, st>>>(a); break;
-        case 3: conv_wgrad_kernel<MI, 3, VEC, FLAT><<<grid, 256, 0, st>>>(a); break;
-        default: conv_wgrad_kernel<MI, 4, VEC, FLAT><<<grid, 256, 0, st>>>(a); break;
+        case 1: conv_wgrad_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
+        case 2: conv_wgrad_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
+        case 3: conv_wgrad_kernel<MI, 3><<<grid, 256, 0, st>>>(a); break;
+        default: conv_wgrad_kernel<MI, 4><<<grid, 256, 0, st>>>(a); break;
     }
 }
-template <bool VEC, bool FLAT>
 static void launch_wgrad(int MI, int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
     switch (MI) {
-        case 1: launch_wgrad_nj<1, VEC, FLAT>(NJ, grid, st, a); break;
-        case 2: launch_wgrad_nj<2, VEC, FLAT>(NJ, grid, st, a); break;
-        case 3: launch_wgrad_nj<3, VEC, FLAT>(NJ, grid, st, a); break;
-        default: launch_wgrad_nj<4, VEC, FLAT>(NJ, grid, st, a); break;
+        case 1: launch_wgrad_nj<1>(NJ, grid, st, a); break;
+        case 2: launch_wgrad_nj<2>(NJ, grid, st, a); break;
+        case 3: launch_wgrad_nj<3>(NJ, grid, st, a); break;
+        default: launch_wgrad_nj<4>(NJ, grid, st, a); break;
     }
 }
 // tuning switches (A/B inside one process: tools/bench_conv.py); read at every call
@@ -610,18 +568,13 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     if (cdiv64(a.ntiles, tpc) > 65535) tpc = cdiv64(a.ntiles, 65535);
     a.tiles_per_chunk = (int)tpc;
     dim3 grid((unsigned)K, (unsigned)cdiv64(a.ntiles, tpc), (unsigned)((a.nmb * a.nnb + 3) / 4));
-    // vector path: complete, aligned blocks (every trunk layer: channel counts are multiples of 32)
-    const bool vec = cin % (16 * MI) == 0 && cout % (16 * NJ) == 0 && ldx % 4 == 0 && lddy % 4 == 0 &&
-                     ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && env_flag("B2M_WGRAD_VEC", 0) != 0;
     // 24-bit multiply operands and 32-bit byte offsets: rows < 2^24, row pitch < 2^22 floats, tensors < 4 GiB
     // (blocks may overhang cin/cout as long as the row PITCH covers them: the extra columns only feed dW rows /
     // columns that are never written)
     a.fast32 = (ldx >= (int64_t)a.nmb * 16 * MI && lddy >= (int64_t)a.nnb * 16 * NJ && n_out < (1 << 24) && n_in < (1 << 24) &&
                 ldx < (1 << 22) && lddy < (1 << 22) && n_out * lddy * 4 < (1ll << 32) && n_in * ldx * 4 < (1ll << 32) &&
                 env_flag("B2M_WGRAD_FAST32", 1)) ? 1 : 0;
-    const bool flat = env_flag("B2M_WGRAD_FLAT", 0) != 0;
-    if (vec) { if (flat) launch_wgrad<true, true>(MI, NJ, grid, st, a); else launch_wgrad<true, false>(MI, NJ, grid, st, a); }
-    else { if (flat) launch_wgrad<false, true>(MI, NJ, grid, st, a); else launch_wgrad<false, false>(MI, NJ, grid, st, a); }
+    launch_wgrad(MI, NJ, grid, st, a);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -1,5 +1,11 @@
 """Micro-benchmark of the sparse-conv kernels on one synthetic scene batch, with interleaved A/B rounds of
-the tuning switches (B2M_CONV_PREF, B2M_WGRAD_FLAT) inside one process (same device, same clocks)."""
+tuning switches inside one process (same device, same clocks).
+
+    python tools/bench_conv.py                       # base vs the variants below
+    VARIANTS="tw2:B2M_CONV_TW3=0;npf2:B2M_CONV_NPF=2" python tools/bench_conv.py
+
+Switches read by csrc/conv.hip at every call: B2M_CONV_TW3 (48-column strips), B2M_CONV_NPF (chunks of loads in
+flight), B2M_CONV_FAST32 / B2M_WGRAD_FAST32 (24-bit multiply addressing)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,7 +26,12 @@ def timeit(fn, n=4):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 
-VARIANTS = [('base', {}), ('npf2', {'B2M_CONV_NPF': '2'})]
+VARIANTS = [('base', {})]
+for spec in os.environ.get('VARIANTS', 'tw2:B2M_CONV_TW3=0;slow64:B2M_WGRAD_FAST32=0').split(';'):
+    if spec:
+        name, kv = spec.split(':'); k_, v_ = kv.split('=')
+        VARIANTS.append((name, {k_: v_}))
+SWITCHES = ('B2M_CONV_TW3', 'B2M_CONV_NPF', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32')
 cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
          ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
          ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64)]
@@ -38,7 +49,7 @@ for name, rb, K, c1, c2, co in cases:
     res = {v: [[], []] for v, _ in VARIANTS}
     for rnd in range(4):
         for v, env in VARIANTS:
-            for k_ in ('B2M_CONV_PREF', 'B2M_WGRAD_FLAT', 'B2M_WGRAD_VEC', 'B2M_CONV_NPF', 'B2M_CONV_TW3', 'B2M_WGRAD_FAST32', 'B2M_CONV_FAST32', 'B2M_DIAG'): os.environ.pop(k_, None)
+            for k_ in SWITCHES: os.environ.pop(k_, None)
             os.environ.update(env)
             wp = F_.weight_pack(w)          # the packed layout depends on the strip-width switch
             if rnd == 0: f_fwd(); f_wg(); torch.cuda.synchronize()
