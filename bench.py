@@ -80,6 +80,7 @@ def main():
     ap.add_argument('--cpu-scenes', type=int, default=2, help='scenes in the CPU baseline sample')
     ap.add_argument('--detail', type=int, default=0, help='1 prints a per-layer-shape table of the conv launches to stderr')
     ap.add_argument('--cpu-timeout', type=int, default=240, help='seconds after which the CPU baseline is abandoned')
+    ap.add_argument('--votes', type=int, default=1, help='0 skips the votes -> instance masks leg (outside the timed steps)')
     args = ap.parse_args()
 
     # The CPU baseline runs FIRST, before this process touches the GPU (pure torch-CPU oracle, rank 0, N=1 only).
@@ -215,12 +216,74 @@ def main():
         'roofline': roofline, 'roofline_wgrad': roofline_wgrad,
     }
 
+    # ---- second half of configs[1] ("+ iou_nms on HIP"): votes -> instance masks of the same 8 scenes, reported
+    # beside the headline value (never part of it)
+    if args.votes:
+        result['votes_to_masks'] = votes_leg(model, batch, cfg, cpu=bool(args.cpu_baseline) and world == 1)
+
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
     if cpu_result is not None:
         result['cpu_baseline'] = cpu_result
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+
+
+def votes_leg(model, batch, cfg, cpu):
+    """Evaluater flow (evaluation.py:86-97) on synthetic votes: every segment of the batch votes for the box of
+    its ground-truth object with 2.5 cm noise on offset and bounds, score logits ~ N(0,2), semantics = ground
+    truth.  Times Model.pred2mask(batch, pred, 'eval') over the whole batch; with `cpu`, scene 0 is
+    also run on the CPU oracle (oracle/nms_ref.py, pinned bit for bit to the reference) and compared."""
+    from box2mask_amd import synth
+    g = torch.Generator().manual_seed(7)
+    S = batch['input_location'].shape[0]
+    valid, id2idx, _, is_fg = synth.scannet_tables()
+    sem_idx = id2idx[batch['gt_semantics'].cpu()].clamp_min(0)
+    pred = {
+        cfg.mlp_offsets: batch['gt_bb_offsets'].cpu() + 0.025 * torch.randn(S, 3, generator=g),
+        cfg.mlp_bounds: (batch['gt_bb_bounds'].cpu() + 0.025 * torch.randn(S, 3, generator=g)).clamp_min(cfg.min_bb_size),
+        cfg.mlp_bb_scores: 2.0 * torch.randn(S, 1, generator=g),
+        cfg.mlp_semantics: torch.nn.functional.one_hot(sem_idx, len(valid)).float(),
+    }
+    cpu_batch = dict(batch)
+    for k in ('input_location', 'batch_ids'):
+        cpu_batch[k] = batch[k].cpu()
+    model.eval()
+    res = model.pred2mask(cpu_batch, pred, 'eval')          # warm-up
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = model.pred2mask(cpu_batch, pred, 'eval')
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    n_scenes = len(batch['scene'])
+    fg_votes = int(is_fg(valid[sem_idx].long()).sum())
+    out = {'value': round(n_scenes / dt, 2), 'unit': 'scenes/s', 'ms_per_scene': round(dt / n_scenes * 1e3, 3),
+           'scenes': n_scenes, 'segments': int(S), 'foreground_votes': fg_votes,
+           'instances': int(sum(len(r['conf']) for r in res.values())),
+           'flow': "Model.pred2mask(batch, pred, 'eval') with eval_ths %s; pred on the host as in "
+                   "evaluation.py:86, masks returned to the host" % (list(cfg.eval_ths),)}
+    if cpu:
+        from oracle import nms_ref
+        m = (cpu_batch['batch_ids'] == 0).numpy()
+        scores = torch.sigmoid(pred[cfg.mlp_bb_scores])[m].numpy()
+        bbs = nms_ref.to_bbs_min_max(cpu_batch['input_location'][m].numpy(), pred[cfg.mlp_offsets][m].numpy(),
+                                     pred[cfg.mlp_bounds][m].numpy(), scores)
+        sem = valid[sem_idx[m]].long().numpy()
+        t0 = time.perf_counter()
+        ref = nms_ref.detection2mask_scene(bbs, sem, lambda x: (x > 2) & (x != 22), np.asarray(batch['seg2vox'][0]),
+                                           np.asarray(batch['vox2point'][0]), list(cfg.eval_ths), 'eval')
+        cdt = time.perf_counter() - t0
+        got = res[batch['scene'][0]['name']]
+        same = (np.array_equal(ref['conf'], got['conf'].numpy()) and np.array_equal(ref['label_id'], got['label_id'])
+                and np.array_equal(ref['mask'], got['mask'].numpy()))
+        out['cpu_baseline'] = {'value': round(1.0 / cdt, 3), 'unit': 'scenes/s', 'cores': 1, 'kind': 'port',
+                               'sample': 'scene 0 of the batch on oracle/nms_ref.py (numpy restatement, bit-exact '
+                                         'against the reference on tests/golden): %.2f s' % cdt,
+                               'identical_to_gpu_result': bool(same)}
+    model.train()
+    return out
 
 
 def cpu_baseline(n_scenes, voxels, timeout_s, ref_voxels):

@@ -30,6 +30,28 @@ struct ConvArgs {
 // loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
 __device__ float g_zeros[64];
 
+// Diagnostic build only (-DB2M_STAMPS, tools/stamps.py): s_memtime stamps per phase of the offset walk, summed
+// over all waves.  Not compiled into the shipped library.
+#ifdef B2M_STAMPS
+__device__ unsigned long long g_stamps[12];
+#define B2M_STAMP(v)                                 \
+    do {                                             \
+        __builtin_amdgcn_sched_barrier(0);           \
+        v = __builtin_amdgcn_s_memtime();            \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
+extern "C" int b2m_debug_stamps(unsigned long long* out8, int reset) {   // out8: 12 counters
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define B2M_STAMP(v) do { } while (0)
+#endif
+
 static_assert(B2M_TILE == 64, "conv kernels assume 64-row tiles (4 row groups of 16)");
 #define NG 4     // row groups per tile
 
@@ -49,7 +71,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
     constexpr int KS = KC / 4;                // k-steps per chunk == floats per lane per gathered row
     constexpr int SW = 16 * TW;               // output channels per strip
     constexpr int LW = 64 * TW * KS;          // floats per packed weight block
-    __shared__ float smem[4 * B2M_TILE * SW];
+    __shared__ float smem[4 * (B2M_TILE + 1) * SW];   // per wave: 64 rows + one spare row for padded pairs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t witem = (int64_t)blockIdx.x * 4 + wave;
@@ -64,7 +86,11 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
     const int nch1 = (a.c1 + KC - 1) / KC;    // chunks served by the first source (c1 % KC == 0 when c2 > 0)
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int64_t row0 = tile * B2M_TILE;
-    float* Cs = smem + wave * (B2M_TILE * SW);
+    float* Cs = smem + wave * ((B2M_TILE + 1) * SW);
+#ifdef B2M_STAMPS
+    unsigned long long st_begin, st0, st1, st2, st3, st_idx = 0, st_loop = 0, st_epi = 0, st_noff = 0, st_groups = 0;
+    B2M_STAMP(st_begin);
+#endif
 
     // ---- init the strip: 0 | Y (accumulate) | + bias
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
@@ -83,6 +109,11 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
         *(f32x4*)&Cs[cs_index<TW>(row, c4)] = v;
     }
 
+#ifdef B2M_STAMPS
+    unsigned long long st_a, st_b;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    B2M_STAMP(st_a);
+#endif
     // ---- active offsets of this tile (K <= 128): lane k holds the pair count of offset k / k+64
     int cnt0 = 0, cnt1 = 0;
     if (IDENT) {
@@ -93,6 +124,10 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
         if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
     }
 
+#ifdef B2M_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B2M_STAMP(st_b);
+#endif
     // Walk the kernel offsets with purely scalar control flow: the pair count of offset k is read from lane k
     // (k is wave-uniform), empty offsets are skipped, and with split-K the active offsets are dealt round-robin
     // to the slices by a running phase counter.
@@ -104,6 +139,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
         phase = phase + 1 == a.nslice ? 0 : phase + 1;
         if (!mine) continue;
         const int G = (n + 15) >> 4;           // 1..4 dense row groups
+        B2M_STAMP(st0);
         // pair lists: lane (i,q) gathers input row idx[g] and later flushes the 4 output rows packed in out[g].
         // Rows of padded pairs (idx < 0) are clamped to row 0: an MFMA output row depends only on its own A row,
         // and the flush below skips padded pairs, so whatever they compute is never used.
@@ -124,6 +160,10 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
                 }
             }
         }
+#ifdef B2M_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        B2M_STAMP(st1);
+#endif
         f32x4 acc[NG][TW];
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -209,26 +249,51 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
         };
         run_source(a.x1, a.ldx1, a.c1, 0, nch1);
         if (a.c2 > 0) run_source(a.x2, a.ldx2, a.c2, nch1, nchunk);
+        B2M_STAMP(st2);
 
         // ---- add the offset's result into the strip.  D[row = 4q + r][col = i]; the pairs of one offset have
-        // distinct output rows and padded pairs are skipped, so no two lanes of an instruction touch the same
-        // address: plain read-modify-write is race free inside the wave.
+        // distinct output rows, so the read-modify-writes of an offset never alias and can be batched: all reads
+        // of FG row groups, then the adds, then the writes (one LDS round trip per batch instead of one per
+        // element -- unbatched, the dependent ds_read -> add -> ds_write chains were 15 % of a wave's life).
+        // Padded pairs are steered to the spare row B2M_TILE of the strip, so there is no divergence.
+        constexpr int FG = 2;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g < G) {
-                const uint32_t o4 = out[g];
+        for (int g0 = 0; g0 < NG; g0 += FG) {
+            if (g0 < G) {
+                int ad[FG][4];
+                float old[FG][4][TW];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (16 * g + 4 * q + r < n) {
-                        const int row = (o4 >> (8 * r)) & 255;
+                for (int gg = 0; gg < FG; ++gg) {
+                    const int g = g0 + gg;
+                    const uint32_t o4 = out[g];
 #pragma unroll
-                        for (int t = 0; t < TW; ++t) Cs[cs_index<TW>(row, 16 * t + i)] += acc[g][t][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = (16 * g + 4 * q + r < n) ? (int)((o4 >> (8 * r)) & 255) : B2M_TILE;
+                        ad[gg][r] = row;
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) old[gg][r][t] = Cs[cs_index<TW>(row, 16 * t + i)];
                     }
                 }
+#pragma unroll
+                for (int gg = 0; gg < FG; ++gg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int t = 0; t < TW; ++t)
+                            Cs[cs_index<TW>(ad[gg][r], 16 * t + i)] = old[gg][r][t] + acc[g0 + gg][t][r];
             }
         }
+#ifdef B2M_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        B2M_STAMP(st3);
+        st_idx += st1 - st0; st_loop += st2 - st1; st_epi += st3 - st2; st_noff += 1; st_groups += G;
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#ifdef B2M_STAMPS
+    unsigned long long st_mid;
+    B2M_STAMP(st_mid);
+#endif
 
     // ---- write the strip
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
@@ -248,6 +313,17 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
             for (int u = 0; u < 4; ++u) if (col + u < a.cout) dst[u] = v[u];
         }
     }
+#ifdef B2M_STAMPS
+    unsigned long long st_end;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B2M_STAMP(st_end);
+    if (lane == 0) {
+        atomicAdd(&g_stamps[0], st_idx); atomicAdd(&g_stamps[1], st_loop); atomicAdd(&g_stamps[2], st_epi);
+        atomicAdd(&g_stamps[3], st_end - st_begin); atomicAdd(&g_stamps[4], st_noff); atomicAdd(&g_stamps[5], 1ull);
+        atomicAdd(&g_stamps[6], st_end - st_mid); atomicAdd(&g_stamps[7], st_groups);
+        atomicAdd(&g_stamps[8], st_a - st_begin); atomicAdd(&g_stamps[9], st_b - st_a);
+    }
+#endif
 }
 
 static int env_flag(const char* name, int dflt);
@@ -338,6 +414,7 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     // fill 1024 SIMDs and each item walks K*cin/16 dependent steps: split the offsets over up to 16 waves.
     const int64_t items0 = a.ntiles * a.nstrips;
     int nslice = 1;
+    // (more, smaller slices were measured too: 2-6x as many waves lose 0-60 % to the atomic combine)
     if (items0 < 4096 && K > 1) {
         nslice = (int)cdiv64(4096, items0);
         if (nslice > 16) nslice = 16;
