@@ -46,6 +46,20 @@ CONV_CASES = [
 
 @pytest.mark.parametrize('kind,level,cins,cout,bias', CONV_CASES)
 def test_conv_forward_backward(maps, kind, level, cins, cout, bias):
+    _conv_case(maps, kind, level, cins, cout, bias)
+
+
+@pytest.mark.parametrize('kind,level,cins,cout,bias', [CONV_CASES[1], CONV_CASES[2], CONV_CASES[4], CONV_CASES[5],
+                                                      CONV_CASES[8], CONV_CASES[12]])
+def test_conv_64bit_addressing(maps, monkeypatch, kind, level, cins, cout, bias):
+    """Operands beyond 4 GiB / 2^24 rows take 64-bit address arithmetic inside the kernels; the switch is decided
+    per launch, so force it here on small inputs (the C library reads the variables at every call)."""
+    monkeypatch.setenv('B2M_CONV_FAST32', '0')
+    monkeypatch.setenv('B2M_WGRAD_FAST32', '0')
+    _conv_case(maps, kind, level, cins, cout, bias)
+
+
+def _conv_case(maps, kind, level, cins, cout, bias):
     from box2mask_amd import functional as F_
     from oracle import sparse_ref as S
     m, h = maps
