@@ -20,7 +20,7 @@ I64 = C.c_int64
 F32 = C.c_float
 F64 = C.c_double
 
-# name -> argument types (return type is always int).  Must list EVERY symbol of include/b2m.h;
+# name -> argument types (return type is always int).  Must list EVERY symbol of include/*.h;
 # tests/test_abi.py cross-checks this table against the header.
 PROTOTYPES = {
     'b2m_coords_build': [P, I64, P, P, I64, P, P],
@@ -50,9 +50,19 @@ PROTOTYPES = {
     'b2m_mask_gather': [P, I64, P, I32, P, I64, P, P],
     'b2m_mask_pack': [P, I32, I64, P, I64, P],
     'b2m_set_ious': [P, P, I64, P, P],
+    # include/b2m_prepare.h
+    'b2m_vox_shift': [P, I64, P, P, P],
+    'b2m_vox_keys': [P, I64, P, F64, P, P, P],
+    'b2m_sort_u64': [P, I64, P],
+    'b2m_unique_rank': [P, I64, P, P, I64, P, I64, P, P],
+    'b2m_vox_decode': [P, I64, I32, P, P],
+    'b2m_vox_nearest': [P, I64, P, F64, P, P, I64, I64, P, P, P],
+    'b2m_vox_gather': [P, I64, P, P, P, P, P, P],
+    'b2m_seg_centroid': [P, P, I64, I64, F64, P, P, P, P, P],
 }
 PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_device_ok': (C.c_int, []),
-         'b2m_weight_pack_size': (C.c_int64, [I32, I32, I32])}
+         'b2m_weight_pack_size': (C.c_int64, [I32, I32, I32]),
+         'b2m_unique_insert': (C.c_int64, [P, I64, P, I64, P, P, P, P])}
 
 _lib = None
 

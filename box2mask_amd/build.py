@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libb2m_hip.so')
-SOURCES = ['coords.hip', 'conv.hip', 'norm.hip', 'nms.hip']
+SOURCES = ['coords.hip', 'conv.hip', 'norm.hip', 'nms.hip', 'voxelize.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics', '-Wall',
          '-Wno-unused-function']
@@ -23,7 +23,8 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'b2m.h')]
+    inc = os.path.join(HERE, '..', 'include')
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith('.o')] + [os.path.join(inc, f) for f in os.listdir(inc)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -52,7 +52,7 @@ def _sample_rect(rng, origin, eu, ev, normal, density, surf_id, cell):
 
 def make_scene(seed: int, target_voxels: int = 150_000, voxel_size: float = 0.02,
                pts_per_m2: float = 2.0e4, cell: float = 0.25, noise_sigma: float = 0.0,
-               name: str | None = None):
+               name: str | None = None, points_only: bool = False):
     """One synthetic indoor scene in the per-item format the reference Dataset returns.
 
     ``target_voxels`` scales the room so that the voxel count lands within about +-10 % of it
@@ -119,6 +119,9 @@ def make_scene(seed: int, target_voxels: int = 150_000, voxel_size: float = 0.02
     pt_sem = np.concatenate([np.full(len(q[0]), q[4], np.int64) for q in parts], 0)
     colors = rng.normal(0.0, 1.0, (len(positions), 3))
     _, segments = np.unique(seg_key, return_inverse=True)   # dense per-scene segment ids
+    if points_only:     # the raw scene, as dataprocessing/scannet.py hands it to the dataset class (float64)
+        return {'name': name or ('synth%04d' % seed), 'positions': positions, 'colors': colors,
+                'normals': normals, 'segments': segments.reshape(-1).astype(np.int64)}
 
     # ---- voxelisation, as /root/reference/models/dataloader.py:61-68 ----
     input_coords = positions - min(0, np.min(positions))

@@ -1,0 +1,85 @@
+"""CPU restatement of the reference's scene preparation -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(box2mask_amd/prepare.py) never does.
+
+Follows /root/reference/models/dataloader.py:61-123 (voxelisation block of ScanNet.__getitem__) and :946-995
+(collate_fn) with /root/reference/utils/util.py:123-130 (to_unique).  The nearest-point association uses
+scikit-learn's ball tree exactly as the reference does (sklearn is the reference's own dependency for this step and
+is part of this image); `nearest_bruteforce` is an independent fp64 check of it for small inputs.
+
+Pinned: tests/golden/prepare.npz holds inputs and outputs of the REAL reference code (tools/gen_golden.py drives
+ScanNet.__getitem__ and collate_fn of /root/reference with a synthetic scene behind stand-ins for the modules that
+only load data); tests/test_oracle_prepare.py checks this restatement against it bit for bit.
+"""
+import numpy as np
+
+try:                                    # the reference's dependency for dataloader.py:75
+    from sklearn.neighbors import NearestNeighbors
+except ImportError:                     # pragma: no cover
+    NearestNeighbors = None
+
+
+def voxelize_scene(positions, colors, normals, segments, voxel_size, use_normals=True):
+    """dataloader.py:61-123 for do_segment_pooling=True.  All arrays numpy (float64 / int64)."""
+    positions = np.asarray(positions)
+    shift = min(0, np.min(positions))                                   # :63
+    input_coords = (positions - shift) / voxel_size                     # :63-65
+    vox = np.round(input_coords)                                        # :67
+    vox_coords, vox2point = np.unique(vox, axis=0, return_inverse=True)  # :68
+    vox2point = vox2point.reshape(-1)
+    nbrs = NearestNeighbors(n_neighbors=1, algorithm='ball_tree').fit(input_coords)   # :75
+    point2vox = nbrs.kneighbors(vox_coords, return_distance=False).reshape(-1)        # :76-77
+    feats = np.concatenate([colors, normals], 1) if use_normals else np.asarray(colors)   # :82-88
+    vox_segments = np.asarray(segments)[point2vox]                      # :90
+    vox_features = feats[point2vox]                                     # :91
+    vox_world = vox_coords * voxel_size + shift                         # :94
+    uniq, seg2vox = np.unique(vox_segments, return_inverse=True)        # :108
+    seg2vox = seg2vox.reshape(-1)
+    seg2point = seg2vox[vox2point]                                      # :109
+    middle = np.zeros((uniq.shape[0], 3))
+    for i, seg in enumerate(uniq):                                      # :113-115
+        middle[i] = np.mean(vox_world[seg == vox_segments], axis=0)
+    return {'vox_coords': vox_coords, 'vox2point': vox2point, 'point2vox': point2vox, 'vox_segments': vox_segments,
+            'vox_features': vox_features, 'vox_world_coords': vox_world, 'seg2vox': seg2vox, 'seg2point': seg2point,
+            'input_location': middle, 'pred2point': seg2point, 'unique_vox_segments': uniq}
+
+
+def nearest_bruteforce(input_coords, vox_coords, chunk=256):
+    """argmin_p sum_j (vox[j] - p[j])^2 in fp64, summed x,y,z; lowest p on exact ties."""
+    input_coords = np.asarray(input_coords, np.float64)
+    out = np.empty(len(vox_coords), np.int64)
+    for a in range(0, len(vox_coords), chunk):
+        q = np.asarray(vox_coords[a:a + chunk], np.float64)
+        d = (q[:, None, 0] - input_coords[None, :, 0]) ** 2
+        d = d + (q[:, None, 1] - input_coords[None, :, 1]) ** 2
+        d = d + (q[:, None, 2] - input_coords[None, :, 2]) ** 2
+        out[a:a + chunk] = np.argmin(d, 1)
+    return out
+
+
+def to_unique(segments):
+    """utils/util.py:123-130."""
+    segs = [np.array(s, copy=True) for s in segments]
+    for i in range(1, len(segs)):
+        segs[i] += np.max(segs[i - 1]) + 1
+    cat = np.concatenate(segs, 0)
+    _, pooling_ids = np.unique(cat, return_inverse=True)
+    return pooling_ids.reshape(-1).astype(np.int64)
+
+
+def collate(items):
+    """collate_fn.__call__ in 'test' mode (dataloader.py:954-984): numpy arrays with the dtypes of the torch
+    tensors the reference makes."""
+    coords = []
+    for b, it in enumerate(items):                                      # ME.utils.batched_coordinates, :966
+        c = np.floor(it['vox_coords']).astype(np.int32)
+        coords.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+    return {
+        'vox_coords': np.concatenate(coords, 0),
+        'vox_features': np.concatenate([it['vox_features'] for it in items], 0).astype(np.float32),       # :967
+        'batch_ids': np.concatenate([np.full(len(it['input_location']), b, np.int64)                      # :969-974
+                                     for b, it in enumerate(items)], 0),
+        'input_location': np.concatenate([it['input_location'] for it in items], 0).astype(np.float32),   # :980
+        'pooling_ids': to_unique([it['vox_segments'] for it in items]),                                   # :981
+    }

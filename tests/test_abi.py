@@ -1,4 +1,4 @@
-"""The C-ABI shared library loads and exports every symbol include/b2m.h declares, and the ctypes
+"""The C-ABI shared library loads and exports every symbol include/*.h declares, and the ctypes
 prototype table matches the header (argument counts and kinds).  No compute calls (no GPU here)."""
 import ctypes
 import os
@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_decls():
-    src = open(os.path.join(ROOT, 'include', 'b2m.h')).read()
+    inc = os.path.join(ROOT, 'include')
+    src = ''.join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith('.h'))
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     decls = {}
     for m in re.finditer(r'\b(int64_t|int|const char\*)\s+(b2m_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):

@@ -1,0 +1,159 @@
+"""GPU parity of scene preparation (include/b2m_prepare.h, box2mask_amd/prepare.py) against the golden vectors of
+the real reference (tests/golden/prepare.npz) and against the CPU oracle on other inputs.  Integer outputs (voxel
+rows, inverse maps, associated points, segment ranks) are bit-exact; float32 features are bit-exact; segment
+centroids are compared in fp64 with rtol 1e-12 (integer sums vs numpy's running mean) and as float32 exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'prepare.npz'))
+
+
+def _scene(gold, i):
+    return {k: gold['s%d_in_%s' % (i, k)] for k in ('positions', 'colors', 'normals', 'segments')}, \
+        float(gold['s%d_in_voxel_size' % i])
+
+
+def _check_item(item, want, tag):
+    from box2mask_amd import prepare
+    n = lambda t: t.cpu().numpy()
+    assert np.array_equal(n(item['vox_coords'][:, 1:]), want['vox_coords'].astype(np.int32)), tag + ' vox_coords'
+    assert (n(item['vox_coords'][:, 0]) == 0).all()
+    for k in ('vox2point', 'point2vox', 'vox_segments', 'seg2vox', 'seg2point'):
+        got = n(item[k])
+        assert got.dtype == np.int64 and np.array_equal(got, want[k]), tag + ' ' + k
+    assert np.array_equal(n(item['vox_features']), want['vox_features'].astype(np.float32)), tag + ' features'
+    assert np.array_equal(n(prepare.vox_world_coords(item)), want['vox_world_coords']), tag + ' world coords'
+    loc = n(item['input_location'])
+    assert np.allclose(loc, want['input_location'], rtol=1e-12, atol=1e-12), tag + ' centroids'
+    assert np.array_equal(loc.astype(np.float32), want['input_location'].astype(np.float32)), tag + ' centroids f32'
+
+
+def test_voxelize_matches_reference_golden(gold):
+    from box2mask_amd import prepare
+    for i in range(int(gold['n_scenes'])):
+        sc, vs = _scene(gold, i)
+        item = prepare.voxelize_scene(sc, vs)
+        want = {k: gold['s%d_%s' % (i, k)] for k in ('vox_coords', 'vox2point', 'point2vox', 'vox_segments',
+                                                      'vox_features', 'vox_world_coords', 'seg2vox', 'seg2point',
+                                                      'input_location')}
+        _check_item(item, want, 'scene %d' % i)
+
+
+def test_collate_matches_reference_golden(gold):
+    from box2mask_amd import prepare
+    items = [prepare.voxelize_scene(*_scene(gold, i)) for i in (0, 1)]
+    b = prepare.collate(items, 'test')
+    for k in ('vox_features', 'batch_ids', 'input_location', 'pooling_ids'):
+        got = b[k].cpu().numpy()
+        want = gold['collate_%s' % k]
+        assert got.dtype == want.dtype and np.array_equal(got, want), k
+    n0 = items[0]['vox_coords'].shape[0]
+    c = b['vox_coords'].cpu().numpy()
+    assert c.dtype == np.int32 and (c[:n0, 0] == 0).all() and (c[n0:, 0] == 1).all()
+    assert np.array_equal(c[:n0, 1:], gold['s0_vox_coords'].astype(np.int32))
+    assert np.array_equal(c[n0:, 1:], gold['s1_vox_coords'].astype(np.int32))
+
+
+@pytest.mark.parametrize('seed,target,vs', [(3, 20000, 0.02), (4, 40000, 0.04)])
+def test_voxelize_matches_oracle(seed, target, vs):
+    from box2mask_amd import prepare, synth
+    from oracle import prepare_ref as R
+    sc = synth.make_scene(seed, target_voxels=target, points_only=True, pts_per_m2=8000.0)
+    sc['positions'] = sc['positions'] - 0.83            # negative coordinates: exercises the shift
+    want = R.voxelize_scene(sc['positions'], sc['colors'], sc['normals'], sc['segments'], vs)
+    _check_item(prepare.voxelize_scene(sc, vs), want, 'seed %d' % seed)
+
+
+def test_edge_cases():
+    """One point; exact duplicates (lowest index wins); half-way coordinates (np.round is half-to-even); points of a
+    neighbouring cell closer to a centre than the cell's own point."""
+    from box2mask_amd import prepare
+    from oracle import prepare_ref as R
+    one = {'positions': np.array([[0.3, 0.1, 0.2]]), 'colors': np.ones((1, 3)), 'normals': np.ones((1, 3)),
+           'segments': np.array([4])}
+    it = prepare.voxelize_scene(one, 0.02)
+    assert it['vox_coords'].shape == (1, 4) and it['point2vox'].tolist() == [0] and it['seg2vox'].tolist() == [0]
+    vs = 0.5
+    pos = np.array([[0.25, 0.25, 0.25],      # 0.5 -> rounds to 0 (half to even)
+                    [0.75, 0.75, 0.75],      # 1.5 -> 2
+                    [1.25, 1.25, 1.25],      # 2.5 -> 2
+                    [1.25, 1.25, 1.25],      # duplicate of point 2
+                    [0.49, 0.0, 0.0],        # cell (1,0,0), at 0.98: own point, far corner side
+                    [0.26, 0.0, 0.0]])       # cell (1,0,0) as well (0.52 -> 1) but closer to centre (0,0,0)? no: 0.52
+    sc = {'positions': pos, 'colors': np.arange(18.).reshape(6, 3), 'normals': np.zeros((6, 3)),
+          'segments': np.array([1, 1, 2, 2, 3, 3])}
+    it = prepare.voxelize_scene(sc, vs)
+    want = R.voxelize_scene(pos, sc['colors'], sc['normals'], sc['segments'], vs)
+    assert np.array_equal(it['vox_coords'][:, 1:].cpu().numpy(), want['vox_coords'].astype(np.int32))
+    assert np.array_equal(it['vox2point'].cpu().numpy(), want['vox2point'])
+    ic = pos / vs
+    d = ((want['vox_coords'][:, None, :] - ic[None]) ** 2).sum(-1)
+    got = it['point2vox'].cpu().numpy()
+    assert np.array_equal(d[np.arange(len(got)), got], d.min(1))            # a nearest point
+    assert np.array_equal(got, np.argmin(d, 1))                             # and the lowest index among ties
+    with pytest.raises(ValueError):
+        prepare.voxelize_scene({'positions': np.array([[0., 0., 0.], [1e9, 0., 0.]]), 'colors': np.zeros((2, 3)),
+                                'normals': np.zeros((2, 3)), 'segments': np.array([0, 0])}, 0.02)
+
+
+@pytest.mark.parametrize('n', [2, 64, 4096, 8192, 1 << 17])
+def test_sort_u64(n):
+    from box2mask_amd import _lib
+    g = torch.Generator().manual_seed(n)
+    k = torch.randint(0, 1 << 62, (n,), generator=g, dtype=torch.int64)
+    k[: n // 3] = k[n // 3: 2 * (n // 3)][: n // 3]              # repeated keys
+    d = k.cuda()
+    _lib.call('b2m_sort_u64', d.data_ptr(), n)
+    assert torch.equal(d.cpu(), torch.sort(k)[0])
+
+
+def test_full_size_scene_properties():
+    """~150 k voxels / ~1.2 M points (BASELINE configs[1] scene): properties that do not need the oracle."""
+    from box2mask_amd import prepare, synth
+    sc = synth.make_scene(11, points_only=True)
+    vs = 0.02
+    it = prepare.voxelize_scene(sc, vs)
+    c = it['vox_coords'][:, 1:].cpu().numpy().astype(np.int64)
+    key = (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
+    assert (np.diff(key) > 0).all()                                         # sorted, unique
+    shift = min(0, sc['positions'].min())
+    vox = np.round((sc['positions'] - shift) / vs).astype(np.int64)
+    v2p = it['vox2point'].cpu().numpy()
+    assert np.array_equal(c[v2p], vox)                                       # the inverse map of np.unique
+    p2v = it['point2vox'].cpu().numpy()
+    ic = (sc['positions'] - shift) / vs
+    d_assoc = ((ic[p2v] - c) ** 2).sum(1)
+    assert d_assoc.max() <= 0.75 + 1e-9
+    first = np.full(len(c), -1, np.int64); first[v2p[::-1]] = np.arange(len(v2p))[::-1]
+    assert (d_assoc <= ((ic[first] - c) ** 2).sum(1) + 1e-15).all()         # never worse than an own point
+    s2v = it['seg2vox'].cpu().numpy()
+    assert np.array_equal(np.unique(it['vox_segments'].cpu().numpy())[s2v], it['vox_segments'].cpu().numpy())
+
+
+def test_prepared_batch_drives_the_model(gold):
+    """raw points -> device batch -> SelectionNet forward -> instance masks, nothing through the host."""
+    from box2mask_amd import prepare, synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    items = [prepare.voxelize_scene(*_scene(gold, i)) for i in (0, 1)]
+    for it in items:
+        it['scene'] = {'name': it['scene'].get('name', 'x') if isinstance(it['scene'], dict) else 'x'}
+    items[0]['scene']['name'], items[1]['scene']['name'] = 'a', 'b'
+    batch = prepare.collate(items, 'test')
+    torch.manual_seed(0)
+    model = Model(scannet_config(), *synth.scannet_tables())
+    model.eval()
+    pred = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=True)
+    assert pred['mlp_offsets'].shape == (batch['input_location'].shape[0], 3)
+    res = model.pred2mask(batch, pred, 'eval')
+    assert set(res) == {'a', 'b'}
+    for r, it in zip((res['a'], res['b']), items):
+        assert r['mask'].shape[1] == it['vox2point'].shape[0]

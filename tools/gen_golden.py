@@ -254,9 +254,74 @@ def gen_losses():
     print('losses.npz: %d arrays' % len(out))
 
 
+def gen_prepare():
+    """Scene preparation: ScanNet.__getitem__ (dataloader.py:53-123, 'test' mode) and collate_fn (:946-984) of the
+    real reference on synthetic raw scenes.  dataprocessing.{scannet,arkitscenes,s3dis} only LOAD scenes (open3d,
+    pyviz3d, ... absent here), so they are replaced by empty stand-ins whose process_scene returns the synthetic
+    scene; numpy.lib.type_check (an unused import of dataloader.py:4, gone in numpy 2) and
+    ME.utils.batched_coordinates likewise.  Everything this fixture records is computed by the reference's own
+    lines: np.round / np.unique / sklearn ball tree / the segment loop / to_unique."""
+    _install_stubs()
+    sys.modules['MinkowskiEngine'].utils = SimpleNamespace(
+        batched_coordinates=lambda c, dtype=None: synth.batched_coordinates(c))
+    tc = types.ModuleType('numpy.lib.type_check'); tc._is_type_dispatcher = None
+    sys.modules['numpy.lib.type_check'] = tc
+    dp = types.ModuleType('dataprocessing'); dp.__path__ = []
+    sys.modules['dataprocessing'] = dp
+    for n in ('scannet', 'arkitscenes', 's3dis'):
+        m = types.ModuleType('dataprocessing.' + n); sys.modules['dataprocessing.' + n] = m; setattr(dp, n, m)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import models.dataloader as D
+
+    rng = np.random.default_rng(77)
+    scenes = []
+    # 0/1: room-shaped surfaces (shifted so that coordinates go negative), 2 cm;  2: a dense blob at 5 cm with many
+    # points per voxel;  3: three points
+    for seed, tv in ((0, 9000), (1, 6000)):
+        sc = synth.make_scene(seed, target_voxels=tv, pts_per_m2=9000.0, points_only=True)
+        sc['positions'] = sc['positions'] - np.array([0.37, 1.21, 0.0]) * (seed + 1)
+        sc['voxel_size'] = 0.02
+        scenes.append(sc)
+    P = 4000
+    scenes.append({'name': 'blob', 'positions': rng.normal(0, 0.25, (P, 3)), 'colors': rng.uniform(0, 1, (P, 3)),
+                   'normals': rng.normal(size=(P, 3)), 'segments': rng.integers(3, 40, P) * 7, 'voxel_size': 0.05})
+    scenes.append({'name': 'tiny', 'positions': np.array([[0.1, 0.2, 0.3], [0.101, 0.2, 0.3], [1.0, -0.5, 0.25]]),
+                   'colors': rng.uniform(0, 1, (3, 3)), 'normals': rng.normal(size=(3, 3)),
+                   'segments': np.array([5, 5, 9]), 'voxel_size': 0.02})
+    out = {'n_scenes': np.array(len(scenes))}
+    items = []
+    for i, sc in enumerate(scenes):
+        D.scannet.process_scene = lambda name, mode, cfg, do_augmentations=False, _sc=sc: (_sc, None)
+        ds = D.ScanNet.__new__(D.ScanNet)
+        ds.cfg = SimpleNamespace(voxel_size=sc['voxel_size'], use_normals_input=True, do_segment_pooling=True)
+        ds.mode = 'test'; ds.do_augmentations = False; ds.data_list = [sc['name']]
+        ret = ds[0]
+        items.append(ret)
+        for k in ('positions', 'colors', 'normals', 'segments'):
+            out['s%d_in_%s' % (i, k)] = np.asarray(sc[k])
+        out['s%d_in_voxel_size' % i] = np.array(sc['voxel_size'])
+        for k in ('vox_coords', 'vox2point', 'point2vox', 'vox_segments', 'vox_features', 'vox_world_coords',
+                  'seg2vox', 'seg2point', 'input_location'):
+            out['s%d_%s' % (i, k)] = np.asarray(ret[k])
+    # collate of the two 2 cm scenes (one voxel size per config in the reference)
+    cf = D.collate_fn(SimpleNamespace(do_segment_pooling=True), 'test')
+    b = cf([items[0], items[1]])
+    for k in ('vox_features', 'batch_ids', 'input_location', 'pooling_ids'):
+        out['collate_%s' % k] = b[k].numpy()
+    np.savez_compressed(os.path.join(OUT, 'prepare.npz'), **out)
+    print('prepare.npz: %d arrays, %s voxels' % (len(out), [len(it['vox_coords']) for it in items]))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    gen_iou_nms()
-    gen_detection2mask()
-    gen_losses()
+    which = sys.argv[1:] or ['iou_nms', 'detection2mask', 'losses', 'prepare']
+    if 'iou_nms' in which:
+        gen_iou_nms()
+    if 'detection2mask' in which:
+        gen_detection2mask()
+    if 'losses' in which:
+        gen_losses()
+    if 'prepare' in which:
+        gen_prepare()
