@@ -81,6 +81,7 @@ def main():
     ap.add_argument('--detail', type=int, default=0, help='1 prints a per-layer-shape table of the conv launches to stderr')
     ap.add_argument('--cpu-timeout', type=int, default=240, help='seconds after which the CPU baseline is abandoned')
     ap.add_argument('--votes', type=int, default=1, help='0 skips the votes -> instance masks leg (outside the timed steps)')
+    ap.add_argument('--prepare', type=int, default=1, help='0 skips the raw points -> device batch leg (outside the timed steps)')
     args = ap.parse_args()
 
     # The CPU baseline runs FIRST, before this process touches the GPU (pure torch-CPU oracle, rank 0, N=1 only).
@@ -221,6 +222,10 @@ def main():
     if args.votes:
         result['votes_to_masks'] = votes_leg(model, batch, cfg, cpu=bool(args.cpu_baseline) and world == 1)
 
+    # ---- raw scene points -> voxelised, collated device batch (what feeds the step above)
+    if args.prepare:
+        result['prepare'] = prepare_leg(dev, args.target_voxels, cpu=bool(args.cpu_baseline) and world == 1)
+
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
     if cpu_result is not None:
         result['cpu_baseline'] = cpu_result
@@ -283,6 +288,54 @@ def votes_leg(model, batch, cfg, cpu):
                                          'against the reference on tests/golden): %.2f s' % cdt,
                                'identical_to_gpu_result': bool(same)}
     model.train()
+    return out
+
+
+def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
+    """Dataset item + collate (dataloader.py:61-123, 946-984) of `n_scenes` synthetic raw scenes (~1.2 M points,
+    ~150 k voxels each) with the points already resident in HBM; with `cpu`, scene 0 also runs on the CPU oracle
+    (numpy + the reference's sklearn ball tree; bit-exact against the reference on tests/golden) and is compared."""
+    from box2mask_amd import prepare, synth
+    raw = [synth.make_scene(100 + s, target_voxels=target_voxels, points_only=True) for s in range(n_scenes)]
+    scenes = [{k: (torch.as_tensor(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in sc.items()} for sc in raw]
+    torch.cuda.synchronize()
+
+    def run():
+        items = [prepare.voxelize_scene(sc, 0.02) for sc in scenes]
+        return items, prepare.collate(items, 'test')
+    run()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        items, batch = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    pts = sum(int(sc['positions'].shape[0]) for sc in raw)
+    nvox = int(batch['vox_coords'].shape[0])
+    # bytes every correct implementation moves per scene: positions (24 B/pt) read by the key pass and by the two
+    # association passes, keys + slots + inverse written (8+4+8 B/pt), colours/normals/segment gathered per voxel
+    # (56 B) and the voxel rows / features / maps written (16+24+8+8+4 B)
+    algo = pts * (3 * 24 + 20) + nvox * (56 + 60)
+    out = {'value': round(n_scenes / dt, 2), 'unit': 'scenes/s', 'ms_per_scene': round(dt / n_scenes * 1e3, 3),
+           'points': pts, 'voxels': nvox, 'points_per_s': round(pts / dt, 1),
+           'roofline': {'bound': 'hbm', 'achieved': round(algo / dt / 1e9, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(algo / dt / 1e9 / PEAK_HBM_GBS, 4), 'traffic': None,
+                        'note': 'whole leg incl. 2 host syncs per scene (voxel and segment counts)'}}
+    if cpu:
+        from oracle import prepare_ref
+        sc = raw[0]
+        t0 = time.perf_counter()
+        ref = prepare_ref.voxelize_scene(sc['positions'], sc['colors'], sc['normals'], sc['segments'], 0.02)
+        cdt = time.perf_counter() - t0
+        it = items[0]
+        same = all(np.array_equal(it[k].cpu().numpy(), ref[k]) for k in ('vox2point', 'point2vox', 'seg2vox')) and \
+            np.array_equal(it['vox_coords'][:, 1:].cpu().numpy(), ref['vox_coords'].astype(np.int32)) and \
+            np.array_equal(it['vox_features'].cpu().numpy(), ref['vox_features'].astype(np.float32))
+        out['cpu_baseline'] = {'value': round(1.0 / cdt, 3), 'unit': 'scenes/s', 'cores': 1, 'kind': 'port',
+                               'sample': 'scene 0 (%d points) on oracle/prepare_ref.py (numpy + sklearn ball tree as '
+                                         'dataloader.py:61-123): %.2f s' % (len(sc['positions']), cdt),
+                               'identical_to_gpu_result': bool(same)}
     return out
 
 
