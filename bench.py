@@ -292,7 +292,7 @@ def votes_leg(model, batch, cfg, cpu):
 
 
 def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
-    """Dataset item + collate (dataloader.py:61-123, 946-984) of `n_scenes` synthetic raw scenes (~1.2 M points,
+    """Dataset item incl. weak box supervision + collate (dataloader.py:61-314, 946-995) of `n_scenes` synthetic raw scenes (~1.2 M points,
     ~150 k voxels each) with the points already resident in HBM; with `cpu`, scene 0 also runs on the CPU oracle
     (numpy + the reference's sklearn ball tree; bit-exact against the reference on tests/golden) and is compared."""
     from box2mask_amd import prepare, synth
@@ -300,9 +300,12 @@ def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
     scenes = [{k: (torch.as_tensor(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in sc.items()} for sc in raw]
     torch.cuda.synchronize()
 
+    from types import SimpleNamespace
+    sup = SimpleNamespace(smallest_bb_heuristic=True)           # configs/scannet.txt: bb_supervision, smallest_bb_heuristic
+
     def run():
-        items = [prepare.voxelize_scene(sc, 0.02) for sc in scenes]
-        return items, prepare.collate(items, 'test')
+        items = [prepare.box_supervision(prepare.voxelize_scene(sc, 0.02), sc['labels'], sup) for sc in scenes]
+        return items, prepare.collate(items, 'train')
     run()
     torch.cuda.synchronize()
     reps = 3
@@ -327,14 +330,17 @@ def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
         sc = raw[0]
         t0 = time.perf_counter()
         ref = prepare_ref.voxelize_scene(sc['positions'], sc['colors'], sc['normals'], sc['segments'], 0.02)
+        ipp, ips = prepare_ref.approx_association(sc['positions'], sc['segments'], sc['labels'],
+                                                  ref['unique_vox_segments'], True)
         cdt = time.perf_counter() - t0
         it = items[0]
-        same = all(np.array_equal(it[k].cpu().numpy(), ref[k]) for k in ('vox2point', 'point2vox', 'seg2vox')) and \
+        same = np.array_equal(it['pseudo_inst'][1].cpu().numpy(), ips) and all(np.array_equal(it[k].cpu().numpy(), ref[k]) for k in ('vox2point', 'point2vox', 'seg2vox')) and \
             np.array_equal(it['vox_coords'][:, 1:].cpu().numpy(), ref['vox_coords'].astype(np.int32)) and \
             np.array_equal(it['vox_features'].cpu().numpy(), ref['vox_features'].astype(np.float32))
         out['cpu_baseline'] = {'value': round(1.0 / cdt, 3), 'unit': 'scenes/s', 'cores': 1, 'kind': 'port',
                                'sample': 'scene 0 (%d points) on oracle/prepare_ref.py (numpy + sklearn ball tree as '
-                                         'dataloader.py:61-123): %.2f s' % (len(sc['positions']), cdt),
+                                         'dataloader.py:61-123, vectorised box association :203-314): %.2f s'
+                                         % (len(sc['positions']), cdt),
                                'identical_to_gpu_result': bool(same)}
     return out
 

@@ -59,6 +59,8 @@ PROTOTYPES = {
     'b2m_vox_nearest': [P, I64, P, F64, P, P, I64, I64, P, P, P],
     'b2m_vox_gather': [P, I64, P, P, P, P, P, P],
     'b2m_seg_centroid': [P, P, I64, I64, F64, P, P, P, P, P],
+    'b2m_box_membership': [P, I64, P, P, P, I32, P, P, P, P],
+    'b2m_seg_box_vote': [P, I64, P, P, I64, I64, P, P, P, P, I32, P, P, P, P, P],
 }
 PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_device_ok': (C.c_int, []),
          'b2m_weight_pack_size': (C.c_int64, [I32, I32, I32]),

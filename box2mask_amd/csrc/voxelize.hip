@@ -348,3 +348,106 @@ extern "C" int b2m_seg_centroid(const int32_t* coords, const int64_t* seg2vox, i
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
+
+// ------------------------------------------------------------------ box supervision: points -> boxes -> segments
+// approx_association of /root/reference/models/dataloader.py:203-314 (segment branch, the ScanNet configuration):
+// the reference builds a boxes x points occupancy matrix and walks points and segments in Python.
+#define BOX_MAX 1024
+__global__ void box_membership_kernel(const double* __restrict__ pos, int64_t n, const double* __restrict__ bb_min,
+                                      const double* __restrict__ bb_max, const float* __restrict__ bb_volume,
+                                      int32_t nb, int32_t* __restrict__ count, int32_t* __restrict__ first_bb,
+                                      int32_t* __restrict__ smallest_bb) {
+    __shared__ double lo[BOX_MAX * 3], hi[BOX_MAX * 3];
+    __shared__ float vol[BOX_MAX];
+    for (int e = threadIdx.x; e < nb * 3; e += blockDim.x) { lo[e] = bb_min[e]; hi[e] = bb_max[e]; }
+    for (int e = threadIdx.x; e < nb; e += blockDim.x) vol[e] = bb_volume[e];
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+    int c = 0, first = -1, small = -1;
+    float sv = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        // is_within_bb_np (utils/util.py:91-92): closed intervals on every axis
+        const bool in = x >= lo[3 * b] && y >= lo[3 * b + 1] && z >= lo[3 * b + 2] && x <= hi[3 * b] &&
+                        y <= hi[3 * b + 1] && z <= hi[3 * b + 2];
+        if (in) {
+            if (c == 0) first = b;
+            if (c == 0 || vol[b] < sv) { small = b; sv = vol[b]; }      // np.argmin: first of the smallest
+            ++c;
+        }
+    }
+    count[p] = c; first_bb[p] = first; smallest_bb[p] = small;
+}
+
+extern "C" int b2m_box_membership(const double* pos, int64_t n_pts, const double* bb_min, const double* bb_max,
+                                  const float* bb_volume, int32_t n_boxes, int32_t* count, int32_t* first_bb,
+                                  int32_t* smallest_bb, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(pos && count && first_bb && smallest_bb && n_pts >= 0, "bad arguments");
+    B2M_CHECK_ARG(n_boxes >= 0 && n_boxes <= BOX_MAX && (n_boxes == 0 || (bb_min && bb_max && bb_volume)),
+                  "0 <= n_boxes <= 1024");
+    if (n_pts > 0)
+        box_membership_kernel<<<(unsigned)cdiv64(n_pts, 256), 256, 0, st>>>(pos, n_pts, bb_min, bb_max, bb_volume, n_boxes,
+                                                                            count, first_bb, smallest_bb);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// per segment: lexicographic minimum of (number of boxes, point index) over its points
+__global__ void seg_vote_kernel(const int64_t* __restrict__ segments, int64_t n, const uint64_t* __restrict__ tkeys,
+                                const int32_t* __restrict__ tvals, int64_t mask, const int32_t* __restrict__ count,
+                                unsigned long long* __restrict__ best, int32_t* __restrict__ seg_of_point) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t s = b2m_find(tkeys, mask, (uint64_t)segments[p]);
+    const int32_t r = s < 0 ? -1 : tvals[s];        // segments that lost all their voxels are not in the table
+    seg_of_point[p] = r;
+    if (r >= 0) atomicMin(&best[r], ((unsigned long long)(uint32_t)count[p] << 32) | (unsigned long long)(uint32_t)p);
+}
+__global__ void seg_assign_kernel(const unsigned long long* __restrict__ best, int64_t n_seg,
+                                  const int32_t* __restrict__ first_bb, const int32_t* __restrict__ smallest_bb,
+                                  const int64_t* __restrict__ instance_ids, int32_t heuristic,
+                                  int64_t* __restrict__ inst_per_seg) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const unsigned long long b = best[s];
+    int64_t inst = -2;                               // unknown (dataloader.py:279)
+    if (b != ~0ull) {
+        const uint32_t c = (uint32_t)(b >> 32), p = (uint32_t)b;
+        if (c == 0) inst = -1;                       // a point outside every box: background (:292-294)
+        else if (c == 1) inst = instance_ids[first_bb[p]];           // (:283-290)
+        else if (heuristic) inst = instance_ids[smallest_bb[p]];     // smallest box of the least-covered point (:298-309)
+    }
+    inst_per_seg[s] = inst;
+}
+__global__ void seg_broadcast_kernel(const int32_t* __restrict__ seg_of_point, int64_t n,
+                                     const int64_t* __restrict__ inst_per_seg, int64_t* __restrict__ inst_per_point) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t r = seg_of_point[p];
+    inst_per_point[p] = r < 0 ? -2 : inst_per_seg[r];
+}
+
+extern "C" int b2m_seg_box_vote(const int64_t* segments, int64_t n_pts, const uint64_t* tkeys, const int32_t* tvals,
+                                int64_t cap, int64_t n_seg, const int32_t* count, const int32_t* first_bb,
+                                const int32_t* smallest_bb, const int64_t* instance_ids, int32_t smallest_bb_heuristic,
+                                uint64_t* best, int32_t* seg_of_point, int64_t* inst_per_seg, int64_t* inst_per_point,
+                                void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(segments && tkeys && tvals && count && first_bb && smallest_bb && best && seg_of_point &&
+                  inst_per_seg && inst_per_point && pow2(cap) && n_pts >= 0 && n_pts < (1ll << 32) && n_seg >= 0,
+                  "bad arguments");
+    B2M_HIP(hipMemsetAsync(best, 0xFF, (size_t)n_seg * sizeof(uint64_t), st));
+    if (n_pts > 0)
+        seg_vote_kernel<<<(unsigned)cdiv64(n_pts, 256), 256, 0, st>>>(segments, n_pts, tkeys, tvals, cap - 1, count,
+                                                                      (unsigned long long*)best, seg_of_point);
+    if (n_seg > 0)
+        seg_assign_kernel<<<(unsigned)cdiv64(n_seg, 256), 256, 0, st>>>((const unsigned long long*)best, n_seg, first_bb,
+                                                                        smallest_bb, instance_ids, smallest_bb_heuristic,
+                                                                        inst_per_seg);
+    if (n_pts > 0)
+        seg_broadcast_kernel<<<(unsigned)cdiv64(n_pts, 256), 256, 0, st>>>(seg_of_point, n_pts, inst_per_seg, inst_per_point);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}

@@ -89,7 +89,7 @@ def voxelize_scene(scene: dict, voxel_size: float, use_normals_input: bool = Tru
     # ---- segments (dataloader.py:106-120)
     if int(segments.min().item()) < 0:
         raise ValueError('voxelize_scene: negative segment ids')
-    useg, S, seg2vox, _, _, _ = _unique_inverse(vox_segments)
+    useg, S, seg2vox, seg_tkeys, seg_tvals, seg_cap = _unique_inverse(vox_segments)
     sums = torch.empty(3 * S, dtype=torch.int64, device=dev)
     counts = torch.empty(S, dtype=torch.int32, device=dev)
     middle = torch.empty((S, 3), dtype=torch.float64, device=dev)
@@ -101,12 +101,81 @@ def voxelize_scene(scene: dict, voxel_size: float, use_normals_input: bool = Tru
         'vox_segments': vox_segments, 'vox_features': feats, 'seg2vox': seg2vox, 'seg2point': seg2point,
         'pred2point': seg2point, 'input_location': middle, 'unique_vox_segments': useg[:S],
         'voxel_shift': shift, 'voxel_size': float(voxel_size),
+        '_device_scene': {'positions': pos, 'segments': segments}, '_segment_table': (seg_tkeys, seg_tvals, seg_cap),
     }
 
 
 def vox_world_coords(item: dict) -> torch.Tensor:
     """ret['vox_world_coords'] of dataloader.py:94: voxel centres in the scene's world frame (fp64)."""
     return item['vox_coords'][:, 1:].double() * item['voxel_size'] + item['voxel_shift']
+
+
+def box_supervision(item: dict, labels: dict, cfg) -> dict:
+    """``bbs_supervision`` + ``approx_association`` of the dataset class (dataloader.py:165-314) for the ScanNet
+    configuration (do_segment_pooling, no point_association / majority_vote): weak box labels -> per-segment
+    instance, box and semantic targets.  Adds the reference's keys to ``item`` and returns it.
+
+    labels: 'per_instance_semantics' (I,), 'per_instance_bb_centers' (I,3) f32, 'per_instance_bb_bounds' (I,3) f32,
+    'unique_instances' (I,), 'seg2inst' (max segment id + 1,) -- dataprocessing/scannet.py:432-436."""
+    if getattr(cfg, 'point_association', False) or getattr(cfg, 'majority_vote', False):
+        raise NotImplementedError('only the segment association of configs/scannet.txt is on the device')
+    pos, segments = item['_device_scene']['positions'], item['_device_scene']['segments']
+    dev = pos.device
+    P = pos.shape[0]
+    scene = item['scene']
+    name = scene['name'] if isinstance(scene, dict) else str(scene)
+    # ---- boxes of the foreground instances (:206-233); a handful of rows, prepared on the host like the reference
+    semantics = np.asarray(labels['per_instance_semantics'])
+    scene_fg = (semantics > 2) & (semantics != 22)
+    if getattr(cfg, 'dropout_boxes', None):
+        rng = np.random.default_rng(seed=abs(int(name, 36)))
+        scene_fg[scene_fg] = rng.binomial(1, 1 - cfg.dropout_boxes, scene_fg.sum()) != 0
+    centers = np.asarray(labels['per_instance_bb_centers'])[scene_fg]
+    bounds = np.asarray(labels['per_instance_bb_bounds'])[scene_fg] + 0.005
+    min_corner, max_corner = centers - bounds, centers + bounds
+    instance_ids = np.asarray(labels['unique_instances'])[scene_fg]
+    if getattr(cfg, 'noisy_boxes', None):
+        rng = np.random.default_rng(seed=abs(int(name, 36)))
+        min_corner = min_corner + rng.normal(loc=0, scale=cfg.noisy_boxes / 2, size=min_corner.shape)
+        max_corner = max_corner + rng.normal(loc=0, scale=cfg.noisy_boxes / 2, size=max_corner.shape)
+        item['noisy_bbs'] = min_corner, max_corner
+    bb_volume = np.prod(2 * bounds, axis=1)
+    B = len(instance_ids)
+    d_min, d_max = _dev(min_corner.reshape(-1, 3), torch.float64, dev), _dev(max_corner.reshape(-1, 3), torch.float64, dev)
+    d_vol = _dev(bb_volume.reshape(-1), torch.float32, dev)
+    d_ids = _dev(instance_ids.reshape(-1), torch.int64, dev)
+    count = torch.empty(P, dtype=torch.int32, device=dev)
+    first_bb, smallest_bb = torch.empty_like(count), torch.empty_like(count)
+    _lib.call('b2m_box_membership', ptr(pos), P, ptr(d_min) if B else None, ptr(d_max) if B else None,
+              ptr(d_vol) if B else None, B, ptr(count), ptr(first_bb), ptr(smallest_bb))
+    tkeys, tvals, cap = item['_segment_table']
+    S = item['input_location'].shape[0]
+    best = torch.empty(S, dtype=torch.int64, device=dev)
+    seg_of_point = torch.empty(P, dtype=torch.int32, device=dev)
+    inst_per_seg = torch.empty(S, dtype=torch.int64, device=dev)
+    inst_per_point = torch.empty(P, dtype=torch.int64, device=dev)
+    _lib.call('b2m_seg_box_vote', ptr(segments), P, ptr(tkeys), ptr(tvals), cap, S, ptr(count), ptr(first_bb),
+              ptr(smallest_bb), ptr(d_ids) if B else None, 1 if getattr(cfg, 'smallest_bb_heuristic', False) else 0,
+              ptr(best), ptr(seg_of_point), ptr(inst_per_seg), ptr(inst_per_point))
+    item['pseudo_inst'] = inst_per_point, inst_per_seg
+    # ---- per-segment targets (:176-200): gathers over a few thousand rows
+    instances = inst_per_seg
+    seg2inst = _dev(np.asarray(labels['seg2inst']), torch.int64, dev)
+    per_sem = _dev(semantics, torch.int64, dev)
+    gt_full_sem = per_sem[seg2inst[item['unique_vox_segments']]]
+    fg = instances > -1
+    safe = instances.clamp_min(0)
+    per_bounds = _dev(np.asarray(labels['per_instance_bb_bounds']), torch.float64, dev)
+    per_centers = _dev(np.asarray(labels['per_instance_bb_centers']), torch.float64, dev)
+    fgc = fg[:, None].to(torch.float64)
+    item['fg_instances'] = fg
+    item['gt_bb_bounds'] = per_bounds[safe] * fgc
+    item['gt_bb_offsets'] = per_centers[safe] * fgc - item['input_location'] * fgc
+    sem = torch.where(fg, per_sem[safe], torch.zeros_like(safe))
+    sem = torch.where(instances == -1, torch.full_like(sem, 2), sem)
+    item['gt_semantics'] = torch.where(gt_full_sem == 0, torch.zeros_like(sem), sem)
+    item['labels'] = labels
+    return item
 
 
 _GT_KEYS = (('gt_bb_bounds', torch.float32), ('gt_bb_offsets', torch.float32), ('gt_semantics', torch.int64),

@@ -120,8 +120,24 @@ def make_scene(seed: int, target_voxels: int = 150_000, voxel_size: float = 0.02
     colors = rng.normal(0.0, 1.0, (len(positions), 3))
     _, segments = np.unique(seg_key, return_inverse=True)   # dense per-scene segment ids
     if points_only:     # the raw scene, as dataprocessing/scannet.py hands it to the dataset class (float64)
+        segments = segments.reshape(-1).astype(np.int64)
+        # labels in the layout of dataprocessing/scannet.py:432-436: furniture boxes are instances 0..B-1, floor
+        # and walls follow as instances of their own (semantics 2 / 1)
+        B = len(boxes)
+        inst = np.where(pt_inst >= 0, pt_inst, B + (pt_sem == 1))
+        seg2inst = np.zeros(int(segments.max()) + 1, np.int32)
+        seg2inst[segments] = inst
+        labels = {
+            'unique_instances': np.arange(B + 2),
+            'per_instance_semantics': np.array([b[2] for b in boxes] + [2, 1], np.int32),
+            'per_instance_bb_centers': np.array([b[0] for b in boxes] + [[L / 2, W / 2, 0.0], [L / 2, W / 2, H / 2]],
+                                                np.float32),
+            'per_instance_bb_bounds': np.array([b[1] for b in boxes] + [[L / 2, W / 2, 0.01], [L / 2, W / 2, H / 2]],
+                                               np.float32),
+            'seg2inst': seg2inst,
+        }
         return {'name': name or ('synth%04d' % seed), 'positions': positions, 'colors': colors,
-                'normals': normals, 'segments': segments.reshape(-1).astype(np.int64)}
+                'normals': normals, 'segments': segments, 'labels': labels}
 
     # ---- voxelisation, as /root/reference/models/dataloader.py:61-68 ----
     input_coords = positions - min(0, np.min(positions))

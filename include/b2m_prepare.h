@@ -63,6 +63,26 @@ int b2m_vox_gather(const int32_t* point2vox, int64_t n_vox, const double* colors
 int b2m_seg_centroid(const int32_t* coords, const int64_t* seg2vox, int64_t n_vox, int64_t n_seg, double voxel_size,
                      const double* shift, uint64_t* sums, int32_t* counts, double* out, void* stream);
 
+/* ---- box supervision: approx_association, dataloader.py:203-314, segment branch ---- */
+
+/* Per scene point: count[p] = number of boxes [bb_min, bb_max] (closed, (n_boxes,3) fp64 each) containing it,
+ * first_bb[p] = lowest such box index (or -1), smallest_bb[p] = the one of smallest bb_volume among them (first on
+ * ties, or -1).  Replaces the boxes x points occupancy matrix and the per-point argwhere list of :235-240.
+ * n_boxes <= 1024. */
+int b2m_box_membership(const double* pos, int64_t n_pts, const double* bb_min, const double* bb_max,
+                       const float* bb_volume, int32_t n_boxes, int32_t* count, int32_t* first_bb,
+                       int32_t* smallest_bb, void* stream);
+
+/* Segment vote of :274-309.  For every voxel-level segment (rank r in the segment table tkeys/tvals of
+ * b2m_unique_rank) the point with the lexicographically smallest (count, index) decides:
+ * count 0 -> -1 (background); 1 -> instance_ids[first_bb]; >1 -> instance_ids[smallest_bb] when
+ * smallest_bb_heuristic, else -2 (unknown).  inst_per_point[p] = the verdict of p's segment, -2 for points whose
+ * segment has no voxel.  best: uint64[n_seg] scratch, seg_of_point: int32[n_pts] scratch/out. */
+int b2m_seg_box_vote(const int64_t* segments, int64_t n_pts, const uint64_t* tkeys, const int32_t* tvals, int64_t cap,
+                     int64_t n_seg, const int32_t* count, const int32_t* first_bb, const int32_t* smallest_bb,
+                     const int64_t* instance_ids, int32_t smallest_bb_heuristic, uint64_t* best,
+                     int32_t* seg_of_point, int64_t* inst_per_seg, int64_t* inst_per_point, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

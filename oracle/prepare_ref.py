@@ -83,3 +83,60 @@ def collate(items):
         'input_location': np.concatenate([it['input_location'] for it in items], 0).astype(np.float32),   # :980
         'pooling_ids': to_unique([it['vox_segments'] for it in items]),                                   # :981
     }
+
+
+def approx_association(positions, segments, labels, unique_segs, smallest_bb_heuristic=True):
+    """dataloader.py:203-314, segment branch (point_association = majority_vote = False, no dropout / noise).
+    Vectorised restatement of the reference's Python loops; pinned by tests/golden/prepare.npz.
+    Returns (inst_per_point (P,), inst_per_seg (S,)) with -1 background, -2 unknown."""
+    semantics = np.asarray(labels['per_instance_semantics'])
+    scene_fg = (semantics > 2) & (semantics != 22)                                   # :207-208
+    centers = np.asarray(labels['per_instance_bb_centers'])[scene_fg]                # :219
+    bounds = np.asarray(labels['per_instance_bb_bounds'])[scene_fg] + 0.005          # :221
+    min_corner, max_corner = centers - bounds, centers + bounds
+    instance_ids = np.asarray(labels['unique_instances'])[scene_fg]                  # :224
+    occ = (np.all(positions[None] >= min_corner[:, None], axis=-1) &
+           np.all(positions[None] <= max_corner[:, None], axis=-1))                  # :235 (B, P)
+    num = occ.sum(axis=0)                                                            # :239
+    bb_volume = np.prod(2 * bounds, axis=1)                                          # :240
+    segments = np.asarray(segments)
+    inst_per_point = np.full(len(positions), -2, np.int64)                           # :279
+    inst_per_seg = np.full(len(unique_segs), -2, np.int64)
+    for i, seg_id in enumerate(unique_segs):                                         # :281-296
+        idx = np.nonzero(seg_id == segments)[0]
+        n_on = num[idx]
+        m = n_on.min()
+        if m == 1:
+            p = idx[np.nonzero(n_on == 1)[0][0]]
+            inst = instance_ids[np.nonzero(occ[:, p])[0][0]]
+        elif m == 0:
+            inst = -1
+        elif smallest_bb_heuristic:                                                  # :298-309
+            p = idx[n_on.argmin()]
+            box_ids = np.nonzero(occ[:, p])[0]
+            inst = instance_ids[box_ids[np.argmin(bb_volume[box_ids])]]
+        else:
+            continue
+        inst_per_seg[i] = inst
+        inst_per_point[idx] = inst
+    return inst_per_point, inst_per_seg
+
+
+def bbs_supervision(item, labels, inst_per_seg):
+    """dataloader.py:165-200 for do_segment_pooling=True: per-segment training targets."""
+    instances = inst_per_seg
+    seg_inst = np.asarray(labels['seg2inst'])[item['unique_vox_segments']]           # :176
+    gt_full_sem = np.asarray(labels['per_instance_semantics'])[seg_inst]             # :177
+    gt_unlabeled = gt_full_sem == 0
+    fg = instances > -1                                                              # :180
+    gt_bb_bounds = np.zeros((len(fg), 3))
+    gt_bb_bounds[fg] = np.asarray(labels['per_instance_bb_bounds'])[instances[fg]]   # :184-185
+    gt_bb_centers = np.zeros((len(fg), 3))
+    gt_bb_centers[fg] = np.asarray(labels['per_instance_bb_centers'])[instances[fg]]
+    gt_bb_offsets = gt_bb_centers - (item['input_location'] * fg[:, None] + 0)       # :190
+    gt_semantics = np.zeros(len(fg), dtype=np.int64)
+    gt_semantics[fg] = np.asarray(labels['per_instance_semantics'])[instances[fg]]   # :196
+    gt_semantics[instances == -1] = 2                                                # :198
+    gt_semantics[gt_unlabeled] = 0                                                   # :200
+    return {'fg_instances': fg, 'gt_bb_bounds': gt_bb_bounds, 'gt_bb_offsets': gt_bb_offsets,
+            'gt_semantics': gt_semantics}

@@ -157,3 +157,86 @@ def test_prepared_batch_drives_the_model(gold):
     assert set(res) == {'a', 'b'}
     for r, it in zip((res['a'], res['b']), items):
         assert r['mask'].shape[1] == it['vox2point'].shape[0]
+
+
+def _labels(gold, i):
+    return {k: gold['s%d_label_%s' % (i, k)] for k in ('unique_instances', 'per_instance_semantics',
+                                                      'per_instance_bb_centers', 'per_instance_bb_bounds', 'seg2inst')}
+
+
+def test_box_supervision_matches_reference_golden(gold):
+    """approx_association + bbs_supervision (dataloader.py:165-314): instance per point / per segment bit-exact,
+    targets exact except the offsets, which carry the centroid's few-ulp difference (rtol 1e-12; equal as float32)."""
+    from types import SimpleNamespace
+    from box2mask_amd import prepare
+    cfg = SimpleNamespace(smallest_bb_heuristic=True, point_association=False, majority_vote=False,
+                          dropout_boxes=None, noisy_boxes=None)
+    items = []
+    for i in (0, 1, 2):
+        sc, vs = _scene(gold, i)
+        sc['name'] = 's%d' % i
+        it = prepare.box_supervision(prepare.voxelize_scene(sc, vs), _labels(gold, i), cfg)
+        items.append(it)
+        n = lambda t: t.cpu().numpy()
+        assert np.array_equal(n(it['pseudo_inst'][0]), gold['s%d_inst_per_point' % i]), i
+        assert np.array_equal(n(it['pseudo_inst'][1]), gold['s%d_inst_per_seg' % i]), i
+        assert np.array_equal(n(it['fg_instances']), gold['s%d_fg_instances' % i])
+        assert np.array_equal(n(it['gt_semantics']), gold['s%d_gt_semantics' % i])
+        assert np.array_equal(n(it['gt_bb_bounds']), gold['s%d_gt_bb_bounds' % i])
+        assert np.allclose(n(it['gt_bb_offsets']), gold['s%d_gt_bb_offsets' % i], rtol=1e-12, atol=1e-12)
+    b = prepare.collate(items[:2], 'train')
+    for k in ('gt_bb_bounds', 'gt_semantics', 'fg_instances'):
+        got = b[k].cpu().numpy()
+        assert got.dtype == gold['collate_%s' % k].dtype and np.array_equal(got, gold['collate_%s' % k]), k
+    assert np.allclose(b['gt_bb_offsets'].cpu().numpy(), gold['collate_gt_bb_offsets'], rtol=0, atol=1e-6)
+    assert (b['gt_bb_offsets'].cpu().numpy() != gold['collate_gt_bb_offsets']).mean() < 1e-3
+
+
+def test_box_supervision_options_match_oracle():
+    """no heuristic (-2 stays), no boxes at all, and a segment without voxels."""
+    from types import SimpleNamespace
+    from box2mask_amd import prepare, synth
+    from oracle import prepare_ref as R
+    sc = synth.make_scene(5, target_voxels=12000, points_only=True, pts_per_m2=7000.0)
+    labels = sc['labels']
+    # overlapping copies of the first boxes so that some segments sit in two boxes
+    labels = dict(labels)
+    labels['per_instance_bb_bounds'] = labels['per_instance_bb_bounds'] * np.float32(1.8)
+    for heuristic in (False, True):
+        cfg = SimpleNamespace(smallest_bb_heuristic=heuristic)
+        it = prepare.box_supervision(prepare.voxelize_scene(sc, 0.02), labels, cfg)
+        ref = R.voxelize_scene(sc['positions'], sc['colors'], sc['normals'], sc['segments'], 0.02)
+        ipp, ips = R.approx_association(sc['positions'], sc['segments'], labels, ref['unique_vox_segments'], heuristic)
+        assert np.array_equal(it['pseudo_inst'][1].cpu().numpy(), ips)
+        assert np.array_equal(it['pseudo_inst'][0].cpu().numpy(), ipp)
+        if not heuristic:
+            assert (ips == -2).any()
+        gt = R.bbs_supervision(ref, labels, ips)
+        assert np.array_equal(it['gt_semantics'].cpu().numpy(), gt['gt_semantics'])
+        assert np.array_equal(it['fg_instances'].cpu().numpy(), gt['fg_instances'])
+    empty = dict(labels)
+    empty['per_instance_semantics'] = np.zeros_like(labels['per_instance_semantics'])     # nothing is foreground
+    it = prepare.box_supervision(prepare.voxelize_scene(sc, 0.02), empty, SimpleNamespace(smallest_bb_heuristic=True))
+    assert (it['pseudo_inst'][1] == -1).all() and not it['fg_instances'].any()
+
+
+def test_prepared_training_batch_trains(gold):
+    """raw points + weak boxes -> device batch -> compute_loss -> backward."""
+    from types import SimpleNamespace
+    from box2mask_amd import prepare, synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    cfg_sup = SimpleNamespace(smallest_bb_heuristic=True)
+    items = []
+    for i in (0, 1):
+        sc, vs = _scene(gold, i)
+        sc['name'] = 's%d' % i
+        items.append(prepare.box_supervision(prepare.voxelize_scene(sc, vs), _labels(gold, i), cfg_sup))
+    batch = prepare.collate(items, 'train')
+    torch.manual_seed(0)
+    model = Model(scannet_config(), *synth.scannet_tables())
+    model.train()
+    losses = model.compute_loss(batch, 150)
+    losses['optimization_loss'].backward()
+    assert torch.isfinite(losses['optimization_loss'])
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())

@@ -55,3 +55,26 @@ def test_collate_bit_exact(gold):
     assert b['vox_coords'].dtype == np.int32 and b['vox_coords'].shape == (n0 + len(items[1]['vox_coords']), 4)
     assert np.array_equal(b['vox_coords'][:n0, 1:], items[0]['vox_coords'].astype(np.int32))
     assert (b['vox_coords'][:n0, 0] == 0).all() and (b['vox_coords'][n0:, 0] == 1).all()
+
+
+def test_box_supervision_bit_exact(gold):
+    for i in (0, 1, 2):
+        sc, vs = _scene(gold, i)
+        labels = {k: gold['s%d_label_%s' % (i, k)] for k in ('unique_instances', 'per_instance_semantics',
+                                                            'per_instance_bb_centers', 'per_instance_bb_bounds',
+                                                            'seg2inst')}
+        item = R.voxelize_scene(sc['positions'], sc['colors'], sc['normals'], sc['segments'], vs)
+        ipp, ips = R.approx_association(sc['positions'], sc['segments'], labels, item['unique_vox_segments'], True)
+        assert np.array_equal(ipp, gold['s%d_inst_per_point' % i]) and np.array_equal(ips, gold['s%d_inst_per_seg' % i])
+        assert len(set(ips.tolist())) > (3 if i < 2 else 2)   # background and several instances
+        if i == 2:                                         # overlapping boxes: the heuristic branch decided some
+            sem = labels['per_instance_semantics']; fgm = (sem > 2) & (sem != 22)
+            lo = (labels['per_instance_bb_centers'] - labels['per_instance_bb_bounds'] - 0.005)[fgm]
+            hi = (labels['per_instance_bb_centers'] + labels['per_instance_bb_bounds'] + 0.005)[fgm]
+            cnt = ((sc['positions'][None] >= lo[:, None]).all(-1) & (sc['positions'][None] <= hi[:, None]).all(-1)).sum(0)
+            multi = [s_ for s_ in item['unique_vox_segments'] if cnt[sc['segments'] == s_].min() > 1]
+            assert len(multi) > 3
+        gt = R.bbs_supervision(item, labels, ips)
+        for k, v in gt.items():
+            want = gold['s%d_%s' % (i, k)]
+            assert v.dtype == want.dtype and np.array_equal(v, want), (i, k)
