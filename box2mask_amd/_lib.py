@@ -48,6 +48,7 @@ PROTOTYPES = {
     'b2m_mask_nms': [P, I32, I64, F32, P, P, P, P],
     'b2m_label_hist': [P, I64, P, I32, P, I64, I32, P, P],
     'b2m_mask_gather': [P, I64, P, I32, P, I64, P, P],
+    'b2m_mask_hist': [P, I64, I32, P, I64, I32, P, P],
     'b2m_mask_pack': [P, I32, I64, P, I64, P],
     'b2m_set_ious': [P, P, I64, P, P],
     # include/b2m_prepare.h

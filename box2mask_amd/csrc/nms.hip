@@ -275,6 +275,50 @@ extern "C" int b2m_label_hist(const uint64_t* bits, int64_t words, const int32_t
     return B2M_OK;
 }
 
+// ------------------------------------------------------------------ full label histogram of every mask row
+// hist[r][c] = |{v in mask r : label[v] == c}|: the prediction x ground-truth-instance intersection counts of
+// assign_instances_for_scan (/root/reference/utils/eval_metric.py:316-330), all pairs in one pass over the bits.
+#define HIST_MAX 2048
+__global__ __launch_bounds__(256) void mask_hist_kernel(const uint64_t* __restrict__ bits, int64_t words,
+                                                        const int32_t* __restrict__ label, int64_t n, int n_class,
+                                                        int64_t words_per_block, int32_t* __restrict__ hist) {
+    __shared__ int h[HIST_MAX];
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < n_class; c += 256) h[c] = 0;
+    __syncthreads();
+    const int64_t w0 = (int64_t)blockIdx.y * words_per_block;
+    int64_t w1 = w0 + words_per_block;
+    if (w1 > words) w1 = words;
+    for (int64_t w = w0 + threadIdx.x; w < w1; w += 256) {
+        uint64_t m = bits[(int64_t)r * words + w];
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t v = w * 64 + b;
+            if (v < n) {
+                const int c = label[v];
+                if (c >= 0 && c < n_class) atomicAdd(&h[c], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_class; c += 256)
+        if (h[c]) atomicAdd(&hist[(int64_t)r * n_class + c], h[c]);
+}
+extern "C" int b2m_mask_hist(const uint64_t* bits, int64_t words, int32_t k, const int32_t* label, int64_t n,
+                             int32_t n_class, int32_t* hist, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(bits && label && hist && k >= 0 && k <= 65535 && n_class >= 1 && n_class <= HIST_MAX && n >= 0,
+                  "bad arguments (n_class <= 2048)");
+    if (k == 0) return B2M_OK;
+    B2M_HIP(hipMemsetAsync(hist, 0, (size_t)k * n_class * sizeof(int32_t), st));
+    if (words == 0) return B2M_OK;
+    const int64_t wpb = 2048;
+    mask_hist_kernel<<<dim3((unsigned)k, (unsigned)cdiv64(words, wpb)), 256, 0, st>>>(bits, words, label, n, n_class, wpb, hist);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 // ------------------------------------------------------------------ bit rows -> byte masks through an index
 __global__ void mask_gather_kernel(const uint64_t* __restrict__ bits, int64_t words, const int32_t* __restrict__ rows,
                                    const int64_t* __restrict__ index, int64_t n_pts, uint8_t* __restrict__ out) {

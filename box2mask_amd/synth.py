@@ -228,6 +228,18 @@ def make_batch(batch_size: int, seed0: int = 0, target_voxels: int = 150_000, mo
     return collate([make_scene(seed0 + s, target_voxels=target_voxels, **kw) for s in range(batch_size)], mode)
 
 
+def gt_instance_ids(batch, b: int) -> np.ndarray:
+    """Per-point ground-truth ids ``label*1000 + instance`` of scene b of a synthetic batch, in the layout of ScanNet's
+    gt_instance_data_txt files (what utils/eval_metric.py reads): furniture segments become instances (one per
+    distinct box), floor / walls keep their semantic label with instance 0."""
+    m = (batch['batch_ids'].cpu() == b).numpy()
+    seg_sem = batch['gt_semantics'].cpu()[m].numpy()
+    centre = (batch['input_location'].cpu()[m] + batch['gt_bb_offsets'].cpu()[m]).numpy().round(3)
+    _, inst = np.unique(np.concatenate([centre, seg_sem[:, None]], 1), axis=0, return_inverse=True)
+    seg_gt = np.where(batch['fg_instances'].cpu()[m].numpy(), seg_sem * 1000 + inst.reshape(-1) + 1, seg_sem * 1000)
+    return seg_gt[np.asarray(batch['seg2vox'][b])][np.asarray(batch['vox2point'][b])].astype(np.int64)
+
+
 def make_votes(seed: int, n_obj: int = 30, n_seg: int = 1500, sigma: float = 0.025):
     """Synthetic box votes for the clustering benchmark: ``n_seg`` segments vote for
     ``n_obj`` objects with Gaussian noise on offsets/bounds; score logits ~ N(0,2).

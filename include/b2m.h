@@ -221,6 +221,12 @@ int b2m_mask_nms(const uint64_t* bits, int32_t k, int64_t words, float th,
 int b2m_label_hist(const uint64_t* bits, int64_t words, const int32_t* rows, int32_t k, const int32_t* sem,
                    int64_t n_vox, int32_t n_class, int32_t* labels, void* stream);
 
+/* hist[r*n_class + c] = |{v < n in bit row r : label[v] == c}| for every mask row: all prediction x ground-truth
+ * intersection counts of assign_instances_for_scan, utils/eval_metric.py:316-330 (label = dense ground-truth
+ * instance index per point), in one pass.  n_class <= 2048; labels outside [0, n_class) are skipped. */
+int b2m_mask_hist(const uint64_t* bits, int64_t words, int32_t k, const int32_t* label, int64_t n, int32_t n_class,
+                  int32_t* hist, void* stream);
+
 /* Gather bits through an index (vox2point) into a byte mask: out[r*n_pts + p] = bit index[p] of row rows[r]
  * (rows NULL = identity, index NULL = identity).
  * Replaces pred_masks[:, vox2point], models/detection_net.py:469-471. */

@@ -352,10 +352,78 @@ def gen_prepare():
     print('prepare.npz: %d arrays, %s voxels' % (len(out), [len(it['vox_coords']) for it in items]))
 
 
+def gen_eval():
+    """AP evaluation: assign_instances_for_scan / evaluate_matches / compute_averages of the real
+    /root/reference/utils/eval_metric.py on synthetic predictions (noisy copies of the ground-truth instances,
+    duplicates, wrong labels, tiny masks, void regions).  np.float / np.bool (removed numpy aliases the file still
+    spells, eval_metric.py:111,139) are aliased for this run only."""
+    import tempfile
+    for a, t in (('float', float), ('bool', bool), ('int', int)):
+        if not hasattr(np, a):
+            setattr(np, a, t)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import utils.eval_metric as E
+    rng = np.random.default_rng(5)
+    valid = E.VALID_CLASS_IDS
+    out = {'n_scenes': np.array(3)}
+    matches = {}
+    for si in range(3):
+        n = 30000 + 5000 * si
+        # ground truth: contiguous index ranges as instances; labels incl. void classes 1/2, one unannotated block (0)
+        cuts = np.sort(rng.choice(np.arange(200, n - 200), 24 + si, replace=False))
+        inst_of = np.searchsorted(cuts, np.arange(n), side='right')
+        n_inst = inst_of.max() + 1
+        inst_label = rng.choice(np.concatenate([valid[:6], [1, 2]]), n_inst)
+        inst_label[0] = 0
+        gt_ids = np.where(inst_label[inst_of] == 0, 0, inst_label[inst_of] * 1000 + inst_of + 1).astype(np.int64)
+        # tiny ground-truth instance (< 100 vertices) of a valid class inside instance 3
+        tiny = np.nonzero(inst_of == 3)[0][:60]
+        gt_ids[tiny] = valid[2] * 1000 + 900
+        masks, labels, confs = [], [], []
+        for g in range(n_inst):
+            if rng.random() < 0.15:
+                continue                                        # missed instance
+            for rep in range(1 + (rng.random() < 0.2)):         # sometimes a duplicate detection
+                m = inst_of == g
+                flip = rng.random(n) < rng.choice([0.01, 0.05, 0.2, 0.45])
+                m = np.where(flip & (np.abs(np.arange(n) - np.nonzero(inst_of == g)[0].mean()) < 3000), ~m, m)
+                masks.append(m)
+                lab = inst_label[g] if rng.random() < 0.85 else rng.choice(valid[:6])
+                labels.append(lab if lab > 2 else valid[0])
+                confs.append(rng.random())
+        for _ in range(3):                                      # small and spurious detections
+            m = np.zeros(n, bool); s0 = rng.integers(0, n - 400); m[s0:s0 + rng.choice([40, 99, 100, 350])] = True
+            masks.append(m); labels.append(rng.choice(valid[:6])); confs.append(rng.random())
+        masks.append(np.zeros(n, bool)); labels.append(1); confs.append(0.9)     # label outside the benchmark
+        pred = {'conf': np.array(confs, np.float32), 'label_id': np.array(labels, np.int32), 'mask': np.stack(masks)}
+        name = 'scene%d' % si
+        with tempfile.NamedTemporaryFile('w', suffix='.txt', delete=False) as f:
+            f.write('\n'.join(str(int(v)) for v in gt_ids) + '\n')
+        gt2pred, pred2gt = E.assign_instances_for_scan(name, pred, f.name)
+        os.unlink(f.name)
+        matches[name] = {'gt': gt2pred, 'pred': pred2gt}
+        out['s%d_gt_ids' % si] = gt_ids
+        out['s%d_conf' % si] = pred['conf']; out['s%d_label_id' % si] = pred['label_id']
+        out['s%d_mask' % si] = np.packbits(pred['mask'], axis=1)
+        out['s%d_n' % si] = np.array(n)
+    ap, _ = E.evaluate_matches(matches)
+    avgs = E.compute_averages(ap)
+    out['ap'] = ap
+    out['all_ap'] = np.array([avgs['all_ap'], avgs['all_ap_50%'], avgs['all_ap_25%']])
+    out['class_ap'] = np.array([[avgs['classes'][c]['ap'], avgs['classes'][c]['ap50%'], avgs['classes'][c]['ap25%']]
+                                for c in E.CLASS_LABELS])
+    # a one-scene table as well (exercises has_gt / has_pred per class differently)
+    ap1, _ = E.evaluate_matches({'scene0': matches['scene0']})
+    out['ap_scene0'] = ap1
+    np.savez_compressed(os.path.join(OUT, 'eval_metric.npz'), **out)
+    print('eval_metric.npz: mAP %.4f  AP50 %.4f  AP25 %.4f' % tuple(out['all_ap']))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['iou_nms', 'detection2mask', 'losses', 'prepare']
+    which = sys.argv[1:] or ['iou_nms', 'detection2mask', 'losses', 'prepare', 'eval']
     if 'iou_nms' in which:
         gen_iou_nms()
     if 'detection2mask' in which:
@@ -364,3 +432,5 @@ if __name__ == '__main__':
         gen_losses()
     if 'prepare' in which:
         gen_prepare()
+    if 'eval' in which:
+        gen_eval()
