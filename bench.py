@@ -48,9 +48,9 @@ class LaunchTimer:
         s.record()
         if name == 'b2m_conv_fwd':
             # x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
-            meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12])
+            meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12], n_in=args[6])
         else:   # b2m_conv_wgrad: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
-            meta = dict(cin=args[2], cout=args[6], K=args[11], n_out=args[10], rb_cnt=args[9])
+            meta = dict(cin=args[2], cout=args[6], K=args[11], n_out=args[10], rb_cnt=args[9], n_in=args[3])
 
         def done():
             e.record()
@@ -173,8 +173,12 @@ def main():
         ms = s.elapsed_time(e)
         P = pairs_of(meta, cache, rb_lookup)
         flops = 2.0 * P * meta['cin'] * meta['cout']
-        a = agg.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
-        a['ms'] += ms; a['flops'] += flops; a['launches'] += 1
+        # bytes any implementation moves: both feature matrices once, the weights once, the pair lists
+        # once (5 B per rulebook slot; identity maps have none)
+        slots = 0 if meta['rb_cnt'] is None else meta['K'] * ((meta['n_out'] + 63) // 64) * 64
+        nbytes = 4.0 * (meta['n_in'] * meta['cin'] + meta['n_out'] * meta['cout'] + meta['K'] * meta['cin'] * meta['cout']) + 5.0 * slots
+        a = agg.setdefault(name, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
+        a['ms'] += ms; a['flops'] += flops; a['launches'] += 1; a['bytes'] += nbytes
 
     if args.detail:
         shapes = {}
@@ -186,10 +190,19 @@ def main():
         for key, d in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
             print('%-11s %4d %4d %4d %9d %6d %9.3f %8.2f' % (key + (d[2] // args.steps, d[0] / args.steps, d[1] / d[0] / 1e9 if d[0] else 0)), file=sys.stderr)
 
-    def roof(a):
+    # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py; FETCH_SIZE x2
+    # on gfx950 + WRITE_SIZE, as MI355X_MICROARCH.md prescribes); None when the file is absent
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+    except (OSError, ValueError):
+        pmc = {}
+
+    def roof(a, kernel=None):
         tf = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] > 0 else 0.0
         return {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                'traffic': pmc.get(kernel, {}).get('traffic_bytes'),
+                'algorithmic_bytes': round(a.get('bytes', 0.0) / max(a['launches'], 1)),
                 'launches_per_step': a['launches'] // max(args.steps, 1),
                 'avg_launch_ms': round(a['ms'] / max(a['launches'], 1), 4),
                 'gflop_per_step': round(a['flops'] / max(args.steps, 1) / 1e9, 2),
@@ -197,9 +210,9 @@ def main():
 
     fwd = agg.get('b2m_conv_fwd', dict(ms=0.0, flops=0.0, launches=0))
     wg = agg.get('b2m_conv_wgrad', dict(ms=0.0, flops=0.0, launches=0))
-    roofline = roof(fwd)
+    roofline = roof(fwd, 'conv_fwd_kernel')
     roofline['kernel'] = 'conv_fwd_kernel<16> (forward + data gradient)'
-    roofline_wgrad = roof(wg)
+    roofline_wgrad = roof(wg, 'conv_wgrad_kernel')
     roofline_wgrad['kernel'] = 'conv_wgrad_kernel'
 
     scenes = world * args.batch_size * args.steps

@@ -1,0 +1,44 @@
+"""Per-kernel HBM traffic of one bench step from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs,
+--kernel-trace only), corrected as MI355X_MICROARCH.md's HBM section prescribes: both counters are in KiB, and on
+gfx950 FETCH_SIZE tallies wide reads at half their bytes (x2).  The x2 is calibrated here on bn_stats_kernel, a pure
+streaming read of the tensor bn_apply_kernel writes (WRITE_SIZE is exact): the ratio is printed.
+
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN_traffic.json
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path):
+    by = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        base = r['Kernel_Name'].replace('void ', '').split('<')[0].split('(')[0]
+        by[base][0] += float(r['Counter_Value']); by[base][1] += 1
+    return by
+
+
+def main():
+    fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    out = {'_units': 'bytes per launch; fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024',
+           '_source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 '
+                      '--cpu-baseline 0 --votes 0 --prepare 0 (two passes)'}
+    cal = None
+    if 'bn_stats_kernel' in fetch and 'bn_apply_kernel' in write:
+        cal = fetch['bn_stats_kernel'][0] / max(write['bn_apply_kernel'][0], 1e-9)
+        out['_calibration'] = 'FETCH_SIZE(bn_stats: reads x once) / WRITE_SIZE(bn_apply: writes a tensor of the same ' \
+                              'size) = %.4f -> FETCH_SIZE counts half the streamed bytes, as the guide states' % cal
+    for k in sorted(fetch, key=lambda k: -fetch[k][0]):
+        f, n = fetch[k]
+        w = write.get(k, [0.0, 0])[0]
+        if f + w < 1000:
+            continue
+        out[k] = {'launches': n, 'fetch_size_raw_kib': round(f / n, 1), 'write_size_kib': round(w / n, 1),
+                  'fetch_bytes': round(2 * f * 1024 / n), 'write_bytes': round(w * 1024 / n),
+                  'traffic_bytes': round((2 * f + w) * 1024 / n)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
