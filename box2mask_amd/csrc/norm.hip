@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const f32x4 s = *(const f32x4*)(scale + cg * 4), b = *(const f32x4*)(shift + cg * 4);
     for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
         f32x4 v = *(const f32x4*)(x + r * ldx + cg * 4);
-        v = v * s + b;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_fmaf(v[u], s[u], b[u]);    // the backward recomputes this sign
         if (res) v += *(const f32x4*)(res + r * ldr + cg * 4);
         if (relu) {
 #pragma unroll
@@ -230,30 +231,40 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ x, int64_t ldx, int64_t n, int c,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int relu,
+                                                            const float* __restrict__ mscale,
+                                                            const float* __restrict__ mshift,
                                                             double* __restrict__ partial) {
     column_reduce(n, c, partial, [&](int64_t r, int cg, f32x4& a, f32x4& b) {
         f32x4 g = *(const f32x4*)(dy + r * lddy + cg * 4);
+        const f32x4 xx = *(const f32x4*)(x + r * ldx + cg * 4);
         if (relu) {
-            const f32x4 yy = *(const f32x4*)(y + r * ldy + cg * 4);
+            f32x4 yy;
+            if (y) yy = *(const f32x4*)(y + r * ldy + cg * 4);
+            else {      // no residual: the sign of the forward's fmaf(x, scale, shift), one tensor read less
+                const f32x4 ms = *(const f32x4*)(mscale + cg * 4), mb = *(const f32x4*)(mshift + cg * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yy[u] = __builtin_fmaf(xx[u], ms[u], mb[u]);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
         }
-        const f32x4 xx = *(const f32x4*)(x + r * ldx + cg * 4);
         const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
         a = g; b = g * ((xx - m) * is);
     });
 }
 extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
                                  int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd,
-                                 int32_t relu, double* partial, double* sums, float* sums_f32, void* stream) {
+                                 int32_t relu, const float* mask_scale, const float* mask_shift, double* partial,
+                                 double* sums, float* sums_f32, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(dy && x && mean && invstd && partial && sums && (!relu || y), "NULL argument");
+    B2M_CHECK_ARG(dy && x && mean && invstd && partial && sums && (!relu || y || (mask_scale && mask_shift)),
+                  "NULL argument (relu needs y, or mask_scale and mask_shift)");
     B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && (!relu || ldy % 4 == 0),
                   "c and leading dimensions must be multiples of 4");
     const int nblk = reduce_blocks(n);
     const int c4 = c / 4, nslots = 256 / c4;
     bn_bwd_reduce_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(dy, lddy, y, ldy, x, ldx, n, c,
-                                                                                   mean, invstd, relu, partial);
+                                                                                   mean, invstd, relu, y ? nullptr : mask_scale, y ? nullptr : mask_shift, partial);
     reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, sums_f32);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
@@ -266,6 +277,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, double count, int relu,
+                                                           const float* __restrict__ mscale,
+                                                           const float* __restrict__ mshift,
                                                            float* __restrict__ dx, int64_t lddx,
                                                            float* __restrict__ dres, int64_t lddres) {
     const int c4 = c >> 2;
@@ -274,6 +287,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
     if (rs >= nslots) return;
     const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
+    f32x4 msc = {0.f, 0.f, 0.f, 0.f}, msh = {0.f, 0.f, 0.f, 0.f};
+    if (mscale) { msc = *(const f32x4*)(mscale + cg * 4); msh = *(const f32x4*)(mshift + cg * 4); }
     f32x4 sg, sgx, ga;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -282,12 +297,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
     for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
         f32x4 g = *(const f32x4*)(dy + r * lddy + cg * 4);
+        const f32x4 xx = *(const f32x4*)(x + r * ldx + cg * 4);
         if (relu) {
-            const f32x4 yy = *(const f32x4*)(y + r * ldy + cg * 4);
+            f32x4 yy;
+            if (y) yy = *(const f32x4*)(y + r * ldy + cg * 4);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yy[u] = __builtin_fmaf(xx[u], msc[u], msh[u]);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
         }
-        const f32x4 xx = *(const f32x4*)(x + r * ldx + cg * 4);
         f32x4 out;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -300,17 +320,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 extern "C" int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
                                 int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd,
-                                const float* gamma, const double* sums, double count, int32_t relu, float* dx,
-                                int64_t lddx, float* dres, int64_t lddres, void* stream) {
+                                const float* gamma, const double* sums, double count, int32_t relu,
+                                const float* mask_scale, const float* mask_shift, float* dx, int64_t lddx, float* dres,
+                                int64_t lddres, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y), "NULL argument");
+    B2M_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y || (mask_scale && mask_shift)),
+                  "NULL argument (relu needs y, or mask_scale and mask_shift)");
     B2M_CHECK_ARG(c > 0 && c % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || ldy % 4 == 0) &&
                       (!dres || lddres % 4 == 0) && count >= 1,
                   "c and leading dimensions must be multiples of 4");
     if (n == 0) return B2M_OK;
     B2M_CHECK_ARG(c <= 1024, "c <= 1024");
     bn_bwd_apply_kernel<<<row_grid(n, c / 4), 256, 0, st>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, sums,
-                                                             count, relu, dx, lddx, dres, lddres);
+                                                             count, relu, y ? nullptr : mask_scale,
+                                                             y ? nullptr : mask_shift, dx, lddx, dres, lddres);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

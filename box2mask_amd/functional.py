@@ -207,14 +207,18 @@ class _BatchNorm(torch.autograd.Function):
         ctx.training, ctx.relu, ctx.count, ctx.sync = training, relu, count, sync
         ctx.has_res = residual is not None
         if training:
-            ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+            # without a fused residual the ReLU mask is the sign of fmaf(x, scale, shift): the backward recomputes it
+            # from x (which it reads anyway) instead of reading y
+            ctx.mask_from_x = bool(relu) and residual is None
+            ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, mean, invstd,
+                                  scale if ctx.mask_from_x else None, shift if ctx.mask_from_x else None)
         else:
-            ctx.save_for_backward(x, y if relu else None, gamma, scale, None)
+            ctx.save_for_backward(x, y if relu else None, gamma, scale, None, None, None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, mean, invstd, mscale, mshift = ctx.saved_tensors
         dy = _f32c(dy)
         n, c = x.shape
         dev = x.device
@@ -230,8 +234,8 @@ class _BatchNorm(torch.autograd.Function):
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         sums32 = torch.empty(2 * c, dtype=torch.float32, device=dev)
         _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
-              x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, partial.data_ptr(),
-              sums.data_ptr(), sums32.data_ptr())
+              x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _ptr(mscale), _ptr(mshift),
+              partial.data_ptr(), sums.data_ptr(), sums32.data_ptr())
         dbeta = sums32[:c]
         dgamma = sums32[c:]
         gsums, count = sums, ctx.count
@@ -241,7 +245,8 @@ class _BatchNorm(torch.autograd.Function):
             dist.all_reduce(gsums, op=dist.ReduceOp.SUM, group=group)
         _call('b2m_bn_bwd_apply', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), gsums.data_ptr(),
-              count, relu, dx.data_ptr(), dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0)
+              count, relu, _ptr(mscale), _ptr(mshift), dx.data_ptr(), dx.stride(0), _ptr(dres),
+              dres.stride(0) if dres is not None else 0)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
                 None, None, None, None, None, dres, None, None, None)
 

@@ -105,15 +105,17 @@ class GradAllReduce:
         inv = 1.0 / self.world
         for bi, b in enumerate(self.buckets):
             self._work[bi].wait()
-            flat = self._flat[bi]
-            off = 0
+            flat = self._flat[bi].mul_(inv)                     # one launch per bucket
+            views, dst, off = [], [], 0
             for p in b:
                 n = p.numel()
-                g = flat[off:off + n].reshape(p.shape) * inv
+                g = flat[off:off + n].view(p.shape)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
-                    p.grad.copy_(g)
+                    views.append(g); dst.append(p.grad)
                 off += n
+            if dst:
+                torch._foreach_copy_(dst, views)                # one launch for the whole bucket
             self._work[bi], self._flat[bi] = None, None
         self._pending = [len(b) for b in self.buckets]
