@@ -487,6 +487,7 @@ struct WgradArgs {
     int fast32;              // complete blocks and 24/32-bit addressable tensors: cheap address arithmetic
     int64_t nwg, xcd_per;    // XCD-aware workgroup order (wg_index); work item = (k fastest, block group, tile chunk)
     int nz;                  // block groups of 4 (ci,co) blocks
+    int pipe;                // software-pipelined kernel (real rulebook, fast32)
 };
 
 template <int MI, int NJ>
@@ -607,8 +608,143 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
 }
 
+// Software-pipelined variant for the common case (real rulebook, complete blocks, 32-bit addressable operands).
+// conv_wgrad_kernel above handles a slot as  list -> wait -> gathers -> wait -> 36..64 MFMAs : two exposed memory
+// round trips per ~1.2k cycles of MFMA work, MFMA pipe 54 % busy at 4 waves per SIMD.  Here the walk over the
+// non-empty slots of the chunk is flat and three stages deep: while the MFMAs of slot s run, the gathers of slot s+1
+// and the pair list of slot s+2 are in flight.  All loads are unconditional (padded pairs read row 0 and their B
+// values are zeroed by a select), so the waits are counted.
+template <int MI, int NJ>
+__global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(WgradArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t wg = wg_index(a.nwg, a.xcd_per);
+    if (wg < 0) return;
+    const int k = (int)(wg % a.K);
+    const int64_t rest = wg / a.K;
+    const int blk = (int)(rest % a.nz) * 4 + wave;
+    const int64_t chunk = rest / a.nz;
+    if (blk >= a.nmb * a.nnb) return;
+    const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
+    const int64_t ldr = a.ntiles * B2M_TILE;
+    const int64_t t0 = chunk * a.tiles_per_chunk;
+    int64_t t1 = t0 + a.tiles_per_chunk;
+    if (t1 > a.ntiles) t1 = a.ntiles;
+    const int nt = (int)(t1 - t0);                       // <= 64 tiles: lane t holds the pair count of tile t0 + t
+    const int cnt = lane < nt ? a.rb_cnt[(int64_t)k * a.ntiles + t0 + lane] : 0;
+    const uint64_t live = __ballot(cnt > 0);
+    if (live == 0) return;
+
+    // flat walk: position = (tile index ti, group g); advance() returns false past the end
+    auto groups_of = [&](int ti) { return (__builtin_amdgcn_readlane(cnt, ti) + 15) >> 4; };
+    auto advance = [&](int& ti, int& g) {
+        if (g + 1 < groups_of(ti)) { ++g; return true; }
+        const uint64_t rest_mask = ti >= 63 ? 0ull : (live >> (ti + 1));
+        if (rest_mask == 0) return false;
+        ti = ti + 1 + __builtin_ctzll(rest_mask); g = 0;
+        return true;
+    };
+    const int64_t kbase = (int64_t)k * ldr;
+    auto load_list = [&](int ti, int g, i32x4& rin, uint32_t& o4) {
+        const int64_t base = kbase + (t0 + ti) * B2M_TILE + 16 * g + 4 * q;
+        rin = *(const i32x4*)(a.rb_in + base);
+        o4 = *(const uint32_t*)(a.rb_out + base);
+    };
+    const uint32_t ldx4 = (uint32_t)a.ldx * 4u, lddy4 = (uint32_t)a.lddy * 4u;
+    const uint32_t cxb = (uint32_t)(ci0 + i) * 4u, cyb = (uint32_t)(co0 + i) * 4u;
+    auto gather = [&](int ti, const i32x4& rin, uint32_t o4, float (&av)[4][MI], float (&bv)[4][NJ], int (&ok)[4]) {
+        const uint32_t row0 = (uint32_t)((t0 + ti) * B2M_TILE);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = rin[s];
+            ok[s] = r;
+            const uint32_t bx = __umul24((uint32_t)(r < 0 ? 0 : r), ldx4) + cxb;
+            const uint32_t by = __umul24(row0 + ((o4 >> (8 * s)) & 255), lddy4) + cyb;
+            const char* px = (const char*)a.x + bx;
+            const char* py = (const char*)a.dy + by;
+#pragma unroll
+            for (int m = 0; m < MI; ++m) av[s][m] = *(const float*)(px + 64 * m);
+#pragma unroll
+            for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = *(const float*)(py + 64 * nn);
+        }
+    };
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mfma = [&](const float (&av)[4][MI], const float (&bv)[4][NJ], const int (&ok)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float bz[NJ];
+#pragma unroll
+            for (int nn = 0; nn < NJ; ++nn) bz[nn] = ok[s] >= 0 ? bv[s][nn] : 0.f;     // padded pair: contributes 0
+#pragma unroll
+            for (int m = 0; m < MI; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NJ; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][m], bz[nn], acc[m][nn], 0, 0, 0);
+        }
+    };
+
+    // prologue: slot 0 list + gathers, slot 1 list
+    int ti = __builtin_ctzll(live), g = 0;
+    i32x4 l0, l1, l2; uint32_t o0, o1, o2;
+    float PA[4][MI], PB[4][NJ], QA[4][MI], QB[4][NJ];
+    int Pok[4], Qok[4];
+    load_list(ti, g, l0, o0);
+    int ti1 = ti, g1 = g;
+    bool has1 = advance(ti1, g1);
+    load_list(has1 ? ti1 : ti, has1 ? g1 : g, l1, o1);
+    gather(ti, l0, o0, PA, PB, Pok);
+    for (;;) {
+        // P holds slot s (in flight), l1 the list of slot s+1 (in flight)
+        int ti2 = ti1, g2 = g1;
+        const bool has2 = has1 && advance(ti2, g2);
+        load_list(has2 ? ti2 : ti1, has2 ? g2 : g1, l2, o2);
+        gather(ti1, l1, o1, QA, QB, Qok);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(PA, PB, Pok);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!has1) break;
+        // Q holds slot s+1, l2 the list of slot s+2
+        int ti3 = ti2, g3 = g2;
+        const bool has3 = has2 && advance(ti3, g3);
+        load_list(has3 ? ti3 : ti2, has3 ? g3 : g2, l0, o0);
+        gather(ti2, l2, o2, PA, PB, Pok);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(QA, QB, Qok);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!has2) break;
+        // rotate: P = slot s+2, its successor's list is in l0
+        ti1 = ti3; g1 = g3; has1 = has3; l1 = l0; o1 = o0;
+    }
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NJ; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + 16 * m + 4 * q + r, co = co0 + 16 * nn + i;
+                if (ci < a.cin && co < a.cout) {
+                    const float v = acc[m][nn][r];
+                    if (v != 0.f) atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)ci * a.lddw + co], v);
+                }
+            }
+}
+
 template <int MI>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
+    if (a.pipe) {
+        switch (NJ) {
+            case 1: conv_wgrad_pipe_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
+            case 2: conv_wgrad_pipe_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
+            case 3: conv_wgrad_pipe_kernel<MI, 3><<<grid, 256, 0, st>>>(a); break;
+            default: conv_wgrad_pipe_kernel<MI, 4><<<grid, 256, 0, st>>>(a); break;
+        }
+        return;
+    }
     switch (NJ) {
         case 1: conv_wgrad_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
         case 2: conv_wgrad_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
@@ -676,6 +812,10 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     a.fast32 = (ldx >= (int64_t)a.nmb * 16 * MI && lddy >= (int64_t)a.nnb * 16 * NJ && n_out < (1 << 24) && n_in < (1 << 24) &&
                 ldx < (1 << 22) && lddy < (1 << 22) && n_out * lddy * 4 < (1ll << 32) && n_in * ldx * 4 < (1ll << 32) &&
                 env_flag("B2M_WGRAD_FAST32", 1)) ? 1 : 0;
+    // A/B on one box (tools/bench_conv.py): +8..26 % on the 32/96/128-channel layers; the 64x64 blocks of the
+    // 64-channel layers drop to 2 waves per SIMD and lose 10 %, they stay on the plain kernel
+    a.pipe = (a.fast32 && rb_in != nullptr && !(MI * NJ >= 16 && cin <= 64 && cout <= 64) &&
+              env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
     launch_wgrad(MI, NJ, grid, st, a);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
