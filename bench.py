@@ -213,7 +213,7 @@ def main():
     roofline = roof(fwd, 'conv_fwd_kernel')
     roofline['kernel'] = 'conv_fwd_kernel<16> (forward + data gradient)'
     roofline_wgrad = roof(wg, 'conv_wgrad_kernel')
-    roofline_wgrad['kernel'] = 'conv_wgrad_kernel'
+    roofline_wgrad['kernel'] = 'conv_wgrad_kernel + conv_wgrad_pipe_kernel'
 
     scenes = world * args.batch_size * args.steps
     value = scenes / elapsed

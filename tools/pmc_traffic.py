@@ -15,6 +15,8 @@ def load(path):
     by = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
         base = r['Kernel_Name'].replace('void ', '').split('<')[0].split('(')[0]
+        if base.startswith('conv_wgrad'):
+            base = 'conv_wgrad_kernel'          # plain + software-pipelined variants: one b2m_conv_wgrad entry
         by[base][0] += float(r['Counter_Value']); by[base][1] += 1
     return by
 

@@ -21,6 +21,8 @@ def main():
     for r in rows:
         name = re.sub(r'^void ', '', r['Name'])
         base = re.split(r'[<(]', name)[0]
+        if base.startswith('conv_wgrad'):
+            base = 'conv_wgrad_kernel'          # plain + software-pipelined variants: one b2m_conv_wgrad entry
         if base.startswith('at::') or base.startswith('__amd') or 'Cijk' in base:
             base = 'torch / runtime kernels'
         g = groups.setdefault(base, [0, 0.0])
