@@ -84,6 +84,7 @@ class CoordinateManager:
         self.tables = []                   # level -> (keys, vals, cap)
         self.parent, self.koff = [], []    # level l -> maps of level l rows into level l+1
         self._rb = {}
+        self._occ = False                  # level-0 occupancy bitmap: False = not built yet, None = too large
         self.dup_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.tables.append(self._build_table(c0, self.dup_count))
 
@@ -123,6 +124,22 @@ class CoordinateManager:
             self.koff.append(koff[:n])
 
     # -- kernel maps
+    OCC_MAX_BYTES = 256 << 20
+
+    def _occupancy(self):
+        """(bits, X, Y, Z) of the level-0 voxels, or None when the bounding grid is too large for a bitmap."""
+        if self._occ is False:
+            c = self.coords[0]
+            self._occ = None
+            if c.shape[0]:
+                b, x, y, z = (int(v) + 1 for v in c.amax(0).tolist())
+                words = (b * x * y * z + 63) // 64 + 1
+                if words * 8 <= self.OCC_MAX_BYTES:
+                    bits = torch.empty(words, dtype=torch.int64, device=self.device)
+                    _lib.call('b2m_occupancy', c.data_ptr(), c.shape[0], b, x, y, z, bits.data_ptr(), words)
+                    self._occ = (bits, x, y, z)
+        return self._occ
+
     def rulebook_same(self, level: int, ksize: int) -> Rulebook:
         """Stride-1 map of a cubic odd kernel on `level` (in == out coordinate set)."""
         key = ('same', level, ksize)
@@ -133,8 +150,10 @@ class CoordinateManager:
             keys, vals, cap = self.tables[level]
             K = ksize ** 3
             nbr = torch.empty((K, max(n, 1)), dtype=torch.int32, device=self.device)
+            occ = self._occupancy() if (level == 0 and ksize > 1) else None
             _lib.call('b2m_kernel_map', c.data_ptr(), n, ksize, 1 << level, keys.data_ptr(), vals.data_ptr(), cap,
-                      nbr.data_ptr(), nbr.shape[1])
+                      occ[0].data_ptr() if occ else None, occ[1] if occ else 0, occ[2] if occ else 0,
+                      occ[3] if occ else 0, nbr.data_ptr(), nbr.shape[1])
             self._rb[key] = Rulebook(nbr, K, n, n, self.keep_tables)
         return self._rb[key]
 

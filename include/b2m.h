@@ -67,10 +67,17 @@ int b2m_coords_stride(const int32_t* coords, int64_t n, int32_t ts,
 /* Stride-1 kernel map as a neighbour table: nbr[k*ld + o] = row of coords[o] + offset_k, or -1.
  * offsets: odd ksize centred, x fastest (k = (dx+h) + ks*(dy+h) + ks^2*(dz+h)), times ts.
  * Replaces [ME] kernel_map() for kernel_size 3 / 5, stride 1 — models/resnet.py:61-65,
- * models/detection_net.py:37.  ld >= n. */
+ * models/detection_net.py:37.  ld >= n.  occ/dim_*: see b2m_occupancy (NULL/0 = probe every offset). */
 int b2m_kernel_map(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts,
                    const uint64_t* keys, const int32_t* vals, int64_t cap,
+                   const uint64_t* occ, int32_t dim_x, int32_t dim_y, int32_t dim_z,
                    int32_t* nbr, int64_t ld, void* stream);
+
+/* Occupancy bitmap of a stride-1 coordinate set: bit ((b*dim_z + z)*dim_y + y)*dim_x + x.  Optional accelerator of
+ * b2m_kernel_map (occ != NULL, ts == 1): offsets whose bit is clear are answered without touching the hash table.
+ * All coordinates must lie in [0,dim_*) and b in [0,batches); words >= ceil(batches*dim_x*dim_y*dim_z / 64) + 1. */
+int b2m_occupancy(const int32_t* coords, int64_t n, int32_t batches, int32_t dim_x, int32_t dim_y, int32_t dim_z,
+                  uint64_t* bits, int64_t words, void* stream);
 
 /* k2s2 maps from (parent, koff):  child[k*ld_c + o] = fine row (table over coarse rows, used by the
  * strided convolution) and up[k*ld_f + i] = parent[i] iff koff[i]==k (table over fine rows, used by
