@@ -211,3 +211,70 @@ def test_spatial_reorder_is_invisible_at_the_boundary():
     assert pairs[True][0] == pairs[False][0]                     # same kernel map, different tiling
     assert pairs[True][1] < 0.9 * pairs[False][1]                # fewer active (tile, offset) slots
     assert pairs[True][2] < 0.95 * pairs[False][2]               # fewer 16-pair MFMA row groups
+
+
+@pytest.mark.gpu
+def test_training_trajectory_matches_oracle():
+    """Three normalised-gradient steps of the whole network (train-mode BatchNorm, all heads) on the device and on the
+    CPU oracle from the same initial weights.  Catches anything that only shows up once the weights move (stale
+    packed weights, gradient accumulation, state carried between steps).  BatchNorm over the 8 rows of the deepest
+    levels amplifies rounding noise into the gradient direction (the fp32 oracle drifts 2 % from the fp64 one in
+    three steps, and two runs of the device path -- atomics order -- differ by as much), so this is a check of the
+    loop, not of the last digits: same first loss, every later loss within 8 % of the fp64 oracle, and it trains."""
+    from box2mask_amd.detection_net import SelectionNet
+    from box2mask_amd import nn as ME
+    from oracle import unet_ref, sparse_ref
+    cfg = scannet_config()
+    valid, _, _, is_fg = synth.scannet_tables()
+    torch.manual_seed(3)
+    net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6]).cuda()
+    net.train()
+    batch = synth.make_batch(8, seed0=12, target_voxels=2000, pts_per_m2=6000.0)
+    S_ = batch['input_location'].shape[0]
+    heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    hier = sparse_ref.Hierarchy(batch['vox_coords'].numpy())
+    step_len, n_steps = 0.05, 3               # every step moves the weights by this much in total (L2)
+    torch.manual_seed(4)
+    target = None
+
+    def descend(params, grads):
+        with torch.no_grad():
+            gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads if g is not None))
+            for v, g in zip(params, grads):
+                if g is not None:
+                    v -= (step_len / gn).to(v.dtype) * g
+
+    dev = []
+    for step in range(n_steps):
+        out = net(ME.SparseTensor(batch['vox_features'], batch['vox_coords']), batch['pooling_ids'].cuda(), S_)
+        if target is None:
+            target = {h: torch.randn(out[h].F.shape) for h in heads}
+        loss = sum(((out[h].F - target[h].cuda()) ** 2).mean() for h in heads)
+        params = list(net.parameters())
+        for p in params:
+            p.grad = None
+        loss.backward()
+        descend(params, [p.grad for p in params])
+        dev.append(float(loss))
+
+    def oracle_run(dt):
+        p = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+                 else (v.to(dt) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
+        leaves = [v for v in p.values() if v.requires_grad]
+        losses = []
+        for step in range(n_steps):
+            o = unet_ref.forward(p, batch['vox_coords'].numpy(), batch['vox_features'].to(dt), batch['pooling_ids'], cfg,
+                                 training=True, hier=hier, n_segments=S_)
+            l = sum(((o[h] - target[h].to(dt)) ** 2).mean() for h in heads)
+            descend(leaves, torch.autograd.grad(l, leaves, allow_unused=True))
+            losses.append(float(l))
+        return losses
+
+    o32, o64 = oracle_run(torch.float32), oracle_run(torch.float64)
+    print('losses device', dev, 'oracle32', o32, 'oracle64', o64)
+    assert abs(dev[0] - o64[0]) <= 1e-4 * abs(o64[0])
+    assert dev[-1] < dev[0] and o64[-1] < o64[0]                 # it trains
+    assert all(x > y for x, y in zip(dev, dev[1:]))
+    for a, c in zip(dev, o64):
+        assert abs(a - c) <= 0.08 * abs(c), (dev, o32, o64)
