@@ -136,8 +136,9 @@ def box_supervision(item: dict, labels: dict, cfg) -> dict:
     instance_ids = np.asarray(labels['unique_instances'])[scene_fg]
     if getattr(cfg, 'noisy_boxes', None):
         rng = np.random.default_rng(seed=abs(int(name, 36)))
-        min_corner = min_corner + rng.normal(loc=0, scale=cfg.noisy_boxes / 2, size=min_corner.shape)
-        max_corner = max_corner + rng.normal(loc=0, scale=cfg.noisy_boxes / 2, size=max_corner.shape)
+        # in place, like the reference: the float32 corner arrays absorb the float64 noise with a rounding
+        min_corner += rng.normal(loc=0, scale=cfg.noisy_boxes / 2, size=min_corner.shape)
+        max_corner += rng.normal(loc=0, scale=cfg.noisy_boxes / 2, size=max_corner.shape)
         item['noisy_bbs'] = min_corner, max_corner
     bb_volume = np.prod(2 * bounds, axis=1)
     B = len(instance_ids)

@@ -240,3 +240,20 @@ def test_prepared_training_batch_trains(gold):
     losses['optimization_loss'].backward()
     assert torch.isfinite(losses['optimization_loss'])
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_box_supervision_dropout_and_noise_match_reference_golden(gold):
+    """cfg.dropout_boxes / cfg.noisy_boxes (dataloader.py:210-232): the random streams are seeded by the scene name,
+    so the kept boxes, the noisy corners and the resulting targets must equal the reference's."""
+    from types import SimpleNamespace
+    from box2mask_amd import prepare
+    sc, vs = _scene(gold, 1)
+    sc['name'] = str(gold['s1_name'])
+    cfg = SimpleNamespace(smallest_bb_heuristic=True, dropout_boxes=0.15, noisy_boxes=0.004)
+    it = prepare.box_supervision(prepare.voxelize_scene(sc, vs), _labels(gold, 1), cfg)
+    assert np.array_equal(it['noisy_bbs'][0], gold['s1_noisy_bbs_min'])
+    assert np.array_equal(it['noisy_bbs'][1], gold['s1_noisy_bbs_max'])
+    assert np.array_equal(it['pseudo_inst'][1].cpu().numpy(), gold['s1_noisy_inst_per_seg'])
+    assert np.array_equal(it['pseudo_inst'][0].cpu().numpy(), gold['s1_noisy_inst_per_point'])
+    for k in ('fg_instances', 'gt_bb_bounds', 'gt_semantics'):
+        assert np.array_equal(it[k].cpu().numpy(), gold['s1_noisy_%s' % k]), k

@@ -340,6 +340,21 @@ def gen_prepare():
         out['s%d_inst_per_seg' % i] = np.asarray(ret['pseudo_inst'][1])
         for k in ('fg_instances', 'gt_bb_bounds', 'gt_bb_offsets', 'gt_semantics'):
             out['s%d_%s' % (i, k)] = np.asarray(ret[k])
+    # the two randomised supervision options (seeded by the scene name, dataloader.py:210-232) on scene 1
+    sc = scenes[1]
+    D.scannet.process_scene = lambda name, mode, cfg, do_augmentations=False, _sc=sc: (_sc, _sc['labels'])
+    ds = D.ScanNet.__new__(D.ScanNet)
+    ds.cfg = SimpleNamespace(voxel_size=sc['voxel_size'], use_normals_input=True, do_segment_pooling=True,
+                             bb_supervision=True, point_association=False, majority_vote=False,
+                             smallest_bb_heuristic=True, dropout_boxes=0.15, noisy_boxes=0.004)
+    ds.mode = 'train'; ds.do_augmentations = False; ds.data_list = [sc['name']]
+    ret = ds[0]
+    out['s1_name'] = np.array(sc['name'])
+    out['s1_noisy_inst_per_seg'] = np.asarray(ret['pseudo_inst'][1])
+    out['s1_noisy_inst_per_point'] = np.asarray(ret['pseudo_inst'][0])
+    out['s1_noisy_bbs_min'], out['s1_noisy_bbs_max'] = (np.asarray(v) for v in ret['noisy_bbs'])
+    for k in ('fg_instances', 'gt_bb_bounds', 'gt_semantics'):
+        out['s1_noisy_%s' % k] = np.asarray(ret[k])
     tb = D.collate_fn(SimpleNamespace(do_segment_pooling=True), 'train')(train_items[:2])
     for k in ('gt_bb_bounds', 'gt_bb_offsets', 'gt_semantics', 'fg_instances'):
         out['collate_%s' % k] = tb[k].numpy()
