@@ -110,27 +110,37 @@ def test_network_forward_backward_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['a', 'b'])
+@pytest.mark.parametrize('case', ['a', 'b', 'c', 'd'])
 def test_losses_match_reference_golden(golden_dir, case):
     """Model.compute_loss_detection against vectors produced by the real reference
-    (Model.compute_loss_detection driven through import stand-ins, tools/gen_golden.py)."""
+    (Model.compute_loss_detection driven through import stand-ins, tools/gen_golden.py).
+    a: score loss; b: IoU loss, early epoch; c: centre-score head; d: per-voxel semantics, losses on all segments."""
     from box2mask_amd.model import Model
     g = np.load(os.path.join(golden_dir, 'losses.npz'))
-    cfg = scannet_config(use_bb_iou_loss=(case == 'b'))
+    heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
+    if case == 'c':
+        heads = heads + ['mlp_center_scores']
+    if case == 'd':
+        heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_per_vox_semantics']
+    cfg = scannet_config(use_bb_iou_loss=(case == 'b'), network_heads=heads, loss_on_fg_instances=(case != 'd'),
+                         bb_supervision=(case in 'ab'), loss_weight_center_scores=0.7,
+                         loss_weight_per_vox_semantics=0.9)
     model = Model(cfg, *synth.scannet_tables())
     pre = 'loss_%s_' % case
-    heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
     pred = {h: torch.from_numpy(g[pre + 'pred_' + h]).cuda().requires_grad_(True) for h in heads}
 
     class H:
         def __init__(self, F): self.F = F
     model.detection_model = lambda sin, ids, n=None: {h: H(v) for h, v in pred.items()}
     batch = {k: torch.from_numpy(g[pre + 'batch_' + k]) for k in
-             ('input_location', 'gt_bb_offsets', 'gt_bb_bounds', 'gt_semantics', 'fg_instances', 'pooling_ids')}
+             ('input_location', 'gt_bb_offsets', 'gt_bb_bounds', 'gt_semantics', 'fg_instances', 'pooling_ids',
+              'gt_per_vox_semantics') if pre + 'batch_' + k in g.files}
     batch['vox_features'] = torch.zeros(4, 6); batch['vox_coords'] = torch.tensor([[0, i, 0, 0] for i in range(4)], dtype=torch.int32)
     losses, _ = model.compute_loss_detection(batch, int(g[pre + 'epoch']))
     losses['optimization_loss'].backward()
-    for k in [k[len(pre):] for k in g.files if k.startswith(pre) and not any(s in k for s in ('pred_', 'grad_', 'batch_', 'epoch'))]:
+    keys = [k[len(pre):] for k in g.files if k.startswith(pre) and not any(s in k for s in ('pred_', 'grad_', 'batch_', 'epoch'))]
+    assert set(keys) == set(losses.keys()), (sorted(keys), sorted(losses.keys()))
+    for k in keys:
         v = losses[k]
         v = v.item() if hasattr(v, 'item') else float(v)
         tol = 2e-4 if 'correlation' in k or 'mIoU' in k else 2e-5

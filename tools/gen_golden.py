@@ -224,14 +224,29 @@ def gen_losses():
             return SimpleNamespace(to=lambda *_: r)
 
     out = {}
-    for case, seed, epoch in (('a', 5, 150), ('b', 9, 3)):
+    # a: score loss on; b: IoU loss on, score loss weight 0 (early epoch); c: centre-score head; d: per-voxel
+    # semantics head, losses over ALL segments (no foreground selection) -- the S3DIS-style configuration
+    for case, seed, epoch in (('a', 5, 150), ('b', 9, 3), ('c', 11, 150), ('d', 13, 150)):
         batch, pred0 = _scene_inputs(seed)
+        heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
+        rng = np.random.default_rng(100 + seed)
+        if case == 'c':
+            heads = heads + ['mlp_center_scores']
+            pred0['mlp_center_scores'] = torch.from_numpy(rng.uniform(0, 0.4, (pred0['mlp_offsets'].shape[0], 1)).astype(np.float32))
+        if case == 'd':
+            heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_per_vox_semantics']
+            del pred0['mlp_semantics']
+            nvox = batch['vox_coords'].shape[0]
+            pred0['mlp_per_vox_semantics'] = torch.from_numpy(rng.normal(0, 1, (nvox, 20)).astype(np.float32))
+            batch['gt_per_vox_semantics'] = batch['gt_semantics'][batch['pooling_ids']]
         pred = {k: v.clone().requires_grad_(True) for k, v in pred0.items()}
         cfg = SimpleNamespace(mlp_offsets='mlp_offsets', mlp_bounds='mlp_bounds', mlp_bb_scores='mlp_bb_scores',
                               mlp_center_scores='mlp_center_scores', mlp_semantics='mlp_semantics',
                               mlp_per_vox_semantics='mlp_per_vox_semantics',
-                              network_heads=['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics'],
-                              loss_on_fg_instances=True, bb_supervision=True, use_bb_iou_loss=(case == 'b'),
+                              network_heads=heads,
+                              loss_on_fg_instances=(case != 'd'), bb_supervision=(case in 'ab'),
+                              use_bb_iou_loss=(case == 'b'), loss_weight_center_scores=0.7,
+                              loss_weight_per_vox_semantics=0.9,
                               loss_weight_bb_offsets=1.0, loss_weight_bb_bounds=0.5, loss_weight_bb_iou=1.0,
                               loss_weight_bb_scores=1.0, loss_weight_semantics=1.0, min_bb_size=0.04,
                               mlp_bb_scores_start_epoch=100, mlp_center_scores_start_epoch=0)
@@ -247,8 +262,10 @@ def gen_losses():
         for k, v in pred.items():
             out['loss_%s_pred_%s' % (case, k)] = pred0[k].numpy()
             out['loss_%s_grad_%s' % (case, k)] = v.grad.numpy() if v.grad is not None else np.zeros_like(pred0[k].numpy())
-        for k in ('input_location', 'gt_bb_offsets', 'gt_bb_bounds', 'gt_semantics', 'fg_instances', 'pooling_ids'):
-            out['loss_%s_batch_%s' % (case, k)] = batch[k].numpy()
+        for k in ('input_location', 'gt_bb_offsets', 'gt_bb_bounds', 'gt_semantics', 'fg_instances', 'pooling_ids',
+                  'gt_per_vox_semantics'):
+            if k in batch:
+                out['loss_%s_batch_%s' % (case, k)] = batch[k].numpy()
         out['loss_%s_epoch' % case] = np.asarray(epoch)
     np.savez_compressed(os.path.join(OUT, 'losses.npz'), **out)
     print('losses.npz: %d arrays' % len(out))
