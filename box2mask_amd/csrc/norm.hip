@@ -2,7 +2,7 @@
 // All HBM-bound: float4 accesses, one pass per tensor, deterministic two-stage column reductions.
 #include "b2m_common.h"
 
-#define RED_MAX_BLOCKS 4096
+#define RED_MAX_BLOCKS 1280   // 256 CUs x 5 resident blocks of bn_bwd_reduce: one full round, no tail
 
 // Column reduction skeleton.  256 threads; thread -> (float4 column group cg, row slot rs).
 // F(row, cg) returns two float4 contributions (a, b); the block writes double partial sums
@@ -20,11 +20,13 @@ __device__ __forceinline__ void column_reduce(int64_t n, int c, double* __restri
     f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
     if (rs < nslots) {
         int64_t r = r0 + rs;
-        for (; r + nslots < r1; r += 2 * nslots) {      // two independent rows per iteration (memory-level parallelism)
-            f32x4 a0, b0, a1, b1;
+        for (; r + 3 * nslots < r1; r += 4 * nslots) {  // four independent rows per iteration (memory-level parallelism)
+            f32x4 a0, b0, a1, b1, a2, b2, a3, b3;
             f(r, cg, a0, b0);
             f(r + nslots, cg, a1, b1);
-            sa += a0; sb += b0; sa += a1; sb += b1;
+            f(r + 2 * nslots, cg, a2, b2);
+            f(r + 3 * nslots, cg, a3, b3);
+            sa += a0; sb += b0; sa += a1; sb += b1; sa += a2; sb += b2; sa += a3; sb += b3;
         }
         for (; r < r1; r += nslots) {
             f32x4 a, b;
