@@ -36,7 +36,7 @@ PROTOTYPES = {
     'b2m_bn_stats': [P, I64, I64, I32, P, P, P],
     'b2m_bn_finalize': [P, F64, I32, P, P, F32, F32, P, P, P, P, P, P, P],
     'b2m_bn_apply': [P, I64, I64, I32, P, P, P, I64, I32, P, I64, P],
-    'b2m_bn_bwd_reduce': [P, I64, P, I64, P, I64, I64, I32, P, P, I32, P, P, P, P, P, P],
+    'b2m_bn_bwd_reduce': [P, I64, P, I64, P, I64, I64, I32, P, P, I32, P, P, P, P, P, P, P],
     'b2m_bn_stats_finalize': [P, I64, I64, I32, P, P, P, P, F32, F32, P, P, P, P, P, P, P],
     'b2m_bn_bwd_apply': [P, I64, P, I64, P, I64, I64, I32, P, P, P, P, F64, I32, P, P, P, I64, P, I64, P],
     'b2m_relu_fwd': [P, I64, P, P],

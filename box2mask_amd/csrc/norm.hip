@@ -51,13 +51,19 @@ __device__ __forceinline__ void column_reduce(int64_t n, int c, double* __restri
 }
 // one wave per output column: lanes sum strided partials, then a fixed-order shuffle tree (deterministic)
 __global__ __launch_bounds__(64) void reduce_final_kernel(const double* __restrict__ partial, int nblk, int c2,
-                                                          double* __restrict__ out, float* __restrict__ out_f32) {
+                                                          double* __restrict__ out, float* __restrict__ out_lo,
+                                                          float* __restrict__ out_hi) {
     const int j = blockIdx.x;
     double s = 0;
     for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * c2 + j];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-    if (threadIdx.x == 0) { out[j] = s; if (out_f32) out_f32[j] = (float)s; }
+    if (threadIdx.x == 0) {
+        out[j] = s;
+        const int c = c2 >> 1;          // fp32 copies of the two halves go to two separate buffers
+        if (j < c) { if (out_lo) out_lo[j] = (float)s; }
+        else if (out_hi) out_hi[j - c] = (float)s;
+    }
 }
 static int reduce_blocks(int64_t n) {
     int64_t b = (n + 255) / 256;
@@ -83,7 +89,7 @@ extern "C" int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, d
     const int nblk = reduce_blocks(n);
     const int c4 = c / 4, nslots = 256 / c4;
     bn_stats_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(x, ldx, n, c, partial);
-    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, stats, nullptr);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, stats, nullptr, nullptr);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
                                  int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd,
                                  int32_t relu, const float* mask_scale, const float* mask_shift, double* partial,
-                                 double* sums, float* sums_f32, void* stream) {
+                                 double* sums, float* dbeta_f32, float* dgamma_f32, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(dy && x && mean && invstd && partial && sums && (!relu || y || (mask_scale && mask_shift)),
                   "NULL argument (relu needs y, or mask_scale and mask_shift)");
@@ -267,7 +273,7 @@ extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, 
     const int c4 = c / 4, nslots = 256 / c4;
     bn_bwd_reduce_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(dy, lddy, y, ldy, x, ldx, n, c,
                                                                                    mean, invstd, relu, y ? nullptr : mask_scale, y ? nullptr : mask_shift, partial);
-    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, sums_f32);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, dbeta_f32, dgamma_f32);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -109,11 +109,11 @@ class _SparseConv(torch.autograd.Function):
             wt = weight_pack(w3, True, ctx.mirror, c1, x2.shape[1])
             dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1])
         if ctx.needs_input_grad[2]:
-            dw3 = torch.zeros_like(w3)
+            dw = torch.zeros_like(weight, dtype=torch.float32)      # in the weight's own shape: adopted as .grad, not cloned
+            dw3 = dw if weight.dim() == 3 else dw.unsqueeze(0)
             wgrad_raw(x1, dy, ctx.rb_f, K, dw3, 0, c1)
             if x2 is not None:
                 wgrad_raw(x2, dy, ctx.rb_f, K, dw3, c1, x2.shape[1])
-            dw = dw3 if weight.dim() == 3 else dw3[0]
         if bias is not None and ctx.needs_input_grad[3]:
             db = dy.sum(0, keepdim=True).reshape(bias.shape)
         return dx1, dx2, dw, db, None, None, None, None
@@ -232,12 +232,12 @@ class _BatchNorm(torch.autograd.Function):
             return dx, None, None, None, None, None, None, None, (g if dres is not None else None), None, None, None
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
-        sums32 = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _ptr(mscale), _ptr(mshift),
-              partial.data_ptr(), sums.data_ptr(), sums32.data_ptr())
-        dbeta = sums32[:c]
-        dgamma = sums32[c:]
+              partial.data_ptr(), sums.data_ptr(), dbeta.data_ptr(), dgamma.data_ptr())
         gsums, count = sums, ctx.count
         group = _sync_group() if ctx.sync else None
         if group is not None:

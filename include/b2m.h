@@ -161,14 +161,15 @@ int b2m_bn_apply(const float* x, int64_t ldx, int64_t n, int32_t c, const float*
                  const float* residual, int64_t ldr, int32_t relu, float* y, int64_t ldy, void* stream);
 
 /* Backward reduction: g = dy * (relu ? y>0 : 1);  sums[0:c] = sum g (= dbeta), sums[c:2c] = sum g*xhat (= dgamma);
- * sums_f32 (2c floats, may be NULL) receives the same values rounded to fp32.
+ * dbeta_f32 / dgamma_f32 (c floats each, may be NULL) receive the two halves rounded to fp32, in two separate
+ * buffers so that the caller can hand them to autograd as parameter gradients without a copy.
  * With relu and no fused residual, y may be NULL when mask_scale / mask_shift (the scale / shift of the forward's
  * b2m_bn_apply) are given: the mask is then fmaf(x, scale, shift) > 0, bit for bit the forward's decision, and the
  * kernel reads one tensor less. */
 int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
                       int64_t n, int32_t c, const float* mean, const float* invstd, int32_t relu,
                       const float* mask_scale, const float* mask_shift, double* partial, double* sums,
-                      float* sums_f32, void* stream);
+                      float* dbeta_f32, float* dgamma_f32, void* stream);
 
 /* dx = gamma*invstd*(g - sum_g/count - xhat*sum_gxhat/count); optionally dres = g.  y / mask_* as in
  * b2m_bn_bwd_reduce. */
