@@ -317,6 +317,9 @@ __global__ __launch_bounds__(256) void rulebook_kernel(const int32_t* __restrict
     const int c = __popcll(b);
     const int64_t base = (int64_t)k * ldr + t * B2M_TILE;
     if (v >= 0) { const int p = prefix_popc(b); rb_in[base + p] = v; rb_out[base + p] = (uint8_t)lane; }
+    // the c valid pairs land in slots 0..c-1; lanes c..63 write the padding of slots c..63, so every slot of the
+    // rulebook is written exactly once and no memset of the (up to 750 MB) arrays is needed
+    if (lane >= c) { rb_in[base + lane] = -1; rb_out[base + lane] = 0; }
     if (lane == 0) {
         rb_cnt[(int64_t)k * ntiles + t] = c;
         if (pair_total && c) atomicAdd(&pair_total[k], c);
@@ -329,8 +332,6 @@ extern "C" int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n
     int64_t ntiles = cdiv64(n_out, B2M_TILE);
     if (pair_total) B2M_HIP(hipMemsetAsync(pair_total, 0, K * sizeof(int32_t), st));
     if (ntiles == 0) return B2M_OK;
-    B2M_HIP(hipMemsetAsync(rb_in, 0xFF, (size_t)K * ntiles * B2M_TILE * sizeof(int32_t), st));
-    B2M_HIP(hipMemsetAsync(rb_out, 0, (size_t)K * ntiles * B2M_TILE, st));
     rulebook_kernel<<<dim3((unsigned)ntiles, (unsigned)((K + 3) / 4)), 256, 0, st>>>(nbr, ld, K, n_out, ntiles, rb_in,
                                                                                    rb_out, rb_cnt, pair_total);
     B2M_LAUNCH_CHECK();
