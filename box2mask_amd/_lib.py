@@ -28,6 +28,7 @@ PROTOTYPES = {
     'b2m_coords_stride': [P, I64, I32, P, P, P, P, P, I64, P, C.POINTER(I64), P],
     'b2m_kernel_map': [P, I64, I32, I32, P, P, I64, P, I32, I32, I32, P, I64, P],
     'b2m_occupancy': [P, I64, I32, I32, I32, I32, P, I64, P],
+    'b2m_kernel_map_rulebook': [P, I64, I32, I32, P, P, I64, P, I32, I32, I32, P, P, P, P],
     'b2m_stride_tables': [P, P, I64, I64, P, I64, P, I64, P],
     'b2m_rulebook': [P, I64, I32, I64, P, P, P, P, P],
     'b2m_conv_fwd': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],

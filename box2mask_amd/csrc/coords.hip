@@ -338,6 +338,81 @@ extern "C" int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n
     return B2M_OK;
 }
 
+// ------------------------------------------------------------------ stride-1 kernel map straight into the rulebook
+// kernel_map_kernel + rulebook_kernel in one pass, without the K x N neighbour table in between (600 MB written
+// and read again for the 5x5x5 stem).  One wave per (tile, (dy,dz) line): lane = output row; the ksize offsets of
+// the line are probed one after the other and compacted with a ballot each.  Same probes, same order, same
+// rulebook bits as the two-step path (tests/test_gpu_coords.py).
+template <bool OCC>
+__global__ __launch_bounds__(256) void map_rulebook_kernel(const int32_t* __restrict__ coords, int64_t n, int32_t ksize,
+                                                           int32_t ts, const uint64_t* __restrict__ keys,
+                                                           const int32_t* __restrict__ vals, int64_t mask,
+                                                           const uint64_t* __restrict__ occ, OccDims d, int64_t ntiles,
+                                                           int32_t* __restrict__ rb_in, uint8_t* __restrict__ rb_out,
+                                                           int32_t* __restrict__ rb_cnt) {
+    const int64_t t = blockIdx.x;
+    const int line = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (line >= ksize * ksize) return;
+    const int lane = lane_id();
+    const int64_t o = t * B2M_TILE + lane;
+    const int h = ksize / 2;
+    const int dy = (line % ksize - h) * ts, dz = (line / ksize - h) * ts;
+    i32x4 c = {0, 0, 0, 0};
+    if (o < n) c = *(const i32x4*)(coords + o * 4);
+    const int y = c.z + dy, z = c.w + dz;
+    bool yz = o < n && (unsigned)y < 65536u && (unsigned)z < 65536u;
+    uint32_t bitsx = ~0u;
+    if (OCC) {
+        yz = yz && y < d.Y && z < d.Z;
+        if (yz) {
+            const int64_t b0 = (((int64_t)c.x * d.Z + z) * d.Y + y) * d.X + (c.y - h);
+            const int64_t bb = b0 < 0 ? 0 : b0;
+            const int sh = (int)(bb & 63);
+            uint64_t w = occ[bb >> 6] >> sh;
+            if (sh) w |= occ[(bb >> 6) + 1] << (64 - sh);
+            if (b0 < 0) w <<= (int)(-b0);
+            bitsx = (uint32_t)w;
+            for (int kx = 0; kx < ksize; ++kx) {
+                const int x = c.y - h + kx;
+                if (x < 0 || x >= d.X) bitsx &= ~(1u << kx);
+            }
+        }
+    }
+    const int64_t ldr = ntiles * B2M_TILE;
+    for (int kx = 0; kx < ksize; ++kx) {
+        const int x = c.y + (kx - h) * ts;
+        int v = -1;
+        if (yz && (unsigned)x < 65536u && ((bitsx >> kx) & 1u)) {
+            const int64_t s = b2m_find(keys, mask, b2m_pack(c.x, x, y, z));
+            if (s >= 0) v = vals[s];
+        }
+        const int k = line * ksize + kx;
+        const uint64_t b = __ballot(v >= 0);
+        const int cnt = __popcll(b);
+        const int64_t base = (int64_t)k * ldr + t * B2M_TILE;
+        if (v >= 0) { const int p = prefix_popc(b); rb_in[base + p] = v; rb_out[base + p] = (uint8_t)lane; }
+        if (lane >= cnt) { rb_in[base + lane] = -1; rb_out[base + lane] = 0; }
+        if (lane == 0) rb_cnt[(int64_t)k * ntiles + t] = cnt;
+    }
+}
+extern "C" int b2m_kernel_map_rulebook(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts, const uint64_t* keys,
+                                       const int32_t* vals, int64_t cap, const uint64_t* occ, int32_t dim_x,
+                                       int32_t dim_y, int32_t dim_z, int32_t* rb_in, uint8_t* rb_out, int32_t* rb_cnt,
+                                       void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7, "ksize must be odd (1,3,5,7)");
+    B2M_CHECK_ARG(coords && keys && vals && rb_in && rb_out && rb_cnt && is_pow2(cap), "bad arguments");
+    B2M_CHECK_ARG(occ == nullptr || (ts == 1 && dim_x > 0 && dim_y > 0 && dim_z > 0), "the occupancy bitmap is for stride 1");
+    const int64_t ntiles = cdiv64(n, B2M_TILE);
+    if (ntiles == 0) return B2M_OK;
+    const dim3 grid((unsigned)ntiles, (unsigned)((ksize * ksize + 3) / 4));
+    const OccDims d{dim_x, dim_y, dim_z};
+    if (occ) map_rulebook_kernel<true><<<grid, 256, 0, st>>>(coords, n, ksize, ts, keys, vals, cap - 1, occ, d, ntiles, rb_in, rb_out, rb_cnt);
+    else map_rulebook_kernel<false><<<grid, 256, 0, st>>>(coords, n, ksize, ts, keys, vals, cap - 1, occ, d, ntiles, rb_in, rb_out, rb_cnt);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 // ------------------------------------------------------------------ Morton keys (spatial row order)
 __device__ __forceinline__ uint64_t spread3(uint32_t v) {      // 16 bits -> every third bit
     uint64_t x = v & 0xFFFFull;

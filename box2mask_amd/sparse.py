@@ -9,6 +9,7 @@ Host-side mirror of what the reference gets from MinkowskiEngine's coordinate ma
 from __future__ import annotations
 
 import ctypes
+import os
 import itertools
 
 import torch
@@ -34,17 +35,20 @@ class Rulebook:
     """Tile rulebook of one kernel map: for every (offset k, tile of TILE output rows) the valid
     (input row, output row) pairs, compacted in output-row order (include/b2m.h: b2m_rulebook)."""
 
-    def __init__(self, nbr: torch.Tensor, K: int, n_out: int, n_in: int, keep_table: bool = False):
-        dev = nbr.device
+    def __init__(self, nbr, K: int, n_out: int, n_in: int, keep_table: bool = False, device=None):
+        """nbr: the (K, n_out) neighbour table to compact, or None when the caller fills the arrays itself
+        (b2m_kernel_map_rulebook)."""
+        dev = nbr.device if nbr is not None else device
         self.K, self.n_out, self.n_in = K, n_out, n_in
         self.ntiles = (n_out + TILE - 1) // TILE
         ldr = self.ntiles * TILE
         self.rb_in = torch.empty(max(K * ldr, 1), dtype=torch.int32, device=dev)
         self.rb_out = torch.empty(max(K * ldr, 1), dtype=torch.uint8, device=dev)
         self.rb_cnt = torch.empty(max(K * self.ntiles, 1), dtype=torch.int32, device=dev)
-        ld = nbr.shape[1] if nbr.dim() == 2 else n_out
-        _lib.call('b2m_rulebook', nbr.data_ptr(), ld, K, n_out, self.rb_in.data_ptr(), self.rb_out.data_ptr(),
-                  self.rb_cnt.data_ptr(), None)
+        if nbr is not None:
+            ld = nbr.shape[1] if nbr.dim() == 2 else n_out
+            _lib.call('b2m_rulebook', nbr.data_ptr(), ld, K, n_out, self.rb_in.data_ptr(), self.rb_out.data_ptr(),
+                      self.rb_cnt.data_ptr(), None)
         self.nbr = nbr if keep_table else None
         self._pairs = None
 
@@ -149,12 +153,20 @@ class CoordinateManager:
             n = c.shape[0]
             keys, vals, cap = self.tables[level]
             K = ksize ** 3
-            nbr = torch.empty((K, max(n, 1)), dtype=torch.int32, device=self.device)
             occ = self._occupancy() if (level == 0 and ksize > 1) else None
-            _lib.call('b2m_kernel_map', c.data_ptr(), n, ksize, 1 << level, keys.data_ptr(), vals.data_ptr(), cap,
-                      occ[0].data_ptr() if occ else None, occ[1] if occ else 0, occ[2] if occ else 0,
-                      occ[3] if occ else 0, nbr.data_ptr(), nbr.shape[1])
-            self._rb[key] = Rulebook(nbr, K, n, n, self.keep_tables)
+            occ_args = (occ[0].data_ptr(), occ[1], occ[2], occ[3]) if occ else (None, 0, 0, 0)
+            if self.keep_tables or os.environ.get('B2M_FUSED_MAP', '1') == '0':        # tests compare the neighbour table itself
+                nbr = torch.empty((K, max(n, 1)), dtype=torch.int32, device=self.device)
+                _lib.call('b2m_kernel_map', c.data_ptr(), n, ksize, 1 << level, keys.data_ptr(), vals.data_ptr(), cap,
+                          *occ_args, nbr.data_ptr(), nbr.shape[1])
+                self._rb[key] = Rulebook(nbr, K, n, n, self.keep_tables)
+            else:                       # straight into the rulebook, no K x n table
+                rb = Rulebook(None, K, n, n, device=self.device)
+                if n:
+                    _lib.call('b2m_kernel_map_rulebook', c.data_ptr(), n, ksize, 1 << level, keys.data_ptr(),
+                              vals.data_ptr(), cap, *occ_args, rb.rb_in.data_ptr(), rb.rb_out.data_ptr(),
+                              rb.rb_cnt.data_ptr())
+                self._rb[key] = rb
         return self._rb[key]
 
     def _stride_tables(self, level: int):

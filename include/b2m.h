@@ -73,6 +73,14 @@ int b2m_kernel_map(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts,
                    const uint64_t* occ, int32_t dim_x, int32_t dim_y, int32_t dim_z,
                    int32_t* nbr, int64_t ld, void* stream);
 
+/* b2m_kernel_map followed by b2m_rulebook in one pass, without the K x n neighbour table: the tile rulebook
+ * (rb_in int32[K*ntiles*64], rb_out uint8[same], rb_cnt int32[K*ntiles], ntiles = ceil(n/64)) of the stride-1
+ * kernel map of an odd cubic kernel.  Bit-identical to the two-step path. */
+int b2m_kernel_map_rulebook(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts,
+                            const uint64_t* keys, const int32_t* vals, int64_t cap,
+                            const uint64_t* occ, int32_t dim_x, int32_t dim_y, int32_t dim_z,
+                            int32_t* rb_in, uint8_t* rb_out, int32_t* rb_cnt, void* stream);
+
 /* Occupancy bitmap of a stride-1 coordinate set: bit ((b*dim_z + z)*dim_y + y)*dim_x + x.  Optional accelerator of
  * b2m_kernel_map (occ != NULL, ts == 1): offsets whose bit is clear are answered without touching the hash table.
  * All coordinates must lie in [0,dim_*) and b in [0,batches); words >= ceil(batches*dim_x*dim_y*dim_z / 64) + 1. */

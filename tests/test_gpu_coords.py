@@ -47,6 +47,13 @@ def _check(coords, levels=4, k0=5):
     for l in range(levels - 1):
         assert np.array_equal(_decode_rulebook(m.rulebook_down(l))[0], h.down(l)), 'down %d' % l
         assert np.array_equal(_decode_rulebook(m.rulebook_up(l))[0], h.up(l)), 'up %d' % l
+    # the production path (no neighbour table: probes go straight into the rulebook) must give the same bits
+    m2 = CoordinateManager(torch.from_numpy(coords), keep_tables=False)
+    for l, ks in [(l, 3) for l in range(levels)] + [(0, k0)]:
+        a, b = m.rulebook_same(l, ks), m2.rulebook_same(l, ks)
+        assert b.nbr is None
+        for f in ('rb_in', 'rb_out', 'rb_cnt'):
+            assert torch.equal(getattr(a, f), getattr(b, f)), (l, ks, f)
     return m, h
 
 
