@@ -394,6 +394,72 @@ extern "C" int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t c
     return B2M_OK;
 }
 
+// ---- all layers of a network in one launch: a plan of descriptors (built on the host once, kept on the device)
+struct PackDesc {
+    const float* w; float* wp;
+    int64_t ldw, first_block, total;
+    int32_t K, rows, cols, transpose, mirror, sb, CI, CO, KC, TW;
+};
+extern "C" int32_t b2m_weight_pack_plan_size(void) { return (int32_t)sizeof(PackDesc); }
+extern "C" int64_t b2m_weight_pack_plan(int32_t n, const int64_t* w, const int64_t* wp, const int64_t* ldw,
+                                        const int32_t* K, const int32_t* cin, const int32_t* cout,
+                                        const int32_t* transpose, const int32_t* mirror, const int32_t* slice_begin,
+                                        const int32_t* slice_count, void* plan_host) {
+    B2M_CHECK_ARG(n >= 0 && (n == 0 || (w && wp && ldw && K && cin && cout && transpose && mirror && slice_begin &&
+                                        slice_count && plan_host)), "bad arguments");
+    PackDesc* d = (PackDesc*)plan_host;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        B2M_CHECK_ARG(w[i] && wp[i] && K[i] >= 1 && cin[i] > 0 && cout[i] > 0 && ldw[i] >= cout[i], "bad layer");
+        PackDesc e;
+        e.w = (const float*)(uintptr_t)w[i]; e.wp = (float*)(uintptr_t)wp[i]; e.ldw = ldw[i];
+        e.K = K[i]; e.rows = cin[i]; e.cols = cout[i]; e.transpose = transpose[i]; e.mirror = mirror[i]; e.sb = slice_begin[i];
+        if (!transpose[i]) { e.CI = cin[i]; e.CO = cout[i]; }
+        else {
+            B2M_CHECK_ARG(slice_begin[i] >= 0 && slice_count[i] > 0 && slice_begin[i] + slice_count[i] <= cin[i], "bad channel slice");
+            e.CI = cout[i]; e.CO = slice_count[i];
+        }
+        e.KC = conv_kc(e.CI); e.TW = conv_tw(e.CO, e.K);
+        e.total = b2m_weight_pack_size(e.K, e.CI, e.CO);
+        e.first_block = blocks;
+        blocks += (e.total + 255) / 256;
+        d[i] = e;
+    }
+    return blocks;
+}
+__global__ void weight_pack_batch_kernel(const PackDesc* __restrict__ plan, int n) {
+    const int64_t blk = blockIdx.x;
+    int lo = 0, hi = n - 1;                              // last descriptor with first_block <= blk
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (plan[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = plan[lo];
+    const int64_t e = (blk - d.first_block) * 256 + threadIdx.x;
+    if (e >= d.total) return;
+    const int KS = d.KC / 4, SW = 16 * d.TW;
+    const int nchunk = (d.CI + d.KC - 1) / d.KC, nstrip = (d.CO + SW - 1) / SW;
+    const int f = (int)(e % (d.TW * KS)); const int64_t e1 = e / (d.TW * KS);
+    const int lane = (int)(e1 % 64); const int64_t b1 = e1 / 64;
+    const int chunk = (int)(b1 % nchunk); const int64_t b2 = b1 / nchunk;
+    const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
+    const int s_ = f / d.TW, t = f % d.TW, q = lane >> 4, i = lane & 15;
+    const int ci = chunk * d.KC + KS * q + s_, co = strip * SW + 16 * t + i;
+    float v = 0.f;
+    if (ci < d.CI && co < d.CO) {
+        if (!d.transpose) v = d.w[((int64_t)k * d.rows + ci) * d.ldw + co];
+        else v = d.w[((int64_t)(d.mirror ? d.K - 1 - k : k) * d.rows + d.sb + co) * d.ldw + ci];
+    }
+    d.wp[e] = v;
+}
+extern "C" int b2m_weight_pack_run(const void* plan_dev, int32_t n, int64_t total_blocks, void* stream) {
+    B2M_CHECK_ARG(n >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31) && (n == 0 || plan_dev), "bad arguments");
+    if (n == 0 || total_blocks == 0) return B2M_OK;
+    weight_pack_batch_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>((const PackDesc*)plan_dev, n);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
                             int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
                             const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,

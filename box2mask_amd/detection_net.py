@@ -11,6 +11,7 @@ from torch import nn
 
 from . import _lib
 from . import iou_nms
+from . import functional as F_
 from . import nn as ME
 from .resnet import BasicBlock, ResNetBase
 from .util import to_bbs_min_max
@@ -129,6 +130,7 @@ class SelectionNet(ResNetBase):
         (detection_net.py:234-364)."""
         cbr = self._cbr
         tr = getattr(self, '_trace', None)          # optional dict: named intermediates for parity debugging
+        F_.packed_weights.refresh()                 # one launch repacks every layer's weight images for this pass
 
         def T(name, t):
             if tr is not None:
@@ -163,7 +165,6 @@ class SelectionNet(ResNetBase):
             mode = 'max' if self.cfg.max_pool_segments_detection_net else 'avg'
             if n_segments is None:
                 n_segments = int(pooling_ids.max().item()) + 1
-            from . import functional as F_
             out = ME.PooledTensor(F_.segment_pool(out.F, pooling_ids, n_segments, mode))
         for network_head in self.cfg.network_heads:
             if self.requires_voxel_outputs and 'per_vox' in network_head:

@@ -6,6 +6,8 @@ the MinkowskiEngine operator the reference calls (file:line cited per function; 
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -22,18 +24,108 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def weight_pack(w3, transpose: bool = False, mirror: bool = False, slice_begin: int = 0, slice_count: int | None = None):
+def weight_pack(w3, transpose: bool = False, mirror: bool = False, slice_begin: int = 0, slice_count: int | None = None,
+                out=None):
     """(K,Cin,Cout) weights -> packed MFMA B-fragment image (include/b2m.h: b2m_weight_pack).
     transpose=True packs the data-gradient operand for input channels [slice_begin, slice_begin+slice_count)."""
     K, cin, cout = w3.shape
     if slice_count is None:
         slice_count = cin
     ci, co = (cout, slice_count) if transpose else (cin, cout)
-    size = _lib.load().b2m_weight_pack_size(K, ci, co)
-    wp = torch.empty(size, dtype=torch.float32, device=w3.device)
+    wp = out
+    if wp is None:
+        size = _lib.load().b2m_weight_pack_size(K, ci, co)
+        wp = torch.empty(size, dtype=torch.float32, device=w3.device)
     _call('b2m_weight_pack', w3.data_ptr(), w3.stride(1), K, cin, cout, 1 if transpose else 0, 1 if mirror else 0,
           slice_begin, slice_count, wp.data_ptr())
     return wp
+
+
+class _PackedWeights:
+    """Packed images of the network's weights, refreshed for ALL layers with one launch per forward pass.
+
+    Every (weight, variant) a convolution asks for is registered on first use with a persistent image buffer; from
+    then on `refresh()` (called at the start of SelectionNet.forward) repacks every registered image in a single
+    b2m_weight_pack_run launch -- the weights only change between steps -- and the per-layer lookups are hits
+    (validated by the tensor's version counter and address), so a training step issues 1 pack launch instead of
+    ~200.  Entries die with their weight tensors."""
+
+    def __init__(self):
+        self.entries = {}          # key -> [weakref(weight), args, image, version, data_ptr]
+        self.plan = None           # (device plan, n, total_blocks, keys)
+        self.dirty = True
+
+    @staticmethod
+    def _w3(weight):
+        w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        assert w3.dtype == torch.float32 and w3.is_contiguous()
+        return w3
+
+    def get(self, weight, transpose=False, mirror=False, slice_begin=0, slice_count=None):
+        w3 = self._w3(weight.detach())
+        K, cin, cout = w3.shape
+        sc = cin if slice_count is None else slice_count
+        key = (id(weight), bool(transpose), bool(mirror), int(slice_begin), int(sc))
+        e = self.entries.get(key)
+        if e is not None and e[0]() is weight and e[4] == weight.data_ptr():
+            if e[3] != weight._version:           # changed since the last refresh: this one image only
+                weight_pack(w3, transpose, mirror, slice_begin, sc, out=e[2])
+                e[3] = weight._version
+            return e[2]
+        image = weight_pack(w3, transpose, mirror, slice_begin, sc)
+        self.entries[key] = [weakref.ref(weight), (K, cin, cout, bool(transpose), bool(mirror), int(slice_begin), int(sc)),
+                             image, weight._version, weight.data_ptr()]
+        self.dirty = True
+        return image
+
+    def _build_plan(self):
+        import ctypes as C
+        import numpy as np
+        dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[4]]
+        for k in dead:
+            del self.entries[k]
+        keys = list(self.entries)
+        n = len(keys)
+        self.dirty = False
+        if n == 0:
+            self.plan = None
+            return
+        lib = _lib.load()
+        es = [self.entries[k] for k in keys]
+        i64 = lambda v: np.ascontiguousarray(v, dtype=np.int64)
+        i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        w = i64([e[4] for e in es]); wp = i64([e[2].data_ptr() for e in es])
+        ldw = i64([e[1][2] for e in es])            # contiguous (K,Cin,Cout): row pitch = Cout
+        cols = [i32([e[1][j] for e in es]) for j in (0, 1, 2)]
+        flags = [i32([int(e[1][j]) for e in es]) for j in (3, 4, 5, 6)]
+        host = np.zeros(n * lib.b2m_weight_pack_plan_size(), np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        blocks = lib.b2m_weight_pack_plan(n, p(w), p(wp), p(ldw), p(cols[0]), p(cols[1]), p(cols[2]), p(flags[0]),
+                                          p(flags[1]), p(flags[2]), p(flags[3]), p(host))
+        if blocks < 0:
+            raise _lib.B2MError('b2m_weight_pack_plan failed: ' + lib.b2m_last_error().decode())
+        dev = es[0][2].device
+        self.plan = (torch.from_numpy(host).to(dev), n, int(blocks), keys)
+
+    def refresh(self):
+        """Repack every registered image whose weight may have changed (one launch)."""
+        if not self.entries:
+            return
+        stale = self.dirty or any(e[0]() is None or e[0]().data_ptr() != e[4] for e in self.entries.values())
+        if stale:
+            self._build_plan()
+        if self.plan is None:
+            return
+        plan, n, blocks, keys = self.plan
+        if all(self.entries[k][3] == self.entries[k][0]()._version for k in keys):
+            return                                  # nothing changed (e.g. repeated inference)
+        _call('b2m_weight_pack_run', plan.data_ptr(), n, blocks)
+        for k in keys:
+            e = self.entries[k]
+            e[3] = e[0]()._version
+
+
+packed_weights = _PackedWeights()
 
 
 def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: int, out=None, accumulate=False):
@@ -87,7 +179,7 @@ class _SparseConv(torch.autograd.Function):
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         w3 = _f32c(w3)
         K, cin, cout = w3.shape
-        wp = weight_pack(w3)
+        wp = packed_weights.get(weight)
         y = conv_raw(x1, x2, wp, K, bias, rb_f, n_out, cout)
         ctx.save_for_backward(x1, x2, weight, bias)
         ctx.rb_f, ctx.rb_b, ctx.mirror, ctx.c1 = rb_f, rb_b, mirror, c1
@@ -103,10 +195,10 @@ class _SparseConv(torch.autograd.Function):
         c1 = ctx.c1
         dx1 = dx2 = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = weight_pack(w3, True, ctx.mirror, 0, c1)
+            wt = packed_weights.get(weight, True, ctx.mirror, 0, c1)
             dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1)
         if x2 is not None and ctx.needs_input_grad[1]:
-            wt = weight_pack(w3, True, ctx.mirror, c1, x2.shape[1])
+            wt = packed_weights.get(weight, True, ctx.mirror, c1, x2.shape[1])
             dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1])
         if ctx.needs_input_grad[2]:
             dw = torch.zeros_like(weight, dtype=torch.float32)      # in the weight's own shape: adopted as .grad, not cloned

@@ -117,6 +117,17 @@ int64_t b2m_weight_pack_size(int32_t K, int32_t cin, int32_t cout);
 int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t cout, int32_t transpose,
                     int32_t mirror, int32_t slice_begin, int32_t slice_count, float* wp, void* stream);
 
+/* The packed images of many layers in one launch.  b2m_weight_pack_plan fills plan_host (n descriptors of
+ * b2m_weight_pack_plan_size() bytes; host memory) from per-layer arguments with the meaning of b2m_weight_pack
+ * (w / wp: device addresses as int64) and returns the number of 256-thread blocks; the caller copies the plan to the
+ * device once and calls b2m_weight_pack_run whenever the weights changed. */
+int32_t b2m_weight_pack_plan_size(void);
+int64_t b2m_weight_pack_plan(int32_t n, const int64_t* w, const int64_t* wp, const int64_t* ldw, const int32_t* K,
+                             const int32_t* cin, const int32_t* cout, const int32_t* transpose,
+                             const int32_t* mirror, const int32_t* slice_begin, const int32_t* slice_count,
+                             void* plan_host);
+int b2m_weight_pack_run(const void* plan_dev, int32_t n, int64_t total_blocks, void* stream);
+
 /* Y[o, 0:cout] (+)= sum_k [X1|X2][in_k(o), :] @ B[k]  (+ bias)
  * Replaces [ME] ConvolutionForward / ConvolutionTransposeForward (resnet.py:61-65,
  * detection_net.py:37-135) and, with an identity rulebook (rb_in == NULL, K == 1), the 1x1

@@ -16,7 +16,7 @@ def _header_decls():
     src = ''.join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith('.h'))
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     decls = {}
-    for m in re.finditer(r'\b(int64_t|int|const char\*)\s+(b2m_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+    for m in re.finditer(r'\b(int64_t|int32_t|int|const char\*)\s+(b2m_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
         args = [a.strip() for a in m.group(3).replace('\n', ' ').split(',')]
         if args == ['void']:
             args = []
