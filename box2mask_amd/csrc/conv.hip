@@ -422,40 +422,59 @@ extern "C" int64_t b2m_weight_pack_plan(int32_t n, const int64_t* w, const int64
         e.KC = conv_kc(e.CI); e.TW = conv_tw(e.CO, e.K);
         e.total = b2m_weight_pack_size(e.K, e.CI, e.CO);
         e.first_block = blocks;
-        blocks += (e.total + 255) / 256;
+        blocks += e.total / (64 * e.TW * (e.KC / 4));          // one workgroup per packed block
         d[i] = e;
     }
     return blocks;
 }
-__global__ void weight_pack_batch_kernel(const PackDesc* __restrict__ plan, int n) {
-    const int64_t blk = blockIdx.x;
-    int lo = 0, hi = n - 1;                              // last descriptor with first_block <= blk
+// one workgroup per packed block (64 lanes x TW*KS floats = a KC x 16*TW tile of the logical B[k]): the source tile is
+// read in whole row segments (64..192 B contiguous) into LDS and written out in fragment order.  Reading it in
+// fragment order straight from memory touched a different 64-byte segment with every 4-byte load (1.4 TB/s).
+#define PACK_PER_WG 8
+__global__ __launch_bounds__(256) void weight_pack_batch_kernel(const PackDesc* __restrict__ plan, int n) {
+    __shared__ float tile[16 * 48];
+    const int64_t blk0 = (int64_t)blockIdx.x * PACK_PER_WG;
+    int lo = 0, hi = n - 1;                              // last descriptor with first_block <= blk0
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (plan[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+        if (plan[mid].first_block <= blk0) lo = mid; else hi = mid - 1;
     }
-    const PackDesc d = plan[lo];
-    const int64_t e = (blk - d.first_block) * 256 + threadIdx.x;
-    if (e >= d.total) return;
-    const int KS = d.KC / 4, SW = 16 * d.TW;
-    const int nchunk = (d.CI + d.KC - 1) / d.KC, nstrip = (d.CO + SW - 1) / SW;
-    const int f = (int)(e % (d.TW * KS)); const int64_t e1 = e / (d.TW * KS);
-    const int lane = (int)(e1 % 64); const int64_t b1 = e1 / 64;
-    const int chunk = (int)(b1 % nchunk); const int64_t b2 = b1 / nchunk;
-    const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
-    const int s_ = f / d.TW, t = f % d.TW, q = lane >> 4, i = lane & 15;
-    const int ci = chunk * d.KC + KS * q + s_, co = strip * SW + 16 * t + i;
-    float v = 0.f;
-    if (ci < d.CI && co < d.CO) {
-        if (!d.transpose) v = d.w[((int64_t)k * d.rows + ci) * d.ldw + co];
-        else v = d.w[((int64_t)(d.mirror ? d.K - 1 - k : k) * d.rows + d.sb + co) * d.ldw + ci];
+    for (int it = 0; it < PACK_PER_WG; ++it) {
+        const int64_t blk = blk0 + it;
+        while (lo + 1 < n && plan[lo + 1].first_block <= blk) ++lo;      // crossing into the next layer is rare
+        const PackDesc d = plan[lo];
+        const int KS = d.KC / 4, SW = 16 * d.TW, LW = 64 * d.TW * KS;
+        const int64_t pb = blk - d.first_block;
+        if (pb * LW >= d.total) return;                                  // past the last layer
+        const int nchunk = (d.CI + d.KC - 1) / d.KC, nstrip = (d.CO + SW - 1) / SW;
+        const int chunk = (int)(pb % nchunk); const int64_t b2 = pb / nchunk;
+        const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
+        const int ci0 = chunk * d.KC, co0 = strip * SW;
+        __syncthreads();                                                 // the previous tile has been consumed
+        for (int j = threadIdx.x; j < d.KC * SW; j += 256) {
+            int ci_l, co_l;
+            if (!d.transpose) { ci_l = j / SW; co_l = j % SW; }          // rows of B are rows of w: SW contiguous floats
+            else { co_l = j / d.KC; ci_l = j % d.KC; }                   // rows of B are columns of w: KC contiguous floats
+            float v = 0.f;
+            if (ci0 + ci_l < d.CI && co0 + co_l < d.CO) {
+                if (!d.transpose) v = d.w[((int64_t)k * d.rows + ci0 + ci_l) * d.ldw + co0 + co_l];
+                else v = d.w[((int64_t)(d.mirror ? d.K - 1 - k : k) * d.rows + d.sb + co0 + co_l) * d.ldw + ci0 + ci_l];
+            }
+            tile[ci_l * SW + co_l] = v;
+        }
+        __syncthreads();
+        float* out = d.wp + pb * LW;
+        for (int e = threadIdx.x; e < LW; e += 256) {
+            const int f = e % (d.TW * KS), lane = e / (d.TW * KS);
+            const int s_ = f / d.TW, t = f % d.TW, q = lane >> 4, i = lane & 15;
+            out[e] = tile[(KS * q + s_) * SW + 16 * t + i];
+        }
     }
-    d.wp[e] = v;
 }
 extern "C" int b2m_weight_pack_run(const void* plan_dev, int32_t n, int64_t total_blocks, void* stream) {
     B2M_CHECK_ARG(n >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31) && (n == 0 || plan_dev), "bad arguments");
     if (n == 0 || total_blocks == 0) return B2M_OK;
-    weight_pack_batch_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>((const PackDesc*)plan_dev, n);
+    weight_pack_batch_kernel<<<(unsigned)cdiv64(total_blocks, PACK_PER_WG), 256, 0, (hipStream_t)stream>>>((const PackDesc*)plan_dev, n);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

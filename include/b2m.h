@@ -119,7 +119,7 @@ int b2m_weight_pack(const float* w, int64_t ldw, int32_t K, int32_t cin, int32_t
 
 /* The packed images of many layers in one launch.  b2m_weight_pack_plan fills plan_host (n descriptors of
  * b2m_weight_pack_plan_size() bytes; host memory) from per-layer arguments with the meaning of b2m_weight_pack
- * (w / wp: device addresses as int64) and returns the number of 256-thread blocks; the caller copies the plan to the
+ * (w / wp: device addresses as int64) and returns the number of workgroups of the launch; the caller copies the plan to the
  * device once and calls b2m_weight_pack_run whenever the weights changed. */
 int32_t b2m_weight_pack_plan_size(void);
 int64_t b2m_weight_pack_plan(int32_t n, const int64_t* w, const int64_t* wp, const int64_t* ldw, const int32_t* K,
