@@ -25,6 +25,7 @@ struct ConvArgs {
     int nslice;      // >1: the tile's active offsets are dealt to nslice waves which add their strips atomically
     int fast32;      // rows < 2^24, pitches < 2^22 floats, tensors < 4 GiB: 24-bit multiply + 32-bit byte offsets
     const float* zeros;   // address of g_zeros passed as data (a select of addresses, not a branch around the load)
+    int wg_combine;  // nslice % 4 == 0: the 4 waves of a workgroup are 4 slices of one item and add up in LDS first
     int64_t nwg;     // workgroups of work; the grid is padded to 8 * xcd_per
     int64_t xcd_per; // > 0: XCD-aware order, see wg_index()
 };
@@ -310,6 +311,32 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 #endif
 
     // ---- write the strip
+    if (a.wg_combine) {
+        // split-K on small maps: the workgroup's 4 waves hold 4 slices of the same (tile, strip).  Wave 0 adds the four
+        // LDS strips and writes once -- a quarter of the atomics, none at all when there are exactly 4 slices.
+        __syncthreads();
+        if (wave != 0) return;
+        const bool plain = a.nslice == 4 && !a.accumulate;
+        for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+            const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
+            const int64_t grow = row0 + row;
+            if (grow >= a.n_out) continue;
+            const int ci = cs_index<TW>(row, c4);
+            f32x4 v = *(const f32x4*)&smem[ci];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) v += *(const f32x4*)&smem[w * ((B2M_TILE + 1) * SW) + ci];
+            const int col = col0 + c4;
+            float* dst = a.y + grow * a.ldy + col;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (col + u < a.cout) {
+                    if (plain) dst[u] = v[u];
+                    else if (v[u] != 0.f) atomicAdd(dst + u, v[u]);
+                }
+            }
+        }
+        return;
+    }
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
@@ -518,14 +545,20 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
         nslice = (int)cdiv64(4096, items0);
         if (nslice > 16) nslice = 16;
         if (nslice > K) nslice = K;
+        if (K >= 4 && nslice > 1) {                    // whole workgroups per item: in-LDS combine of 4 slices
+            nslice = (nslice + 3) / 4 * 4;
+            if (nslice > K) nslice = K / 4 * 4;
+            if (nslice > 16) nslice = 16;
+        }
     }
     a.nslice = nslice;
+    a.wg_combine = (nslice > 1 && nslice % 4 == 0 && env_flag("B2M_CONV_WGCOMBINE", 1)) ? 1 : 0;
     a.fast32 = (n_in < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_in * ldx1 * 4 < (1ll << 32) &&
                 n_in * ldx2 * 4 < (1ll << 32) && env_flag("B2M_CONV_FAST32", 1)) ? 1 : 0;
     static const float* zeros_addr = nullptr;
     if (!zeros_addr) B2M_HIP(hipGetSymbolAddress((void**)&zeros_addr, HIP_SYMBOL(g_zeros)));
     a.zeros = zeros_addr;
-    if (nslice > 1 && !accumulate)
+    if (nslice > 1 && !accumulate && !(a.wg_combine && nslice == 4))
         B2M_HIP(hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)cout * sizeof(float), (size_t)n_out, st));
     const int64_t items = items0 * nslice;
     a.nwg = cdiv64(items, 4);

@@ -15,8 +15,9 @@ from box2mask_amd.sparse import CoordinateManager
 bs = int(os.environ.get('BS', '4'))
 b = synth.make_batch(bs, seed0=0)
 m = CoordinateManager(b['vox_coords'])
-rb0 = m.rulebook_same(0, 3); m.ensure_level(5); rb1 = m.rulebook_same(1, 3); rbu = m.rulebook_up(0); rb5 = m.rulebook_same(0, 5)
+rb0 = m.rulebook_same(0, 3); m.ensure_level(7); rb1 = m.rulebook_same(1, 3); rbu = m.rulebook_up(0); rb5 = m.rulebook_same(0, 5)
 rb2 = m.rulebook_same(2, 3); rb3 = m.rulebook_same(3, 3); rb4 = m.rulebook_same(4, 3)
+rb5l = m.rulebook_same(5, 3); rb6 = m.rulebook_same(6, 3)
 torch.cuda.synchronize()
 print('N0', m.n(0), 'pairs k3', rb0.pairs, 'k5', rb5.pairs)
 
@@ -32,12 +33,13 @@ for spec in os.environ.get('VARIANTS', 'tw2:B2M_CONV_TW3=0;slow64:B2M_WGRAD_FAST
     if spec:
         name, kv = spec.split(':'); k_, v_ = kv.split('=')
         VARIANTS.append((name, {k_: v_}))
-SWITCHES = ('B2M_CONV_TW3', 'B2M_CONV_NPF', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE')
+SWITCHES = ('B2M_CONV_TW3', 'B2M_CONV_NPF', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE')
 cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
          ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
          ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64),
          ('L2 k3 128->128', rb2, 27, 128, 0, 128), ('L2 k3 64->64', rb2, 27, 64, 0, 64), ('L3 k3 256->256', rb3, 27, 256, 0, 256),
-         ('L3 k3 128->128', rb3, 27, 128, 0, 128), ('L4 k3 256->256', rb4, 27, 256, 0, 256)]
+         ('L3 k3 128->128', rb3, 27, 128, 0, 128), ('L4 k3 256->256', rb4, 27, 256, 0, 256),
+         ('L5 k3 256->256', rb5l, 27, 256, 0, 256), ('L6 k3 256->256', rb6, 27, 256, 0, 256)]
 if os.environ.get('CASES'):
     cases = [c for c in cases if any(c[0].startswith(p) for p in os.environ['CASES'].split(','))]
 for name, rb, K, c1, c2, co in cases:
