@@ -25,6 +25,7 @@ struct ConvArgs {
     int nslice;      // >1: the tile's active offsets are dealt to nslice waves which add their strips atomically
     int fast32;      // rows < 2^24, pitches < 2^22 floats, tensors < 4 GiB: 24-bit multiply + 32-bit byte offsets
     const float* zeros;   // address of g_zeros passed as data (a select of addresses, not a branch around the load)
+    int ncs;         // chunk slices: a slice is (offset slice, part ncs of the input-channel chunks); nslice % ncs == 0
     int wg_combine;  // nslice % 4 == 0: the 4 waves of a workgroup are 4 slices of one item and add up in LDS first
     int64_t nwg;     // workgroups of work; the grid is padded to 8 * xcd_per
     int64_t xcd_per; // > 0: XCD-aware order, see wg_index()
@@ -90,7 +91,9 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
     const int64_t wg = wg_index(a.nwg, a.xcd_per);
     if (wg < 0) return;
     const int64_t witem = wg * 4 + wave;
-    const int slice = (int)(witem % a.nslice);
+    const int sl = (int)(witem % a.nslice);
+    const int slice = sl / a.ncs, cslice = sl % a.ncs;       // offsets are dealt to nslice/ncs slices, chunks to ncs
+    const int nkslice = a.nslice / a.ncs;
     const int64_t item = witem / a.nslice;
     const int64_t tile = item / a.nstrips;
     const int strip = (int)(item % a.nstrips);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
         for (int u = 0; u < 4; ++u) {
             const int col = col0 + c4 + u;
             if (col < a.cout) {
-                float t = (a.bias && slice == 0) ? a.bias[col] : 0.f;
+                float t = (a.bias && sl == 0) ? a.bias[col] : 0.f;
                 if (a.accumulate && a.nslice == 1 && grow < a.n_out) t += a.y[grow * a.ldy + col];
                 v[u] = t;
             }
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
         const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
         if (n == 0) continue;
         const bool mine = phase == slice;
-        phase = phase + 1 == a.nslice ? 0 : phase + 1;
+        phase = phase + 1 == nkslice ? 0 : phase + 1;
         if (!mine) continue;
         const int G = (n + 15) >> 4;           // 1..4 dense row groups
         B2M_STAMP(st0);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
         // issued back to back before the first MFMA block (memory-level parallelism per wave); the loads are
         // unconditional -- a chunk index past the end is clamped and only its MFMAs are skipped -- so that the
         // number of loads in flight is static and the compiler emits counted waits.
-        auto run_source = [&](const float* src, int64_t ld, int csrc, int c_lo, int c_hi) {
+        auto run_source = [&](const float* src, int64_t ld, int csrc, int c_base, int c_lo, int c_hi) {
             const float* pa[NG];
             uint32_t bo[NG];               // fast32: byte offset of lane's first channel in its gathered row
 #pragma unroll
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 #pragma unroll
                 for (int j = 0; j < NPF; ++j) {
                     const int c = (c0 + j < c_hi) ? c0 + j : c_hi - 1;
-                    const int cb = (c - c_lo) * KC;        // channel offset inside this source
+                    const int cb = (c - c_base) * KC;      // channel offset inside this source
                     {
                         // TW*KS contiguous floats per lane, ordered [s][t]
                         float wv[TW * KS];
@@ -262,8 +265,9 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
                 }
             }
         };
-        run_source(a.x1, a.ldx1, a.c1, 0, nch1);
-        if (a.c2 > 0) run_source(a.x2, a.ldx2, a.c2, nch1, nchunk);
+        // (tiny maps also split the input-channel chunks: part cslice of ncs of every source)
+        run_source(a.x1, a.ldx1, a.c1, 0, nch1 * cslice / a.ncs, nch1 * (cslice + 1) / a.ncs);
+        if (a.c2 > 0) run_source(a.x2, a.ldx2, a.c2, nch1, nch1 + (nchunk - nch1) * cslice / a.ncs, nch1 + (nchunk - nch1) * (cslice + 1) / a.ncs);
         B2M_STAMP(st2);
 
         // ---- add the offset's result into the strip.  D[row = 4q + r][col = i]; the pairs of one offset have
@@ -551,6 +555,13 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
             if (nslice > 16) nslice = 16;
         }
     }
+    // tiny maps (a few tiles): also split the input-channel chunks, up to 4 ways, so that a wave's dependent chain of
+    // chunk steps gets short; the slices still combine in LDS / with atomics
+    int ncs = 1;
+    const int nchunk_h = (cin + KC - 1) / KC;
+    while (nslice > 1 && ncs < 4 && items0 * nslice * ncs < 2048 && nchunk_h / (ncs * 2) >= 2 && env_flag("B2M_CONV_CHUNKSPLIT", 1)) ncs *= 2;
+    nslice *= ncs;
+    a.ncs = ncs;
     a.nslice = nslice;
     a.wg_combine = (nslice > 1 && nslice % 4 == 0 && env_flag("B2M_CONV_WGCOMBINE", 1)) ? 1 : 0;
     a.fast32 = (n_in < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_in * ldx1 * 4 < (1ll << 32) &&
