@@ -922,12 +922,14 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     const int MI = pick_blk(cin), NJ = pick_blk(cout);
     a.nmb = (cin + 16 * MI - 1) / (16 * MI);
     a.nnb = (cout + 16 * NJ - 1) / (16 * NJ);
-    // chunking: enough waves to fill the chip (>= ~8k), at most 65535 chunks, at least 1 tile per chunk
+    // chunking: enough waves to fill the chip (~16k), but a wave should own at least 4 tiles: every wave ends with
+    // 16*MI x 16*NJ atomics into dW, and on the small deep-level maps those outweighed the MFMA work (A/B per layer:
+    // +30..50 % there with the floor; the large maps are above it anyway)
     const int64_t blocks_per_chunk = (int64_t)K * a.nmb * a.nnb;
     int64_t want_chunks = cdiv64(16384, blocks_per_chunk);
     if (want_chunks < 1) want_chunks = 1;
     int64_t tpc = cdiv64(a.ntiles, want_chunks);
-    if (tpc < 1) tpc = 1;
+    if (tpc < env_flag("B2M_WGRAD_MIN_TILES", 4)) tpc = env_flag("B2M_WGRAD_MIN_TILES", 4);
     if (tpc > 64) tpc = 64;
     a.tiles_per_chunk = (int)tpc;
     a.nz = (a.nmb * a.nnb + 3) / 4;
