@@ -545,8 +545,11 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     const int64_t items0 = a.ntiles * a.nstrips;
     int nslice = 1;
     // (more, smaller slices were measured too: 2-6x as many waves lose 0-60 % to the atomic combine)
-    if (items0 < 4096 && K > 1) {
-        nslice = (int)cdiv64(4096, items0);
+    // 6144 rather than one wave per SIMD slot (4096): a map with ~4.3k items ran 1.05 rounds of waves at 50 TFLOP/s;
+    // as 4 in-LDS-combined slices it runs at 61
+    const int64_t target = env_flag("B2M_CONV_TARGET", 6144);
+    if (items0 < target && K > 1) {
+        nslice = (int)cdiv64(target, items0);
         if (nslice > 16) nslice = 16;
         if (nslice > K) nslice = K;
         if (K >= 4 && nslice > 1) {                    // whole workgroups per item: in-LDS combine of 4 slices
