@@ -895,7 +895,10 @@ static void launch_wgrad(int MI, int NJ, dim3 grid, hipStream_t st, const WgradA
 // tuning switches (A/B inside one process: tools/bench_conv.py); read at every call
 static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int pick_blk(int c) {      // 16-column sub-tiles per wave block
-    if (c % 64 == 0) return 4;
+    // 64 channels: four 32x32 blocks keep all 4 waves of a workgroup busy and fit the pipelined kernel at full
+    // occupancy (+27..35 % over one 64x64 block)
+    if (c == 64) return env_flag("B2M_WGRAD_BLK64", 2);
+    if (c % 64 == 0) return env_flag("B2M_WGRAD_BLKBIG", 4);
     if (c % 48 == 0) return 3;
     if (c % 32 == 0) return 2;
     if (c <= 16) return 1;
