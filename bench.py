@@ -104,7 +104,7 @@ def main():
 
     cfg = scannet_config(multigpu=(world > 1), batch_size=args.batch_size)
     model = Model(cfg, *synth.scannet_tables(), device=dev)
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, fused=True)      # same update as training.py:35, one kernel
     model.train()
 
     # ---- synthetic batch of this rank (weak scaling: every rank gets batch_size scenes), resident in HBM

@@ -69,7 +69,7 @@ def main(argv=None):
     sup = SimpleNamespace(smallest_bb_heuristic=True)
     batch, raws = build_batch(range(args.scenes), args.voxels, 'train', sup)
     model = Model(cfg, *synth.scannet_tables())
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, fused=True)
     model.train()
     history = []
     t0 = time.time()
