@@ -174,9 +174,9 @@ __global__ __launch_bounds__(256) void mask_project_kernel(const float* __restri
 extern "C" int b2m_mask_project(const float* heat, int32_t n_fg, const int32_t* sel, int32_t ksel,
                                 const int32_t* fg_slot, const int64_t* seg2vox, int64_t n_vox, float mask_bin_th,
                                 uint64_t* bits, int64_t words, void* stream) {
-    B2M_CHECK_ARG(heat && sel && fg_slot && seg2vox && bits && n_fg > 0 && ksel >= 0 && words == cdiv64(n_vox, 64),
-                  "bad arguments");
-    if (ksel == 0 || n_vox == 0) return B2M_OK;
+    B2M_CHECK_ARG(ksel >= 0 && words == cdiv64(n_vox, 64), "bad sizes");
+    if (ksel == 0 || n_vox == 0) return B2M_OK;        // no cluster passed the score filter: nothing to project
+    B2M_CHECK_ARG(heat && sel && fg_slot && seg2vox && bits && n_fg > 0, "bad arguments");
     dim3 grid((unsigned)cdiv64(words, 4), (unsigned)ksel);
     mask_project_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(heat, n_fg, sel, fg_slot, seg2vox, n_vox, mask_bin_th,
                                                                bits, words);
@@ -268,8 +268,9 @@ __global__ __launch_bounds__(256) void label_hist_kernel(const uint64_t* __restr
 }
 extern "C" int b2m_label_hist(const uint64_t* bits, int64_t words, const int32_t* rows, int32_t k, const int32_t* sem,
                               int64_t n_vox, int32_t n_class, int32_t* labels, void* stream) {
-    B2M_CHECK_ARG(bits && sem && labels && k >= 0 && n_class >= 1 && n_class <= 256, "bad arguments (n_class <= 256)");
+    B2M_CHECK_ARG(k >= 0 && n_class >= 1 && n_class <= 256, "bad sizes (n_class <= 256)");
     if (k == 0) return B2M_OK;
+    B2M_CHECK_ARG(bits && sem && labels, "NULL argument");
     label_hist_kernel<<<(unsigned)k, 256, 0, (hipStream_t)stream>>>(bits, words, rows, sem, n_vox, n_class, labels);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
@@ -308,9 +309,9 @@ __global__ __launch_bounds__(256) void mask_hist_kernel(const uint64_t* __restri
 extern "C" int b2m_mask_hist(const uint64_t* bits, int64_t words, int32_t k, const int32_t* label, int64_t n,
                              int32_t n_class, int32_t* hist, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(bits && label && hist && k >= 0 && k <= 65535 && n_class >= 1 && n_class <= HIST_MAX && n >= 0,
-                  "bad arguments (n_class <= 2048)");
+    B2M_CHECK_ARG(k >= 0 && k <= 65535 && n_class >= 1 && n_class <= HIST_MAX && n >= 0, "bad sizes (n_class <= 2048)");
     if (k == 0) return B2M_OK;
+    B2M_CHECK_ARG(bits && label && hist, "NULL argument");
     B2M_HIP(hipMemsetAsync(hist, 0, (size_t)k * n_class * sizeof(int32_t), st));
     if (words == 0) return B2M_OK;
     const int64_t wpb = 2048;
@@ -331,8 +332,9 @@ __global__ void mask_gather_kernel(const uint64_t* __restrict__ bits, int64_t wo
 }
 extern "C" int b2m_mask_gather(const uint64_t* bits, int64_t words, const int32_t* rows, int32_t k,
                                const int64_t* index, int64_t n_pts, uint8_t* out, void* stream) {
-    B2M_CHECK_ARG(bits && out && k >= 0 && k <= 65535 && n_pts >= 0, "bad arguments");
-    if (k == 0 || n_pts == 0) return B2M_OK;
+    B2M_CHECK_ARG(k >= 0 && k <= 65535 && n_pts >= 0, "bad sizes");
+    if (k == 0 || n_pts == 0) return B2M_OK;            // empty selection: nothing to write (out may be NULL)
+    B2M_CHECK_ARG(bits && out, "NULL argument");
     mask_gather_kernel<<<dim3((unsigned)cdiv64(n_pts, 256), (unsigned)k), 256, 0, (hipStream_t)stream>>>(
         bits, words, rows, index, n_pts, out);
     B2M_LAUNCH_CHECK();
@@ -351,8 +353,9 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t* __restric
     if (lane_id() == 0) bits[(int64_t)r * words + w] = m;
 }
 extern "C" int b2m_mask_pack(const uint8_t* masks, int32_t k, int64_t n, uint64_t* bits, int64_t words, void* stream) {
-    B2M_CHECK_ARG(masks && bits && k >= 0 && k <= 65535 && words == cdiv64(n, 64), "bad arguments");
+    B2M_CHECK_ARG(k >= 0 && k <= 65535 && words == cdiv64(n, 64), "bad sizes");
     if (k == 0 || n == 0) return B2M_OK;
+    B2M_CHECK_ARG(masks && bits, "NULL argument");
     mask_pack_kernel<<<dim3((unsigned)cdiv64(words, 4), (unsigned)k), 256, 0, (hipStream_t)stream>>>(masks, n, bits, words);
     B2M_LAUNCH_CHECK();
     return B2M_OK;

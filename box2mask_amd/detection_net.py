@@ -130,7 +130,7 @@ class SelectionNet(ResNetBase):
         (detection_net.py:234-364)."""
         cbr = self._cbr
         tr = getattr(self, '_trace', None)          # optional dict: named intermediates for parity debugging
-        F_.packed_weights.refresh()                 # one launch repacks every layer's weight images for this pass
+        F_.packed_weights.begin_pass()              # one launch repacks every layer's weight images for this pass
 
         def T(name, t):
             if tr is not None:

@@ -42,18 +42,21 @@ def weight_pack(w3, transpose: bool = False, mirror: bool = False, slice_begin: 
 
 
 class _PackedWeights:
-    """Packed images of the network's weights, refreshed for ALL layers with one launch per forward pass.
+    """Packed images of the network's weights, rebuilt for ALL layers with one launch per forward pass.
 
-    Every (weight, variant) a convolution asks for is registered on first use with a persistent image buffer; from
-    then on `refresh()` (called at the start of SelectionNet.forward) repacks every registered image in a single
-    b2m_weight_pack_run launch -- the weights only change between steps -- and the per-layer lookups are hits
-    (validated by the tensor's version counter and address), so a training step issues 1 pack launch instead of
-    ~200.  Entries die with their weight tensors."""
+    Every (weight, variant) a convolution asks for is registered on first use with a persistent image buffer;
+    `begin_pass()` (called at the start of SelectionNet.forward) repacks every registered image in a single
+    b2m_weight_pack_run launch and opens a new pass; lookups during that forward and its backward are hits, so a
+    training step issues 1 pack launch instead of ~200.  begin_pass repacks UNCONDITIONALLY: tensor version counters
+    are not a reliable change signal (fused optimizers update parameters without bumping them).  Outside a pass
+    opened for the current weights (direct use of the functional API) an image is reused only if the tensor's
+    version counter and address are unchanged, otherwise it is repacked on the spot.  Entries die with their tensors."""
 
     def __init__(self):
-        self.entries = {}          # key -> [weakref(weight), args, image, version, data_ptr]
+        self.entries = {}          # key -> [weakref(weight), args, image, version, data_ptr, pass_id]
         self.plan = None           # (device plan, n, total_blocks, keys)
         self.dirty = True
+        self.pass_id = 0
 
     @staticmethod
     def _w3(weight):
@@ -68,13 +71,13 @@ class _PackedWeights:
         key = (id(weight), bool(transpose), bool(mirror), int(slice_begin), int(sc))
         e = self.entries.get(key)
         if e is not None and e[0]() is weight and e[4] == weight.data_ptr():
-            if e[3] != weight._version:           # changed since the last refresh: this one image only
+            if e[5] != self.pass_id or e[3] != weight._version:      # not packed in this pass / changed since
                 weight_pack(w3, transpose, mirror, slice_begin, sc, out=e[2])
-                e[3] = weight._version
+                e[3], e[5] = weight._version, self.pass_id
             return e[2]
         image = weight_pack(w3, transpose, mirror, slice_begin, sc)
         self.entries[key] = [weakref.ref(weight), (K, cin, cout, bool(transpose), bool(mirror), int(slice_begin), int(sc)),
-                             image, weight._version, weight.data_ptr()]
+                             image, weight._version, weight.data_ptr(), self.pass_id]
         self.dirty = True
         return image
 
@@ -107,22 +110,20 @@ class _PackedWeights:
         dev = es[0][2].device
         self.plan = (torch.from_numpy(host).to(dev), n, int(blocks), keys)
 
-    def refresh(self):
-        """Repack every registered image whose weight may have changed (one launch)."""
+    def begin_pass(self):
+        """Open a new pass: repack every registered image from the current weights (one launch)."""
+        self.pass_id += 1
         if not self.entries:
             return
-        stale = self.dirty or any(e[0]() is None or e[0]().data_ptr() != e[4] for e in self.entries.values())
-        if stale:
+        if self.dirty or any(e[0]() is None or e[0]().data_ptr() != e[4] for e in self.entries.values()):
             self._build_plan()
         if self.plan is None:
             return
         plan, n, blocks, keys = self.plan
-        if all(self.entries[k][3] == self.entries[k][0]()._version for k in keys):
-            return                                  # nothing changed (e.g. repeated inference)
         _call('b2m_weight_pack_run', plan.data_ptr(), n, blocks)
         for k in keys:
             e = self.entries[k]
-            e[3] = e[0]()._version
+            e[3], e[5] = e[0]()._version, self.pass_id
 
 
 packed_weights = _PackedWeights()

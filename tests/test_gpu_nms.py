@@ -162,3 +162,27 @@ def test_detection2mask_s3dis_flow_golden(golden_dir, mode):
     assert np.array_equal(r['label_id'], d[pre + 'label_id'])
     assert tuple(r['mask'].shape) == tuple(d[pre + 'mask_shape']) and r['mask'].shape[0] > 0
     assert np.array_equal(np.packbits(r['mask'].numpy(), axis=1), d[pre + 'mask'])
+
+
+def test_detection2mask_no_cluster_survives_the_score_filter():
+    """All scores below the threshold: every scene must come back with zero instances (the reference returns empty
+    tensors there), not fail on empty work."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    cfg = scannet_config()
+    batch = synth.make_batch(2, seed0=3, target_voxels=4000, pts_per_m2=6000.0)
+    valid, id2idx, _, _ = synth.scannet_tables()
+    S = batch['input_location'].shape[0]
+    sem_idx = id2idx[batch['gt_semantics']].clamp_min(0)
+    pred = {cfg.mlp_offsets: batch['gt_bb_offsets'].clone(), cfg.mlp_bounds: batch['gt_bb_bounds'].clamp_min(0.04),
+            cfg.mlp_bb_scores: torch.full((S, 1), -20.0),                     # sigmoid ~ 2e-9 < score_th 0.05
+            cfg.mlp_semantics: torch.nn.functional.one_hot(sem_idx, len(valid)).float()}
+    model = Model(cfg, *synth.scannet_tables())
+    for mode in ('eval', 'vox'):
+        res = model.pred2mask(batch, pred, mode)
+        for b, sc in enumerate(batch['scene']):
+            r = res[sc['name']]
+            assert len(r['conf']) == 0 and len(r['label_id']) == 0 and r['mask'].shape[0] == 0
+            n = len(batch['vox2point'][b]) if mode == 'eval' else len(batch['seg2vox'][b])
+            assert r['mask'].shape == (0, n)
