@@ -1,16 +1,17 @@
 // Sparse convolution on the tile rulebook: forward / data-gradient (one kernel) and weight gradient.
 // fp32 in, fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain).
 //
-// Forward work decomposition: an ITEM is (tile of 64 output rows, strip of 32 output channels)
+// Forward work decomposition: an ITEM is (tile of 64 output rows, strip of 32 or 48 output channels)
 // and belongs to ONE wave; the four waves of a workgroup take four consecutive items so that their gathers
 // share L1.  A wave walks the tile's active kernel offsets; for every offset the valid (in,out) pairs are
 // already compacted (rulebook), so the MFMA row groups are dense: up to 4 groups of 16 pairs.  A comes
-// straight from global memory (each lane owns one gathered row, 4 consecutive channels), B (weights)
-// straight from L2 into registers, the per-offset result accumulates in registers over all input-channel
-// chunks and is then added into the wave-private 64x32 output strip in LDS with plain read-modify-write
-// (LDS float atomics measured ~200 cycles per wave instruction: 5 TFLOP/s; never use them here).
-// No workgroup barrier anywhere; latency is covered by occupancy (8 KiB LDS, <=128 VGPRs: 4 waves/SIMD)
-// and by issuing two chunks of loads before the first MFMA block.
+// straight from global memory (each lane owns one gathered row, 4 consecutive channels), B (weights) from the
+// packed fragment-order image, the per-offset result accumulates in registers over all input-channel chunks and is
+// then added into the wave-private output strip in LDS with plain, batched read-modify-write (LDS float atomics
+// measured ~200 cycles per wave instruction: 5 TFLOP/s; never use them here).  No workgroup barrier in the main
+// path; latency is covered by occupancy (8-12 KiB LDS, <=128 / <=168 VGPRs: 4 / 3 waves per SIMD) and by one or two
+// chunks of loads in flight.  Small maps are split over slices (offsets, for tiny maps also channel chunks) whose
+// 4 waves per workgroup combine in LDS behind ONE barrier at the end.
 #include "b2m_common.h"
 #include <stdlib.h>
 
