@@ -232,12 +232,12 @@ def main():
 
     # ---- second half of configs[1] ("+ iou_nms on HIP"): votes -> instance masks of the same 8 scenes, reported
     # beside the headline value (never part of it)
-    if args.votes:
-        result['votes_to_masks'] = votes_leg(model, batch, cfg, cpu=bool(args.cpu_baseline) and world == 1)
+    if args.votes and world == 1:          # N=1 only: the other ranks of a scaling run wait at the final barrier
+        result['votes_to_masks'] = votes_leg(model, batch, cfg, cpu=bool(args.cpu_baseline))
 
     # ---- raw scene points -> voxelised, collated device batch (what feeds the step above)
-    if args.prepare:
-        result['prepare'] = prepare_leg(dev, args.target_voxels, cpu=bool(args.cpu_baseline) and world == 1)
+    if args.prepare and world == 1:
+        result['prepare'] = prepare_leg(dev, args.target_voxels, cpu=bool(args.cpu_baseline))
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, bounded sample
     if cpu_result is not None:
