@@ -46,7 +46,10 @@ class LaunchTimer:
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
-        if name == 'b2m_conv_fwd':
+        if name == 'b2m_bn_apply':
+            # x, ldx, n, c, scale, shift, residual, ldr, relu, y, ldy: streams x (+ residual) in and y out
+            meta = dict(bytes=4.0 * args[2] * args[3] * (3 if args[6] else 2))
+        elif name == 'b2m_conv_fwd':
             # x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
             meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12], n_in=args[6])
         else:   # b2m_conv_wgrad: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
@@ -127,7 +130,7 @@ def main():
         rb_lookup[self.rb_cnt.data_ptr()] = self
     sparse_mod.Rulebook.__init__ = rb_init
 
-    timer = LaunchTimer(['b2m_conv_fwd', 'b2m_conv_wgrad'])
+    timer = LaunchTimer(['b2m_conv_fwd', 'b2m_conv_wgrad', 'b2m_bn_apply'])
     _lib.set_hook(timer.hook)
 
     def step():
@@ -172,8 +175,12 @@ def main():
     # ---- roofline of the dominant kernels from the live event timings
     cache = {}
     agg = {}
+    hbm = dict(ms=0.0, bytes=0.0, launches=0)
     for name, s, e, meta in timer.records:
         ms = s.elapsed_time(e)
+        if name == 'b2m_bn_apply':
+            hbm['ms'] += ms; hbm['bytes'] += meta['bytes']; hbm['launches'] += 1
+            continue
         P = pairs_of(meta, cache, rb_lookup)
         flops = 2.0 * P * meta['cin'] * meta['cout']
         # bytes any implementation moves: both feature matrices once, the weights once, the pair lists
@@ -186,6 +193,8 @@ def main():
     if args.detail:
         shapes = {}
         for name, s_, e_, meta in timer.records:
+            if name == 'b2m_bn_apply':
+                continue
             key = (name[4:], meta['K'], meta['cin'], meta['cout'], meta['n_out'])
             d = shapes.setdefault(key, [0.0, 0.0, 0])
             d[0] += s_.elapsed_time(e_); d[1] += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']; d[2] += 1
@@ -231,6 +240,15 @@ def main():
                    'voxels_per_gpu_batch': n_vox, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 4),
                    'scene_gen_s': round(gen_s, 1), 'setup_steps': SETUP_STEPS},
         'roofline': roofline, 'roofline_wgrad': roofline_wgrad,
+        # an HBM-bound kernel of the path, same live HIP-event method: BatchNorm apply (+residual, +ReLU) streams
+        # 2-3 tensors per launch; small deep-level layers (launch-latency bound) are part of the average
+        'roofline_bn_apply': {'bound': 'hbm', 'achieved': round(hbm['bytes'] / max(hbm['ms'], 1e-9) / 1e6, 1),
+                              'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                              'frac': round(hbm['bytes'] / max(hbm['ms'], 1e-9) / 1e6 / PEAK_HBM_GBS, 4),
+                              'traffic': pmc.get('bn_apply_kernel', {}).get('traffic_bytes'),
+                              'algorithmic_bytes': round(hbm['bytes'] / max(hbm['launches'], 1)),
+                              'launches_per_step': hbm['launches'] // max(args.steps, 1),
+                              'kernel': 'bn_apply_kernel'},
     }
 
     # ---- second half of configs[1] ("+ iou_nms on HIP"): votes -> instance masks of the same 8 scenes, reported
