@@ -107,6 +107,7 @@ __global__ __launch_bounds__(NMC_THREADS) void nmc_kernel(const float* __restric
             if (p < n && is_alive(ord(p))) atomicMin(&s_first, p);
             __syncthreads();
             pf = s_first;
+            __syncthreads();                   // every wave has read s_first before any wave publishes the next window
             if (pf != 0x7FFFFFFF || p0 + NMC_THREADS >= n) break;
             p0 += NMC_THREADS;
         }

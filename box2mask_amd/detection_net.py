@@ -131,6 +131,9 @@ class SelectionNet(ResNetBase):
         cbr = self._cbr
         tr = getattr(self, '_trace', None)          # optional dict: named intermediates for parity debugging
         F_.packed_weights.begin_pass()              # one launch repacks every layer's weight images for this pass
+        arena = getattr(self, '_grad_arena', None)
+        if arena is not None and torch.is_grad_enabled():
+            arena.begin_pass()                      # one memset: every parameter gradient of this pass starts at zero
 
         def T(name, t):
             if tr is not None:

@@ -12,6 +12,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from .grad_arena import grad_slot
 from .sparse import Rulebook
 
 _call = _lib.call
@@ -202,13 +203,21 @@ class _SparseConv(torch.autograd.Function):
             wt = packed_weights.get(weight, True, ctx.mirror, c1, x2.shape[1])
             dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1])
         if ctx.needs_input_grad[2]:
-            dw = torch.zeros_like(weight, dtype=torch.float32)      # in the weight's own shape: adopted as .grad, not cloned
+            # the weight's slot in the model's gradient arena (zeroed once per pass, adopted by autograd as .grad), else a
+            # zero-filled tensor of the weight's own shape
+            dw = grad_slot(weight)
+            if dw is None:
+                dw = torch.zeros_like(weight, dtype=torch.float32)
             dw3 = dw if weight.dim() == 3 else dw.unsqueeze(0)
             wgrad_raw(x1, dy, ctx.rb_f, K, dw3, 0, c1)
             if x2 is not None:
                 wgrad_raw(x2, dy, ctx.rb_f, K, dw3, c1, x2.shape[1])
         if bias is not None and ctx.needs_input_grad[3]:
-            db = dy.sum(0, keepdim=True).reshape(bias.shape)
+            db = grad_slot(bias)
+            if db is not None and db.shape == (1, cout):
+                torch.sum(dy, 0, keepdim=True, out=db)
+            else:
+                db = dy.sum(0, keepdim=True).reshape(bias.shape)
         return dx1, dx2, dw, db, None, None, None, None
 
 
@@ -304,14 +313,14 @@ class _BatchNorm(torch.autograd.Function):
             # from x (which it reads anyway) instead of reading y
             ctx.mask_from_x = bool(relu) and residual is None
             ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, mean, invstd,
-                                  scale if ctx.mask_from_x else None, shift if ctx.mask_from_x else None)
+                                  scale if ctx.mask_from_x else None, shift if ctx.mask_from_x else None, beta)
         else:
-            ctx.save_for_backward(x, y if relu else None, gamma, scale, None, None, None)
+            ctx.save_for_backward(x, y if relu else None, gamma, scale, None, None, None, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, mean, invstd, mscale, mshift = ctx.saved_tensors
+        x, y, gamma, mean, invstd, mscale, mshift, beta = ctx.saved_tensors
         dy = _f32c(dy)
         n, c = x.shape
         dev = x.device
@@ -326,8 +335,10 @@ class _BatchNorm(torch.autograd.Function):
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned
-        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta, dgamma = grad_slot(beta), grad_slot(gamma)
+        if dbeta is None or dgamma is None:
+            dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+            dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _ptr(mscale), _ptr(mshift),
               partial.data_ptr(), sums.data_ptr(), dbeta.data_ptr(), dgamma.data_ptr())

@@ -8,7 +8,6 @@ from __future__ import annotations
 import os
 from glob import glob
 
-import numpy as np
 import torch
 
 from . import _lib
@@ -16,7 +15,7 @@ from . import iou_nms
 from . import nn as ME
 from .detection_net import SelectionNet
 from .iou_nms import semIOU
-from .util import convertSecs, to_bbs_min_max_
+from .util import to_bbs_min_max_
 
 
 def _pearsonr(a: torch.Tensor, b: torch.Tensor):
@@ -25,6 +24,19 @@ def _pearsonr(a: torch.Tensor, b: torch.Tensor):
     a = a.double() - a.double().mean()
     b = b.double() - b.double().mean()
     return (a * b).sum() / torch.sqrt((a * a).sum() * (b * b).sum()).clamp_min(1e-300)
+
+
+def _paired_box_iou(a: torch.Tensor, b: torch.Tensor, floor: float = 1e-6):
+    """IoU of box a[i] with box b[i]; rows are [min xyz, max xyz].  The IoU term of the training loss
+    (model.py:111-126): volumes from the corner differences, intersection clamped at zero, union floored at 1e-6."""
+    def volume(lo, hi):
+        side = hi - lo
+        return side[..., 0] * side[..., 1] * side[..., 2]
+    lo, hi = torch.maximum(a[..., :3], b[..., :3]), torch.minimum(a[..., 3:], b[..., 3:])
+    side = (hi - lo).clamp(min=0)
+    inter = side[..., 0] * side[..., 1] * side[..., 2]
+    union = volume(a[..., :3], a[..., 3:]) + volume(b[..., :3], b[..., 3:]) - inter
+    return inter / torch.clamp(union, min=floor)
 
 
 class Model:
@@ -39,12 +51,16 @@ class Model:
         self.detection_model = SelectionNet(cfg, device, semantic_valid_class_ids, is_foreground,
                                             out_channels=[96, 96, 6]).to(device)
         self._dp = None
+        # every parameter gradient is a view into one flat buffer (one memset per step, in-place all-reduce)
+        from .grad_arena import GradArena
+        self._arena = GradArena(list(self.detection_model.parameters()))
+        self.detection_model._grad_arena = self._arena
         if cfg.multigpu:
             # model.py:24-25: DDP + SyncBN.  Here: packed SyncBN statistics and a flat-bucket RCCL
             # gradient all-reduce (box2mask_amd/parallel.py) instead of torch DDP's hook machinery.
             from .parallel import GradAllReduce
             ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(self.detection_model)
-            self._dp = GradAllReduce(list(self.detection_model.parameters()))
+            self._dp = GradAllReduce(list(self.detection_model.parameters()), arena=self._arena)
             self._dp.broadcast_parameters()
         self.BCEWithLogitsLoss = torch.nn.BCEWithLogitsLoss().to(device)
         self.semantics_loss = torch.nn.CrossEntropyLoss(ignore_index=-100).to(device)
@@ -97,17 +113,9 @@ class Model:
                 pred_bounds, pred_offsets = pred_bounds[fg], pred_offsets[fg]
                 gt_bounds, gt_offsets, loc = gt_bounds[fg], gt_offsets[fg], loc[fg]
             pred_bounds = torch.clamp(pred_bounds, min=cfg.min_bb_size)
-            pr_bbs = to_bbs_min_max_(pred_offsets + loc, pred_bounds, device)
-            gt_bbs = to_bbs_min_max_(gt_offsets + loc, gt_bounds, device)
-            area1 = (pr_bbs[..., 3] - pr_bbs[..., 0]) * (pr_bbs[..., 4] - pr_bbs[..., 1]) * (pr_bbs[..., 5] - pr_bbs[..., 2])
-            area2 = (gt_bbs[..., 3] - gt_bbs[..., 0]) * (gt_bbs[..., 4] - gt_bbs[..., 1]) * (gt_bbs[..., 5] - gt_bbs[..., 2])
-            lt = torch.max(pr_bbs[..., :3], gt_bbs[..., :3])
-            rb = torch.min(pr_bbs[..., 3:], gt_bbs[..., 3:])
-            wh = (rb - lt).clamp(min=0)
-            overlap = wh[..., 0] * wh[..., 1] * wh[..., 2]
-            union = area1 + area2 - overlap
-            union = torch.max(union, union.new_tensor([1e-6]))
-            iou_loss = torch.mean(1.0 - overlap / union)
+            ious = _paired_box_iou(to_bbs_min_max_(pred_offsets + loc, pred_bounds, device),
+                                   to_bbs_min_max_(gt_offsets + loc, gt_bounds, device))
+            iou_loss = torch.mean(1.0 - ious)
             losses_dict['optimization_loss'] += cfg.loss_weight_bb_iou * iou_loss
             losses_dict['iou_loss'] = iou_loss.detach()
 
@@ -165,7 +173,8 @@ class Model:
         return losses_dict, pred
 
     def sync_gradients(self):
-        """Data-parallel gradient mean (DDP's job in the reference, model.py:24); no-op on one GPU."""
+        """Kept for callers of the first release: the data-parallel gradient mean (DDP's job in the reference,
+        model.py:24) now completes by itself when `backward()` returns, so this is a no-op."""
         if self._dp is not None:
             self._dp.all_reduce_mean()
 
@@ -195,26 +204,35 @@ class Model:
         return self.detection_model.state_dict()
 
     def load_checkpoint(self, checkpoint=None, closest_to=None):
-        """model.py:264-288 (same file-name convention, same return tuple)."""
-        checkpoints = glob(self.cfg.checkpoint_path + '/*')
-        if checkpoint is None:
-            if len(checkpoints) == 0:
-                print('No checkpoints found at {}'.format(self.cfg.checkpoint_path))
-                return 0, 0
-            checkpoints = [os.path.splitext(os.path.basename(path))[0].split('_')[-1] for path in checkpoints]
-            checkpoints = np.sort(np.array(checkpoints, dtype=float))
-            if closest_to:
-                ckpt_idx = np.argmin(np.abs(checkpoints - (closest_to * 60 * 60)))
-            else:
-                ckpt_idx = -1
-            path = self.cfg.checkpoint_path + 'checkpoint_{}h:{}m:{}s_{}.tar'.format(
-                *[*convertSecs(checkpoints[ckpt_idx]), checkpoints[ckpt_idx]])
+        """Restore a checkpoint written by training.py:216-224 (`checkpoint_{h}h:{m}m:{s}s_{seconds}.tar` under
+        cfg.checkpoint_path).  Without a name the newest one is taken -- or, with `closest_to` (hours), the one
+        whose training time is nearest.  Returns (epoch, training_time, name, iteration_num); (0, 0) when the
+        directory is empty, as model.py:264-288 does."""
+        root = self.cfg.checkpoint_path
+        if checkpoint is not None:
+            path = '%s%s.tar' % (root, checkpoint)
         else:
-            path = self.cfg.checkpoint_path + '{}.tar'.format(checkpoint)
+            stamped = []                                  # (training seconds, path)
+            for f in glob(root + '/*'):
+                stem = os.path.splitext(os.path.basename(f))[0]
+                try:
+                    stamped.append((float(stem.rsplit('_', 1)[-1]), f))
+                except ValueError:
+                    raise ValueError('unexpected file in the checkpoint directory: %s' % f)
+            if not stamped:
+                print('No checkpoints found at {}'.format(root))
+                return 0, 0
+            stamped.sort(key=lambda e: e[0])
+            if closest_to:
+                want = closest_to * 3600.0
+                path = min(stamped, key=lambda e: abs(e[0] - want))[1]
+            else:
+                path = stamped[-1][1]
         print('Loaded checkpoint from: {}'.format(path))
-        checkpoint = torch.load(path, map_location=self.device)
-        self.load_state_dict(checkpoint['model_state_dict'])
-        return checkpoint['epoch'], checkpoint['training_time'], os.path.basename(path)[:-4], checkpoint['iteration_num']
+        state = torch.load(path, map_location=self.device)
+        self.load_state_dict(state['model_state_dict'])
+        name = os.path.basename(path)[:-len('.tar')]
+        return state['epoch'], state['training_time'], name, state['iteration_num']
 
 
 class _LazyMean:

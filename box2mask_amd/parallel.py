@@ -7,10 +7,12 @@ SURVEY.md Appendix A).  The class is device-agnostic torch code, so the N>1 path
 world_size-2 gloo tests on the CPU; on the GPU the backend "nccl" is RCCL.
 
 Buckets are filled in reverse parameter order (the order backward produces gradients).  When the
-last gradient of a bucket has been accumulated, the bucket is packed into one flat buffer and an
-asynchronous all-reduce is launched; `all_reduce_mean()` waits, divides by the world size and
-scatters the result back into the `.grad` tensors.  Large buckets (default 64 MiB) keep the
-xGMI links busy with few, large collectives.
+last gradient of a bucket has been accumulated an asynchronous all-reduce of the bucket is launched;
+a callback queued on the autograd engine finishes the job when the backward pass ends (wait, mean), so
+the caller's loop is exactly the reference's `loss.backward(); optimizer.step()` (training.py:63-70).
+With a gradient arena (grad_arena.py) a bucket IS a contiguous range of the arena: the collective runs
+in place, nothing is packed or copied back.  Large buckets (default 64 MiB) keep the xGMI links busy
+with few, large collectives.
 """
 from __future__ import annotations
 
@@ -49,11 +51,12 @@ def shard_scenes(n_scenes: int, rank: int, world: int):
 
 
 class GradAllReduce:
-    def __init__(self, params, bucket_bytes: int = 64 << 20, group=None, overlap: bool = True):
+    def __init__(self, params, bucket_bytes: int = 64 << 20, group=None, overlap: bool = True, arena=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.arena = arena
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = []          # list of lists of params, reverse order
+        self.buckets = []          # list of lists of params, reverse parameter order
         cur, size = [], 0
         for p in reversed(self.params):
             cur.append(p)
@@ -67,26 +70,67 @@ class GradAllReduce:
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self._bucket_of[p] = bi
-        self._pending = [len(b) for b in self.buckets]
-        self._work = [None] * len(self.buckets)
-        self._flat = [None] * len(self.buckets)
         self._hooks = []
+        self._reset()
         if overlap and self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    def _reset(self):
+        self._pending = [len(b) for b in self.buckets]
+        self._work = [None] * len(self.buckets)
+        self._flat = [None] * len(self.buckets)       # (tensor, in_place)
+        self._armed = False                           # a finalize callback is queued for the running backward pass
+
     # -- hooks (overlap with backward)
     def _on_grad(self, p):
+        if not self._armed:
+            # first gradient of this backward pass: the engine calls _finalize when the pass is complete
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
+        if self._pending[bi] < 0:
+            raise RuntimeError('GradAllReduce: a gradient arrived twice in one backward pass (parameter used by two '
+                               'graphs of one backward call is not supported)')
         if self._pending[bi] == 0:
             self._launch(bi)
 
     def _launch(self, bi):
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self._flat[bi] = flat
+        b = self.buckets[bi]
+        span = self.arena.span(b) if self.arena is not None else None
+        if span is not None:                  # every gradient of the bucket lives in its arena slot: reduce in place
+            j, lo, hi = span
+            flat, in_place = self.arena.buffers[j][lo:hi], True
+        else:
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+            in_place = False
+        self._flat[bi] = (flat, in_place)
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _finalize(self):
+        """Wait for every bucket, turn sums into means and (only for buckets that had to be packed) write the
+        result back.  Parameters without a gradient keep `.grad is None`."""
+        if self.world <= 1:
+            return
+        for bi in range(len(self.buckets)):
+            if self._work[bi] is None:        # bucket with parameters that received no gradient in this pass
+                self._launch(bi)
+        inv = 1.0 / self.world
+        for bi, b in enumerate(self.buckets):
+            self._work[bi].wait()
+            flat, in_place = self._flat[bi]
+            flat.mul_(inv)                                      # one launch per bucket
+            if not in_place:
+                views, dst, off = [], [], 0
+                for p in b:
+                    n = p.numel()
+                    if p.grad is not None:
+                        views.append(flat[off:off + n].view(p.shape)); dst.append(p.grad)
+                    off += n
+                if dst:
+                    torch._foreach_copy_(dst, views)            # one launch for the whole bucket
+        self._reset()
 
     # -- public
     def broadcast_parameters(self, src: int = 0):
@@ -96,26 +140,10 @@ class GradAllReduce:
             dist.broadcast(p.data, src=src, group=self.group)
 
     def all_reduce_mean(self):
-        """Finish (or perform) the gradient all-reduce and write the mean back into `.grad`."""
+        """Explicit form for callers without hooks (overlap=False): all-reduce now.  With hooks the work was done
+        when backward ended and this is a no-op, so calling it after backward() is always safe."""
         if self.world <= 1:
             return
-        for bi, b in enumerate(self.buckets):
-            if self._work[bi] is None:
-                self._launch(bi)
-        inv = 1.0 / self.world
-        for bi, b in enumerate(self.buckets):
-            self._work[bi].wait()
-            flat = self._flat[bi].mul_(inv)                     # one launch per bucket
-            views, dst, off = [], [], 0
-            for p in b:
-                n = p.numel()
-                g = flat[off:off + n].view(p.shape)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    views.append(g); dst.append(p.grad)
-                off += n
-            if dst:
-                torch._foreach_copy_(dst, views)                # one launch for the whole bucket
-            self._work[bi], self._flat[bi] = None, None
-        self._pending = [len(b) for b in self.buckets]
+        if self._hooks and not self._armed and all(w is None for w in self._work):
+            return
+        self._finalize()

@@ -41,41 +41,46 @@ class BasicBlock(nn.Module):
 
 
 class ResNetBase(nn.Module):
+    """Skeleton the U-Net derives from (resnet.py:86-181): subclasses set BLOCK / LAYERS / PLANES and build their
+    layers in `network_initialization`; `_make_layer` stacks residual blocks and tracks `self.inplanes`."""
     BLOCK = None
     LAYERS = ()
     INIT_DIM = 64
     PLANES = (64, 128, 256, 512)
 
     def __init__(self, in_channels, out_channels, D=3, expand_coordinates=False):
-        nn.Module.__init__(self)
-        self.D = D
-        self.expand_coordinates = expand_coordinates
-        assert self.BLOCK is not None
+        super().__init__()
+        if self.BLOCK is None:
+            raise TypeError('%s must define BLOCK' % type(self).__name__)
+        self.D, self.expand_coordinates = D, expand_coordinates
         self.network_initialization(in_channels, out_channels, D)
         self.weight_initialization()
 
     def weight_initialization(self):
-        # resnet.py:139-146: Kaiming fan-out on MinkowskiConvolution kernels only (transposed
-        # convolutions keep their default init); BN gamma=1, beta=0
-        for m in self.modules():
-            if isinstance(m, ME.MinkowskiConvolution):
-                ME.kaiming_normal_(m.kernel, mode='fan_out', nonlinearity='relu')
-            if isinstance(m, ME.MinkowskiBatchNorm):
-                nn.init.constant_(m.bn.weight, 1)
-                nn.init.constant_(m.bn.bias, 0)
+        """He-normal (fan-out) on every non-transposed convolution kernel, identity affine on every BatchNorm;
+        transposed convolutions keep their constructor's uniform init (resnet.py:139-146 touches neither them nor
+        biases)."""
+        for module in self.modules():
+            if type(module) is ME.MinkowskiConvolution:
+                ME.kaiming_normal_(module.kernel, mode='fan_out', nonlinearity='relu')
+            elif isinstance(module, ME.MinkowskiBatchNorm):
+                nn.init.ones_(module.bn.weight)
+                nn.init.zeros_(module.bn.bias)
 
     def _make_layer(self, block, planes, blocks, stride=1, dilation=1, bn_momentum=0.1, expand_coordinates=False):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                ME.MinkowskiConvolution(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride,
-                                        dimension=self.D),
-                ME.MinkowskiBatchNorm(planes * block.expansion),
-            )
-        layers = [block(self.inplanes, planes, stride=stride, dilation=dilation, downsample=downsample,
-                        dimension=self.D, expand_coordinates=expand_coordinates)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes, stride=1, dilation=dilation, dimension=self.D,
-                                expand_coordinates=expand_coordinates))
-        return nn.Sequential(*layers)
+        """`blocks` residual blocks of width planes * block.expansion.  Only the first one may change the width or
+        the stride; when it does, its shortcut is a 1x1 convolution + BatchNorm (state-dict names `downsample.0/.1`)."""
+        width = planes * block.expansion
+        shortcut = None
+        if stride != 1 or self.inplanes != width:
+            shortcut = nn.Sequential(
+                ME.MinkowskiConvolution(self.inplanes, width, kernel_size=1, stride=stride, dimension=self.D),
+                ME.MinkowskiBatchNorm(width))
+        stack = []
+        for index in range(blocks):
+            first = index == 0
+            stack.append(block(self.inplanes if first else width, planes, stride=stride if first else 1,
+                               dilation=dilation, downsample=shortcut if first else None, dimension=self.D,
+                               expand_coordinates=expand_coordinates))
+        self.inplanes = width
+        return nn.Sequential(*stack)

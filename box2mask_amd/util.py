@@ -1,51 +1,57 @@
-"""Box-format helpers restating /root/reference/utils/util.py:46-70,94-98,123-130 (device-agnostic
-torch glue around the hot path; no heavy compute)."""
-from __future__ import annotations
+"""Box-format and bookkeeping helpers of the votes -> masks path.
 
-import copy
+Behavioural contract (names, argument order, result layout) = /root/reference/utils/util.py:46-70 (box
+corners), :94-98 (h/m/s split), :123-130 (dense pooling ids); the bodies are written from that contract and
+pinned by tests/golden/iou_nms.npz (`bbs_out`, `uniq_out`).
+"""
+from __future__ import annotations
 
 import numpy as np
 import torch
 
 
+def _corners(centers, half_extent, xp):
+    # [min corner | max corner], one row per box
+    return xp.cat((centers - half_extent, centers + half_extent), 1) if xp is torch else \
+        np.concatenate((centers - half_extent, centers + half_extent), 1)
+
+
 def to_bbs_min_max(locations, offsets, bounds, scores=None, use_torch=True):
-    """centre = location + offset; box = [centre - bounds, centre + bounds]; the score column is
-    PREPENDED -> (n,7) [score, min3, max3]  (util.py:46-64; the comment at util.py:45 says otherwise)."""
-    centers = offsets + locations
+    """Votes -> axis-aligned boxes: the voted centre is `locations + offsets`, `bounds` are half extents.
+    Result rows are [score, min xyz, max xyz] when a (n,1) score column is given, else [min xyz, max xyz]
+    (the score comes FIRST; the reference's comment at util.py:45 says otherwise, its code and every
+    consumer -- iou_nms.py:79 sorts by column 0 -- say this).  numpy inputs with use_torch=False give a
+    float64 array like the reference's np.zeros-based construction."""
     if use_torch:
-        bbs = torch.zeros((centers.shape[0], 6), device=centers.device, dtype=centers.dtype)
-        bbs[:, :3] = centers - bounds
-        bbs[:, 3:] = centers + bounds
-        if scores is not None:
-            bbs = torch.cat((scores, bbs), axis=1)
-    else:
-        bbs = np.zeros((centers.shape[0], 6))
-        bbs[:, :3] = centers - bounds
-        bbs[:, 3:] = centers + bounds
-        if scores is not None:
-            bbs = np.concatenate((scores, bbs), axis=1)
-    return bbs
+        centers = offsets + locations
+        boxes = _corners(centers, bounds, torch).to(torch.float32)
+        return boxes if scores is None else torch.cat((scores, boxes), 1)
+    centers = np.asarray(offsets) + np.asarray(locations)
+    boxes = _corners(centers, np.asarray(bounds), np).astype(np.float64)
+    return boxes if scores is None else np.concatenate((scores, boxes), 1)
 
 
 def to_bbs_min_max_(centers, bounds, device):
-    bounding_boxes = torch.zeros((bounds.shape[0], 6), device=device)
-    bounding_boxes[:, :3] = centers - bounds
-    bounding_boxes[:, 3:] = centers + bounds
-    return bounding_boxes
+    """Same corner layout from centres that are already absolute (loss code: model.py:98-100,147-150)."""
+    return _corners(centers, bounds, torch).to(device=device, dtype=torch.float32)
 
 
 def convertSecs(sec):
-    seconds = int(sec % 60)
-    minutes = int((sec / 60) % 60)
-    hours = int((sec / (60 * 60)))
-    return hours, minutes, seconds
+    """Seconds -> (hours, minutes, seconds) as ints; hours are not wrapped.  The three quotients are the float
+    expressions checkpoint file names were written with (training.py:229), so names round-trip."""
+    return tuple(int(v) for v in (sec / 3600, (sec / 60) % 60, sec % 60))
 
 
 def to_unique(segments):
-    """Dense pooling ids over a batch (util.py:123-130)."""
-    unique_segments = copy.deepcopy(segments)
-    for i in range(1, len(unique_segments)):
-        unique_segments[i] += np.max(unique_segments[i - 1]) + 1
-    unique_segments = np.concatenate(unique_segments, 0)
-    _, pooling_ids = np.unique(unique_segments, return_inverse=True)
-    return torch.from_numpy(pooling_ids.reshape(-1)).long()
+    """Per-scene segment id arrays -> one LongTensor of dense pooling ids over the batch: ids of scene i are
+    shifted past the largest id of scenes < i, then ranked (np.unique order).  The caller's arrays are not
+    modified."""
+    shifted, base = [], 0
+    for seg in segments:
+        seg = np.asarray(seg)
+        s = seg + base
+        shifted.append(s)
+        base = int(s.max()) + 1 if s.size else base
+    flat = np.concatenate(shifted, 0) if shifted else np.zeros(0, np.int64)
+    _, rank = np.unique(flat, return_inverse=True)
+    return torch.from_numpy(np.ascontiguousarray(rank.reshape(-1))).long()

@@ -136,6 +136,32 @@ def conv_nbr(x: torch.Tensor, w: torch.Tensor, nbr, bias: torch.Tensor | None = 
     return y
 
 
+def conv_nbr_explicit(x: torch.Tensor, w: torch.Tensor, nbr, gy: torch.Tensor | None = None):
+    """Forward and, given dL/dY, the data and weight gradients of `conv_nbr`, written out per offset from the
+    definition (no autograd tape, in-place accumulation) so that whole 150 k .. 1.2 M-row layers fit the host:
+        Y[o]    += X[i] W[k]          dX[i] += dY[o] W[k]^T          dW[k] = X[i]^T dY[o]      over pairs (i,o) of k.
+    tests/test_oracle_sparse.py checks it against autograd of `conv_nbr`.  Returns (y, dx, dw); dx/dw None without gy."""
+    nbr_t = torch.as_tensor(np.asarray(nbr), dtype=torch.long)
+    K, n_out = nbr_t.shape
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    with torch.no_grad():
+        y = torch.zeros(n_out, w3.shape[2], dtype=x.dtype)
+        dx = torch.zeros_like(x) if gy is not None else None
+        dw = torch.zeros_like(w3) if gy is not None else None
+        for k in range(K):
+            o = torch.nonzero(nbr_t[k] >= 0).reshape(-1)
+            if o.numel() == 0:
+                continue
+            i = nbr_t[k, o]
+            xi = x.index_select(0, i)
+            y.index_add_(0, o, xi @ w3[k])
+            if gy is not None:
+                go = gy.index_select(0, o)
+                dx.index_add_(0, i, go @ w3[k].t())
+                dw[k] = xi.t() @ go
+    return y, dx, (dw.reshape(w.shape) if dw is not None else None)
+
+
 def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5):
     """MinkowskiBatchNorm == BatchNorm1d on the feature matrix."""
     return torch.nn.functional.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)

@@ -1,0 +1,219 @@
+"""Parity of the sparse convolution in EVERY dispatch regime of csrc/conv.hip, at the sizes the benchmark runs, and
+against an independent dense reference.
+
+  1. forced regimes on the 12 k-row maps of test_gpu_ops: the un-split vector-store path that carries levels 0/1 in
+     the benchmark (B2M_CONV_TARGET=0), the atomic split-K combine, no chunk slices, the plain weight-gradient
+     kernel, 64-tile chunks in the pipelined weight-gradient kernel (the 64-lane `live` walk incl. lane 63), and
+     the non-XCD workgroup order;
+  2. whole layers at benchmark size -- one 150 k-voxel scene (k3 96->96, 128(96|32)->96, k5 6->32, 1x1 128->96)
+     and the 1.2 M-row batch of BASELINE configs[1] (k3 96->96) -- forward, data gradient, weight gradient
+     against oracle/sparse_ref.conv_nbr_explicit;
+  3. dense equivalence on RANDOM occupancy without the oracle: stride-1 maps == F.conv3d on the zero-filled
+     grid read at the active sites, k2s2 == F.conv3d(stride=2), the transposed k2s2 == F.conv_transpose3d masked
+     to the existing fine sites; gradients from torch autograd of the dense op
+     (/root/reference/models/resnet.py:61-65, detection_net.py:37-135).
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3        # north_star: conv features within 1e-3 fp32
+
+
+def _close(a, b, what, tol=TOL):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max()) / scale
+    assert err < tol, '%s: max rel-to-max error %.3e' % (what, err)
+    return err
+
+
+# ------------------------------------------------------------------ 1. forced dispatch regimes
+REGIMES = {
+    'unsplit': {'B2M_CONV_TARGET': '0'},
+    'atomic_combine': {'B2M_CONV_WGCOMBINE': '0'},
+    'no_chunk_slices': {'B2M_CONV_CHUNKSPLIT': '0'},
+    'many_slices': {'B2M_CONV_TARGET': '100000'},
+    'wgrad_plain': {'B2M_WGRAD_PIPE': '0'},
+    'wgrad_64_tile_chunks': {'B2M_WGRAD_MIN_TILES': '64'},
+    'no_xcd_order': {'B2M_XCD': '0'},
+    'unsplit_64bit': {'B2M_CONV_TARGET': '0', 'B2M_CONV_FAST32': '0', 'B2M_WGRAD_FAST32': '0'},
+}
+
+
+@pytest.fixture(scope='module')
+def maps():
+    from test_gpu_ops import _scene
+    from box2mask_amd.sparse import CoordinateManager
+    from oracle import sparse_ref as S
+    b = _scene()
+    m = CoordinateManager(b['vox_coords'])
+    h = S.Hierarchy(b['vox_coords'].numpy(), n_levels=3)
+    m.ensure_level(2)
+    return m, h
+
+
+def _regime_cases():
+    from test_gpu_ops import CONV_CASES
+    pick = [0, 1, 2, 3, 4, 5, 6, 8, 9]          # every rulebook kind: k3 (1 and 2 sources), k5, down, up
+    return [CONV_CASES[i] for i in pick]
+
+
+@pytest.mark.parametrize('regime', sorted(REGIMES))
+@pytest.mark.parametrize('kind,level,cins,cout,bias', _regime_cases())
+def test_conv_forced_regime(maps, monkeypatch, regime, kind, level, cins, cout, bias):
+    """The C library reads its switches at every call, so each regime is forced on the small maps."""
+    from test_gpu_ops import _conv_case
+    for k, v in REGIMES[regime].items():
+        monkeypatch.setenv(k, v)
+    _conv_case(maps, kind, level, cins, cout, bias)
+
+
+# ------------------------------------------------------------------ 2. benchmark-size layers
+@pytest.fixture(scope='module')
+def scene150k():
+    from box2mask_amd import synth
+    from box2mask_amd.sparse import CoordinateManager
+    b = synth.make_batch(1, seed0=3, target_voxels=150_000)
+    m = CoordinateManager(b['vox_coords'], reorder=True)      # Morton rows, as the network runs them
+    coords = m.coords[0].cpu().numpy()
+    return m, coords
+
+
+def _full_case(m, coords, ksize, c1, c2, cout, seed):
+    from box2mask_amd import functional as F_
+    from oracle import sparse_ref as S
+    n = len(coords)
+    cin = c1 + c2
+    K = ksize ** 3
+    torch.manual_seed(seed)
+    x = torch.randn(n, cin)
+    w = torch.randn(K, cin, cout) / (cin * min(K, 10)) ** 0.5 if K > 1 else torch.randn(cin, cout) / cin ** 0.5
+    gy = torch.randn(n, cout)
+    if K > 1:
+        rb = m.rulebook_same(0, ksize)
+        nbr = S.kernel_map_same(coords, ksize, 1)
+        yo, dxo, dwo = S.conv_nbr_explicit(x, w, nbr, gy)
+    else:
+        rb = None
+        yo = x @ w; dxo = gy @ w.t(); dwo = x.t() @ gy
+    xg = x.cuda().requires_grad_(True); wg = w.cuda().requires_grad_(True)
+    x1, x2 = (xg[:, :c1].contiguous(), xg[:, c1:].contiguous()) if c2 else (xg, None)
+    yg = F_.sparse_conv(x1, x2, wg, None, rb, rb, K > 1, n)
+    yg.backward(gy.cuda())
+    torch.cuda.synchronize()
+    e = (_close(yg, yo, 'forward'), _close(xg.grad, dxo, 'dgrad'), _close(wg.grad, dwo, 'wgrad'))
+    print('rows %d K %d %d->%d: fwd %.2e dgrad %.2e wgrad %.2e' % (n, K, cin, cout, *e))
+
+
+@pytest.mark.parametrize('ksize,c1,c2,cout', [(3, 96, 0, 96), (3, 96, 32, 96), (5, 6, 0, 32), (1, 128, 0, 96),
+                                              (3, 32, 0, 32)])
+def test_full_size_layer_150k(scene150k, ksize, c1, c2, cout):
+    m, coords = scene150k
+    _full_case(m, coords, ksize, c1, c2, cout, zlib.crc32(repr((ksize, c1, c2, cout)).encode()) % 1000)
+
+
+def test_full_size_layer_1p2m_rows():
+    """The level-0 map of the benchmark batch (8 scenes, ~1.2 M rows): un-split path over ~37 k items, XCD order
+    over the whole grid, weight-gradient chunks of 64 tiles."""
+    from box2mask_amd import synth
+    from box2mask_amd.sparse import CoordinateManager
+    b = synth.make_batch(8, seed0=0, target_voxels=150_000)
+    m = CoordinateManager(b['vox_coords'], reorder=True)
+    coords = m.coords[0].cpu().numpy()
+    assert len(coords) > 1_000_000
+    _full_case(m, coords, 3, 96, 0, 96, 11)
+
+
+# ------------------------------------------------------------------ 3. dense equivalence, random occupancy, no oracle
+def _random_sites(B, X, Y, Z, density, seed):
+    rng = np.random.default_rng(seed)
+    occ = rng.random((B, X, Y, Z)) < density
+    occ[:, 0, 0, 0] = True                       # pin the grid origin so that dense and sparse indices agree
+    c = np.argwhere(occ).astype(np.int32)
+    return c[rng.permutation(len(c))]            # rows in random order
+
+
+def _dense_weight(w, k):
+    """(K,Cin,Cout), offset index x-fastest -> conv3d weight (Cout,Cin,kx,ky,kz) for a dense [b,c,x,y,z] grid."""
+    K, ci, co = w.shape
+    return w.reshape(k, k, k, ci, co).permute(4, 3, 2, 1, 0).contiguous()
+
+
+def _scatter_dense(feat, coords, shape, ts=1):
+    B, X, Y, Z = shape
+    d = torch.zeros(B, feat.shape[1], X, Y, Z, dtype=feat.dtype)
+    c = torch.as_tensor(coords).long()
+    d[c[:, 0], :, c[:, 1] // ts, c[:, 2] // ts, c[:, 3] // ts] = feat
+    return d
+
+
+def _read_dense(d, coords, ts=1):
+    c = torch.as_tensor(coords).long()
+    return d[c[:, 0], :, c[:, 1] // ts, c[:, 2] // ts, c[:, 3] // ts]
+
+
+@pytest.mark.parametrize('ksize,level,cin,cout', [(3, 0, 32, 48), (3, 0, 96, 96), (5, 0, 6, 32), (3, 1, 64, 64)])
+def test_dense_equivalence_stride1_random_occupancy(ksize, level, cin, cout):
+    from box2mask_amd import functional as F_
+    from box2mask_amd.sparse import CoordinateManager
+    shape = (2, 44, 36, 28) if cin * cout < 96 * 96 else (2, 32, 28, 24)      # keeps the dense fp64 reference at seconds
+    c0 = _random_sites(*shape, 0.3, 17 + ksize + level)
+    m = CoordinateManager(torch.from_numpy(c0))
+    m.ensure_level(level)
+    coords = m.coords[level].cpu().numpy()
+    ts = 1 << level
+    n = len(coords)
+    gshape = (shape[0],) + tuple((s + ts - 1) // ts for s in shape[1:])
+    torch.manual_seed(ksize * 10 + level)
+    x = torch.randn(n, cin, dtype=torch.float64)
+    w = torch.randn(ksize ** 3, cin, cout, dtype=torch.float64) / (cin * 10) ** 0.5
+    gy = torch.randn(n, cout, dtype=torch.float64)
+    xd = x.clone().requires_grad_(True); wd = w.clone().requires_grad_(True)
+    yd = _read_dense(F.conv3d(_scatter_dense(xd, coords, gshape, ts), _dense_weight(wd, ksize), padding=ksize // 2), coords, ts)
+    yd.backward(gy)
+    rb = m.rulebook_same(level, ksize)
+    xg = x.float().cuda().requires_grad_(True); wg = w.float().cuda().requires_grad_(True)
+    yg = F_.sparse_conv(xg, None, wg, None, rb, rb, True, n)
+    yg.backward(gy.float().cuda())
+    _close(yg, yd, 'forward'); _close(xg.grad, xd.grad, 'dgrad'); _close(wg.grad, wd.grad, 'wgrad')
+
+
+@pytest.mark.parametrize('cin,cout', [(32, 32), (96, 64)])
+def test_dense_equivalence_k2s2_and_transpose_random_occupancy(cin, cout):
+    from box2mask_amd import functional as F_
+    from box2mask_amd.sparse import CoordinateManager
+    shape = (2, 44, 36, 28)                                   # even sides: coarse cells align with the dense stride-2 grid
+    c0 = _random_sites(*shape, 0.25, 23)
+    m = CoordinateManager(torch.from_numpy(c0))
+    m.ensure_level(1)
+    fine, coarse = m.coords[0].cpu().numpy(), m.coords[1].cpu().numpy()
+    cshape = (shape[0],) + tuple(s // 2 for s in shape[1:])
+    nf, nc = len(fine), len(coarse)
+    torch.manual_seed(cin)
+    # ---- strided convolution fine -> coarse
+    x = torch.randn(nf, cin, dtype=torch.float64); w = torch.randn(8, cin, cout, dtype=torch.float64) / cin ** 0.5
+    gy = torch.randn(nc, cout, dtype=torch.float64)
+    xd = x.clone().requires_grad_(True); wd = w.clone().requires_grad_(True)
+    yd = _read_dense(F.conv3d(_scatter_dense(xd, fine, shape), _dense_weight(wd, 2), stride=2), coarse, 2)
+    yd.backward(gy)
+    xg = x.float().cuda().requires_grad_(True); wg = w.float().cuda().requires_grad_(True)
+    yg = F_.sparse_conv(xg, None, wg, None, m.rulebook_down(0), m.rulebook_up(0), False, nc)
+    yg.backward(gy.float().cuda())
+    _close(yg, yd, 'down forward'); _close(xg.grad, xd.grad, 'down dgrad'); _close(wg.grad, wd.grad, 'down wgrad')
+    # ---- transposed convolution coarse -> the EXISTING fine sites
+    x = torch.randn(nc, cin, dtype=torch.float64); w = torch.randn(8, cin, cout, dtype=torch.float64) / cin ** 0.5
+    gy = torch.randn(nf, cout, dtype=torch.float64)
+    xd = x.clone().requires_grad_(True); wd = w.clone().requires_grad_(True)
+    wt = wd.reshape(2, 2, 2, cin, cout).permute(3, 4, 2, 1, 0).contiguous()       # conv_transpose3d: (Cin,Cout,kx,ky,kz)
+    yd = _read_dense(F.conv_transpose3d(_scatter_dense(xd, coarse, cshape, 2), wt, stride=2), fine)
+    yd.backward(gy)
+    xg = x.float().cuda().requires_grad_(True); wg = w.float().cuda().requires_grad_(True)
+    yg = F_.sparse_conv(xg, None, wg, None, m.rulebook_up(0), m.rulebook_down(0), False, nf)
+    yg.backward(gy.float().cuda())
+    _close(yg, yd, 'up forward'); _close(xg.grad, xd.grad, 'up dgrad'); _close(wg.grad, wd.grad, 'up wgrad')

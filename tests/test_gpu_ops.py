@@ -1,4 +1,6 @@
 """GPU parity of the individual operators (conv fwd / dgrad / wgrad, BN, pooling) against the oracle."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -65,7 +67,7 @@ def _conv_case(maps, kind, level, cins, cout, bias):
     m, h = maps
     c1, c2 = cins
     cin = c1 + c2
-    torch.manual_seed(hash((kind, level, cin, cout)) % 1000)
+    torch.manual_seed(zlib.crc32(repr((kind, level, cin, cout)).encode()) % 1000)     # stable across processes
     if kind == 'k3':
         rb_f = rb_b = m.rulebook_same(level, 3); nbr = h.k3(level); K = 27; mirror = True; n_in = n_out = h.n(level)
     elif kind == 'k5':

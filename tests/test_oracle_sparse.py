@@ -185,3 +185,30 @@ def _random_params(cfg):
         conv(head + '.3', 1, 96, 96, True); bn(head + '.5', 96)
         conv(head + '.6', 1, 96, od, True)
     return p
+
+
+def test_explicit_gradients_equal_autograd():
+    """conv_nbr_explicit (the tape-free form used for full-size layers) == autograd of conv_nbr."""
+    rng = np.random.default_rng(5)
+    c = np.unique(rng.integers(0, 12, (900, 4)), axis=0).astype(np.int32)
+    c[:, 0] %= 2
+    c = np.unique(c, axis=0)
+    nbr = S.kernel_map_same(c, 3, 1)
+    torch.manual_seed(5)
+    x = torch.randn(len(c), 7, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(27, 7, 5, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(len(c), 5, dtype=torch.float64)
+    y = S.conv_nbr(x, w, nbr)
+    y.backward(gy)
+    y2, dx2, dw2 = S.conv_nbr_explicit(x.detach(), w.detach(), nbr, gy)
+    assert torch.allclose(y2, y.detach(), atol=1e-12)
+    assert torch.allclose(dx2, x.grad, atol=1e-12) and torch.allclose(dw2, w.grad, atol=1e-12)
+    # strided map (different in/out row counts)
+    cc, parent, koff = S.stride_coords(c, 1)
+    tab = S.child_table(parent, koff, len(cc))
+    x = torch.randn(len(c), 4, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(8, 4, 6, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(len(cc), 6, dtype=torch.float64)
+    y = S.conv_nbr(x, w, tab); y.backward(gy)
+    y2, dx2, dw2 = S.conv_nbr_explicit(x.detach(), w.detach(), tab, gy)
+    assert torch.allclose(y2, y.detach(), atol=1e-12) and torch.allclose(dx2, x.grad, atol=1e-12) and torch.allclose(dw2, w.grad, atol=1e-12)

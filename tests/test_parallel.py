@@ -32,9 +32,59 @@ def _worker(rank, world, port, q):
     x = torch.randn(5, 8)
     for it in range(2):                                   # two steps: the hook state must reset
         net.zero_grad(set_to_none=(it == 1))
-        net(x).pow(2).sum().backward()
-        dp.all_reduce_mean()
+        net(x).pow(2).sum().backward()                    # the reference's loop: nothing between backward() and step()
     out['grads'] = [p.grad.clone() for p in net.parameters()]
+    dp.all_reduce_mean()                                  # explicit call after the fact: must be a no-op
+    out['grads_again'] = [p.grad.clone() for p in net.parameters()]
+    # --- a parameter that receives no gradient keeps .grad None, the others are still averaged
+    net3 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    net3.load_state_dict(net.state_dict())
+    unused = torch.nn.Parameter(torch.ones(3))
+    dp3 = GradAllReduce(list(net3.parameters()) + [unused], bucket_bytes=256, overlap=True)
+    net3(x).pow(2).sum().backward()
+    assert unused.grad is None
+    out['grads3'] = [p.grad.clone() for p in net3.parameters()]
+    # --- gradient arena: operators write into slots of one flat buffer, the all-reduce runs in place on bucket ranges
+    from box2mask_amd.grad_arena import GradArena, grad_slot
+
+    class ArenaLinear(torch.autograd.Function):           # stands in for the HIP operators (they need a GPU)
+        @staticmethod
+        def forward(ctx, inp, w):
+            ctx.save_for_backward(inp, w)
+            return inp @ w
+
+        @staticmethod
+        def backward(ctx, g):
+            inp, w = ctx.saved_tensors
+            dw = grad_slot(w)
+            if dw is None:
+                dw = torch.zeros_like(w)
+            dw += inp.t() @ g                             # accumulate into the pre-zeroed slot
+            return g @ w.t(), dw
+
+    torch.manual_seed(1)
+    ws = [torch.nn.Parameter(torch.randn(8, 8) * 0.3) for _ in range(5)]
+    arena = GradArena(ws)
+    dpa = GradAllReduce(ws, bucket_bytes=600, overlap=True, arena=arena)
+    assert len(dpa.buckets) >= 2
+
+    def run():
+        arena.begin_pass()
+        h = x
+        for w_ in ws:
+            h = torch.tanh(ArenaLinear.apply(h, w_))
+        h.pow(2).sum().backward()
+    run()
+    base = arena.buffers[0].data_ptr()
+    out['arena_in_place'] = all(w_.grad.data_ptr() == base + 4 * arena.offset[id(w_)] for w_ in ws)
+    out['arena_g1'] = [w_.grad.clone() for w_ in ws]
+    run()                                                 # gradients kept: second pass goes to the other buffer and adds up
+    out['arena_g2'] = [w_.grad.clone() for w_ in ws]
+    for w_ in ws:
+        w_.grad = None
+    run()                                                 # after zero_grad(set_to_none): buffer 0 again
+    out['arena_g3'] = [w_.grad.clone() for w_ in ws]
+    out['arena_ws'] = [w_.detach().clone() for w_ in ws]
     out['x'] = x
     # --- no-overlap path gives the same result
     net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
@@ -93,6 +143,24 @@ def test_world_size_2_gloo():
         for r in (a, b):
             assert torch.allclose(r['grads'][i], ref, atol=1e-6)
             assert torch.allclose(r['grads2'][i], ref, atol=1e-6)
+            assert torch.equal(r['grads_again'][i], r['grads'][i])
+            assert torch.allclose(r['grads3'][i], ref, atol=1e-6)
+    # arena path: in place, equal to the single-process mean; kept gradients add up; buffer reuse after zero_grad
+    assert a['arena_in_place'] and b['arena_in_place']
+    ws = [w.clone().requires_grad_(True) for w in a['arena_ws']]
+    gsum = None
+    for x in (a['x'], b['x']):
+        h = x
+        for w in ws:
+            h = torch.tanh(h @ w)
+        g = torch.autograd.grad(h.pow(2).sum(), ws)
+        gsum = g if gsum is None else [u + v for u, v in zip(gsum, g)]
+    for i in range(len(ws)):
+        ref = gsum[i] / 2
+        for r in (a, b):
+            assert torch.allclose(r['arena_g1'][i], ref, atol=1e-6)
+            assert torch.allclose(r['arena_g2'][i], 2 * ref, atol=1e-6)
+            assert torch.allclose(r['arena_g3'][i], ref, atol=1e-6)
     feats = torch.cat([a['bn'][2], b['bn'][2]])
     for r in (a, b):
         s, cnt, _ = r['bn']
