@@ -79,13 +79,20 @@ def main():
     ap.add_argument('--batch-size', type=int, default=8, help='scenes per GPU (configs/scannet.txt: 8)')
     ap.add_argument('--target-voxels', type=int, default=150_000)
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing')
-    ap.add_argument('--cpu-voxels', type=int, default=40_000, help='voxels per scene of the CPU baseline sample')
-    ap.add_argument('--cpu-scenes', type=int, default=2, help='scenes in the CPU baseline sample')
+    ap.add_argument('--cpu-voxels', type=int, default=150_000, help='voxels per scene of the CPU baseline sample (default: the metric\'s scene size)')
+    ap.add_argument('--cpu-scenes', type=int, default=1, help='scenes in the CPU baseline sample')
     ap.add_argument('--detail', type=int, default=0, help='1 prints a per-layer-shape table of the conv launches to stderr')
     ap.add_argument('--cpu-timeout', type=int, default=240, help='seconds after which the CPU baseline is abandoned')
     ap.add_argument('--votes', type=int, default=1, help='0 skips the votes -> instance masks leg (outside the timed steps)')
     ap.add_argument('--prepare', type=int, default=1, help='0 skips the raw points -> device batch leg (outside the timed steps)')
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N rank processes here, BEFORE this process makes any
+    # GPU call (children via subprocess; a process that has initialised the GPU must never exec another program).
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.gpus > 1 and int(os.environ['WORLD_SIZE']) != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%s' % (args.gpus, os.environ['WORLD_SIZE']))
 
     # The CPU baseline runs FIRST, before this process touches the GPU (pure torch-CPU oracle, rank 0, N=1 only).
     cpu_result = None
@@ -99,7 +106,8 @@ def main():
     from box2mask_amd.parallel import init_distributed
 
     rank, world = init_distributed()
-    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node == --gpus'
+    if world != args.gpus:
+        sys.exit('bench.py: started as %d rank(s) but --gpus %d' % (world, args.gpus))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -136,8 +144,7 @@ def main():
     def step():
         opt.zero_grad()                 # torch default (set_to_none=True), as the reference's train_step
         losses = model.compute_loss(batch, 150)
-        losses['optimization_loss'].backward()
-        model.sync_gradients()
+        losses['optimization_loss'].backward()      # (N > 1: the gradient all-reduce completes inside backward)
         opt.step()
         return losses
 
@@ -166,6 +173,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(losses['optimization_loss'].item())
+    peak_mem_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+
+    # ---- the same K steps with the batch handed over as pinned HOST buffers (SURVEY 8d defines the metric with the
+    # H2D copy; `value` stays the HBM-resident rate, this one is reported beside it)
+    host_keys = ('vox_coords', 'vox_features', 'pooling_ids', 'input_location', 'gt_bb_offsets', 'gt_bb_bounds',
+                 'gt_semantics', 'fg_instances', 'batch_ids')
+    dev_batch = dict(batch)
+    pinned = {k: batch[k].cpu().pin_memory() for k in host_keys}
+    h2d_bytes = sum(v.numel() * v.element_size() for v in pinned.values())
+    timer.enabled = False
+
+    def step_h2d():
+        for k in host_keys:
+            batch[k] = pinned[k].to(dev, non_blocking=True)
+        return step()
+    step_h2d()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_h = time.perf_counter()
+    for _ in range(args.steps):
+        step_h2d()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed_h2d = time.perf_counter() - t_h
+    if world > 1:
+        t = torch.tensor([elapsed_h2d], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_h2d = float(t.item())
+    batch.update(dev_batch)
 
     if rank != 0:
         if world > 1:
@@ -202,24 +240,30 @@ def main():
         for key, d in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
             print('%-11s %4d %4d %4d %9d %6d %9.3f %8.2f' % (key + (d[2] // args.steps, d[0] / args.steps, d[1] / d[0] / 1e9 if d[0] else 0)), file=sys.stderr)
 
-    # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py; FETCH_SIZE x2
-    # on gfx950 + WRITE_SIZE, as MI355X_MICROARCH.md prescribes); None when the file is absent
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
-    except (OSError, ValueError):
-        pmc = {}
+    # HBM-side bytes per launch: NOT measured in this run -- read from the newest committed summary of two separate
+    # `rocprofv3 --pmc` passes of this same command (tools/pmc_traffic.py; FETCH_SIZE x2 on gfx950 + WRITE_SIZE, as
+    # MI355X_MICROARCH.md prescribes).  `traffic_source` names the file; None when there is none.
+    import glob
+    pmc, pmc_src = {}, None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json'))):
+        try:
+            pmc, pmc_src = json.load(open(f)), 'committed PMC passes: profiles/' + os.path.basename(f)
+        except (OSError, ValueError):
+            pass
 
     def roof(a, kernel=None):
         tf = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] > 0 else 0.0
         return {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                 'traffic': pmc.get(kernel, {}).get('traffic_bytes'),
+                'traffic_source': pmc_src if pmc.get(kernel, {}).get('traffic_bytes') is not None else None,
                 'algorithmic_bytes': round(a.get('bytes', 0.0) / max(a['launches'], 1)),
                 'launches_per_step': a['launches'] // max(args.steps, 1),
                 'avg_launch_ms': round(a['ms'] / max(a['launches'], 1), 4),
                 'gflop_per_step': round(a['flops'] / max(args.steps, 1) / 1e9, 2),
                 'ms_per_step': round(a['ms'] / max(args.steps, 1), 3)}
 
+    scenes = world * args.batch_size * args.steps
     fwd = agg.get('b2m_conv_fwd', dict(ms=0.0, flops=0.0, launches=0))
     wg = agg.get('b2m_conv_wgrad', dict(ms=0.0, flops=0.0, launches=0))
     roofline = roof(fwd, 'conv_fwd_kernel')
@@ -227,13 +271,16 @@ def main():
     roofline_wgrad = roof(wg, 'conv_wgrad_kernel')
     roofline_wgrad['kernel'] = 'conv_wgrad_kernel + conv_wgrad_pipe_kernel'
 
-    scenes = world * args.batch_size * args.steps
     value = scenes / elapsed
     result = {
         'metric': 'ScanNet scenes/sec (fwd+bwd, ~150k voxels @2cm)', 'value': round(value, 3), 'unit': 'scenes/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        # the same steps with the batch arriving in pinned host memory (PCIe copy inside the timed region)
+        'value_incl_h2d': round(scenes / elapsed_h2d, 3), 'h2d_mb_per_step': round(h2d_bytes / 1e6, 1),
+        # /root/reference/README.md:102 quotes "~48GB GPURAM" for this batch size on MinkowskiEngine
+        'peak_mem_gb': round(peak_mem_gb, 2),
         'config': {'workload': 'ScanNet 2cm voxels, batch_size=%d per GPU, sparse-conv fwd/bwd + losses + Adam '
                                '(BASELINE configs[1])' % args.batch_size,
                    'global_batch': world * args.batch_size, 'voxels_per_scene': n_vox // args.batch_size,
@@ -246,6 +293,7 @@ def main():
                               'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                               'frac': round(hbm['bytes'] / max(hbm['ms'], 1e-9) / 1e6 / PEAK_HBM_GBS, 4),
                               'traffic': pmc.get('bn_apply_kernel', {}).get('traffic_bytes'),
+                              'traffic_source': pmc_src if pmc.get('bn_apply_kernel', {}).get('traffic_bytes') is not None else None,
                               'algorithmic_bytes': round(hbm['bytes'] / max(hbm['launches'], 1)),
                               'launches_per_step': hbm['launches'] // max(args.steps, 1),
                               'kernel': 'bn_apply_kernel'},
@@ -266,6 +314,27 @@ def main():
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+
+
+def spawn_ranks(n):
+    """One process per GPU on this node, rendezvous on 127.0.0.1; rank 0's JSON line goes to our stdout.
+    torch.cuda.device_count() does not initialise the GPU on this image, so it is safe to call here."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print('bench.py: --gpus %d requested but only %d device(s) are visible' % (n, have), file=sys.stderr)
+        return 2
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def votes_leg(model, batch, cfg, cpu):
@@ -393,8 +462,8 @@ def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
 
 
 def cpu_baseline(n_scenes, voxels, timeout_s, ref_voxels):
-    """Coordinate/kernel-map build + forward + backward of a small synthetic batch on the CPU oracle
-    (torch CPU, per-offset index_select -> mm -> index_add_), scaled to 150k-voxel scenes per second.
+    """Coordinate/kernel-map build + forward + backward of ONE full-size synthetic scene (the metric's ~150 k voxels,
+    no scaling) on the CPU oracle (torch CPU, per-offset index_select -> mm -> index_add_): scenes per second.
     Threads: min(16, cores available) -- the reference pins MinkowskiEngine's CPU path to
     OMP_NUM_THREADS=16 (/root/reference/config_loader.py:3-4).  Abandoned after `timeout_s` seconds."""
     import signal
@@ -432,7 +501,7 @@ def cpu_baseline(n_scenes, voxels, timeout_s, ref_voxels):
         loss = sum(v.abs().mean() for k, v in out.items())
         loss.backward()
         dt = time.perf_counter() - t0
-        value = round((nvox / float(ref_voxels)) / dt, 5)
+        value = round(n_scenes / dt, 5)
         note = '%.1f s' % dt
     except _Timeout:
         value, note = None, 'abandoned after %d s' % timeout_s
@@ -440,11 +509,9 @@ def cpu_baseline(n_scenes, voxels, timeout_s, ref_voxels):
         signal.alarm(0)
         signal.signal(signal.SIGALRM, old)
     return {'value': value, 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d synthetic scenes of ~%d voxels (%d voxels in all, seeds 0..%d): coordinate/kernel-map build + '
-                      'forward + backward on the CPU oracle (oracle/unet_ref.py, torch %s, %d threads): %s; value = '
-                      '(voxels / %d) / seconds, i.e. scaled to %dk-voxel scenes'
-                      % (n_scenes, voxels, nvox, n_scenes - 1, torch.__version__, cores, note, ref_voxels,
-                         ref_voxels // 1000)}
+            'sample': '%d synthetic scene(s) of the metric\'s size (%d voxels in all, seed 0..%d; no scaling): coordinate/'
+                      'kernel-map build + forward + backward on the CPU oracle (oracle/unet_ref.py, torch %s, %d threads): '
+                      '%s; value = scenes / seconds' % (n_scenes, nvox, n_scenes - 1, torch.__version__, cores, note)}
 
 
 if __name__ == '__main__':

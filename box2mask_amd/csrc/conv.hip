@@ -28,8 +28,8 @@ struct ConvArgs {
     const float* zeros;   // address of g_zeros passed as data (a select of addresses, not a branch around the load)
     int ncs;         // chunk slices: a slice is (offset slice, part ncs of the input-channel chunks); nslice % ncs == 0
     int wg_combine;  // nslice % 4 == 0: the 4 waves of a workgroup are 4 slices of one item and add up in LDS first
-    int64_t nwg;     // workgroups of work; the grid is padded to 8 * xcd_per
-    int64_t xcd_per; // > 0: XCD-aware order, see wg_index()
+    int64_t nwg;     // workgroups of work; the grid is padded, see xcd_order()
+    int64_t xcd_per; // > 0: XCD-aware order in chunks of this many workgroups, see wg_index()
 };
 
 // loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
@@ -58,12 +58,30 @@ extern "C" int b2m_debug_stamps(unsigned long long* out8, int reset) {   // out8
 #endif
 
 // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  Consecutive
-// tiles are neighbours in space (Morton row order) and gather largely the same input rows, so each XCD gets one
-// CONTIGUOUS range of the work: hardware workgroup b does work item (b % 8) * per + b / 8.  With the plain order the
-// same rows were fetched into up to 8 L2s (PMC: L2-miss traffic 3.6x the algorithmic bytes of conv_fwd).
-__device__ __forceinline__ int64_t wg_index(int64_t nwg, int64_t xcd_per) {
-    if (xcd_per <= 0) return blockIdx.x;
-    const int64_t v = (int64_t)(blockIdx.x & 7) * xcd_per + (blockIdx.x >> 3);
+// tiles are neighbours in space (Morton row order) and gather largely the same input rows, so an XCD should work on
+// CONTIGUOUS runs of the work -- with the plain order the same rows were fetched into up to 8 L2s (PMC: L2-miss
+// traffic 3.6x the algorithmic bytes of conv_fwd).  The work is cut into chunks of `chunk` workgroups and XCD x takes
+// chunks x, x+8, x+16, ...: hardware workgroup b = 8*j + x does work item ((j / chunk) * 8 + x) * chunk + j % chunk.
+// Default: one chunk per XCD (contiguous eighths).  Work per tile varies over a scene, so the eighths differ in total
+// work (up to 8 % on 4 scenes, 5 % on the 8 scenes of the benchmark); finer chunks (B2M_XCD_TILES=32) even that out
+// but measured 0-2 % SLOWER in the training step -- L2 locality is worth more than the balance
+// (profiles/r02_pipe_analysis.md).
+struct XcdOrder { int64_t chunk; unsigned grid; };
+static inline XcdOrder xcd_order(int64_t nwg, int64_t chunk_pref) {
+    XcdOrder o;
+    if (chunk_pref <= 0 || nwg <= 0) { o.chunk = 0; o.grid = (unsigned)nwg; return o; }
+    int64_t chunk = chunk_pref;
+    const int64_t eighth = cdiv64(nwg, 8);
+    if (chunk > eighth) chunk = eighth;                    // small launches: one chunk per XCD (the round-1 order)
+    const int64_t nchunks = cdiv64(nwg, chunk);
+    o.chunk = chunk;
+    o.grid = (unsigned)(cdiv64(nchunks, 8) * chunk * 8);
+    return o;
+}
+__device__ __forceinline__ int64_t wg_index(int64_t nwg, int64_t chunk) {
+    if (chunk <= 0) return blockIdx.x;
+    const int64_t x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int64_t v = ((j / chunk) * 8 + x) * chunk + (j % chunk);
     return v < nwg ? v : -1;
 }
 
@@ -372,6 +390,8 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 #endif
 }
 
+#include "conv_fwd_pipe.h"
+
 static int env_flag(const char* name, int dflt);
 static inline int conv_kc(int cin) { return cin >= 16 ? 16 : 8; }
 // strip width in 16-column tiles: 48-column strips for the 96-channel spatial layers (A fragments reused 3x:
@@ -577,9 +597,54 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
         B2M_HIP(hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)cout * sizeof(float), (size_t)n_out, st));
     const int64_t items = items0 * nslice;
     a.nwg = cdiv64(items, 4);
-    a.xcd_per = env_flag("B2M_XCD", 1) ? cdiv64(a.nwg, 8) : 0;
-    const unsigned grid = (unsigned)(a.xcd_per > 0 ? a.xcd_per * 8 : a.nwg);
+    // XCD chunks of B2M_XCD_TILES tiles (default: contiguous eighths): a workgroup holds 4 (tile, strip, slice) items
+    const int64_t xcd_tiles = env_flag("B2M_XCD", 1) ? env_flag("B2M_XCD_TILES", 1 << 30) : 0;
+    const XcdOrder xo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / 4);
+    a.xcd_per = xo.chunk;
+    const unsigned grid = xo.grid;
     const bool ident = rb_in == nullptr;
+    // The shapes that carry the FLOPs -- real rulebook, whole 16-channel chunks, un-split map, 32-bit addressable --
+    // take the never-draining pipelined kernel (conv_fwd_pipe.h), D steps deep (B2M_CONV_PIPE = depth, 0 = off).
+    {
+        const int nc = cin / 16;
+        int depth = env_flag("B2M_CONV_PIPE", 2);
+        if (depth > 3) depth = 3;
+        if (depth == 3 && nc % 3 != 0) depth = 2;
+        if (depth >= 2 && !ident && fast && KC == 16 && nslice == 1 && a.fast32 && nc % depth == 0 && nc >= depth) {
+            const int wpb = env_flag("B2M_PIPE_WPB", 1) == 4 ? 4 : 1;      // waves per workgroup (1: every item frees its slot alone)
+            a.nwg = cdiv64(items, wpb);
+            const XcdOrder po = xcd_order(a.nwg, xcd_tiles * a.nstrips / wpb);
+            a.xcd_per = po.chunk;
+            const unsigned pgrid = po.grid;
+            const int skipg = env_flag("B2M_PIPE_SKIPG", 1);               // no gathers for absent row groups
+#define B2M_PIPE_LAUNCH(DV)                                                                                \
+            do {                                                                                           \
+                if (wpb == 4) {                                                                            \
+                    if (TW == 3) conv_fwd_pipe_kernel<DV, 3, 0, 4, false><<<pgrid, 256, 0, st>>>(a);       \
+                    else conv_fwd_pipe_kernel<DV, 2, 0, 4, false><<<pgrid, 256, 0, st>>>(a);               \
+                } else if (skipg) {                                                                        \
+                    if (TW == 3) conv_fwd_pipe_kernel<DV, 3, 0, 1, true><<<pgrid, 64, 0, st>>>(a);         \
+                    else conv_fwd_pipe_kernel<DV, 2, 0, 1, true><<<pgrid, 64, 0, st>>>(a);                 \
+                } else {                                                                                   \
+                    if (TW == 3) conv_fwd_pipe_kernel<DV, 3, 0, 1, false><<<pgrid, 64, 0, st>>>(a);        \
+                    else conv_fwd_pipe_kernel<DV, 2, 0, 1, false><<<pgrid, 64, 0, st>>>(a);                \
+                }                                                                                          \
+            } while (0)
+            const int dbg = env_flag("B2M_PIPE_DBG", 0);          // diagnostic builds, wrong results: tools/pipe_breakdown.py
+            if (dbg && TW == 3 && wpb == 1) {
+                switch (dbg) {
+                    case 2: conv_fwd_pipe_kernel<2, 3, 2><<<pgrid, 64, 0, st>>>(a); break;
+                    case 4: conv_fwd_pipe_kernel<2, 3, 4><<<pgrid, 64, 0, st>>>(a); break;
+                    default: conv_fwd_pipe_kernel<2, 3, 6><<<pgrid, 64, 0, st>>>(a); break;
+                }
+            } else
+            if (depth == 2) B2M_PIPE_LAUNCH(2);
+            else B2M_PIPE_LAUNCH(3);
+#undef B2M_PIPE_LAUNCH
+            B2M_LAUNCH_CHECK();
+            return B2M_OK;
+        }
+    }
     const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (fast ? 0 : 1);
     // chunks of loads in flight per wave: 2 pays on the 48-column-strip layers with >= 4 chunks (+7 % in the A/B of
     // tools/bench_conv.py), 1 elsewhere (narrow / 1x1 layers lose occupancy with 2)
@@ -942,8 +1007,11 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     a.nz = (a.nmb * a.nnb + 3) / 4;
     a.nwg = (int64_t)K * cdiv64(a.ntiles, tpc) * a.nz;
     B2M_CHECK_ARG(a.nwg < (1ll << 31) - 8, "too many workgroups");
-    a.xcd_per = env_flag("B2M_XCD", 1) ? cdiv64(a.nwg, 8) : 0;
-    dim3 grid((unsigned)(a.xcd_per > 0 ? a.xcd_per * 8 : a.nwg));
+    // work item = (k fastest, block group, tile chunk): a chunk of the XCD order = all offsets and blocks of
+    // B2M_XCD_WG_CHUNKS tile chunks (default: contiguous eighths)
+    const XcdOrder xo = xcd_order(a.nwg, env_flag("B2M_XCD", 1) ? (int64_t)env_flag("B2M_XCD_WG_CHUNKS", 1 << 20) * K * a.nz : 0);
+    a.xcd_per = xo.chunk;
+    dim3 grid(xo.grid);
     // 24-bit multiply operands and 32-bit byte offsets: rows < 2^24, row pitch < 2^22 floats, tensors < 4 GiB
     // (blocks may overhang cin/cout as long as the row PITCH covers them: the extra columns only feed dW rows /
     // columns that are never written)

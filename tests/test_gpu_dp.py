@@ -34,7 +34,6 @@ def _worker(rank, world, port, q):
     model.train()
     losses, pred = model.compute_loss_detection(batch, 150)
     losses['optimization_loss'].backward()
-    model.sync_gradients()
     g = torch.cat([p.grad.reshape(-1)[:64].cpu() for p in list(model.parameters())[:6]])
     q.put((rank, {'pred': {k: v.detach().cpu().numpy() for k, v in pred.items()}, 'grad': g.numpy(),
                   'loss': float(losses['optimization_loss'].item()), 'scenes': mine,

@@ -14,7 +14,7 @@ from box2mask_amd.sparse import CoordinateManager
 
 bs = int(os.environ.get('BS', '4'))
 b = synth.make_batch(bs, seed0=0)
-m = CoordinateManager(b['vox_coords'])
+m = CoordinateManager(b['vox_coords'], reorder=True)      # Morton rows, as the network runs them
 rb0 = m.rulebook_same(0, 3); m.ensure_level(7); rb1 = m.rulebook_same(1, 3); rbu = m.rulebook_up(0); rb5 = m.rulebook_same(0, 5)
 rb2 = m.rulebook_same(2, 3); rb3 = m.rulebook_same(3, 3); rb4 = m.rulebook_same(4, 3)
 rb5l = m.rulebook_same(5, 3); rb6 = m.rulebook_same(6, 3)
@@ -31,9 +31,9 @@ def timeit(fn, n=4):
 VARIANTS = [('base', {})]
 for spec in os.environ.get('VARIANTS', 'tw2:B2M_CONV_TW3=0;slow64:B2M_WGRAD_FAST32=0').split(';'):
     if spec:
-        name, kv = spec.split(':'); k_, v_ = kv.split('=')
-        VARIANTS.append((name, {k_: v_}))
-SWITCHES = ('B2M_CONV_TW3', 'B2M_CONV_NPF', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_WGRAD_BLK64', 'B2M_WGRAD_BLKBIG')
+        name, kvs = spec.split(':')
+        VARIANTS.append((name, dict(kv.split('=') for kv in kvs.split(','))))
+SWITCHES = ('B2M_XCD_TILES', 'B2M_XCD_WG_CHUNKS', 'B2M_CONV_PIPE', 'B2M_PIPE_WPB', 'B2M_PIPE_SKIPG', 'B2M_CONV_TW3', 'B2M_CONV_NPF', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_WGRAD_BLK64', 'B2M_WGRAD_BLKBIG')
 cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
          ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
          ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64),

@@ -1,0 +1,25 @@
+"""Launch time of the pipelined forward kernel with single components removed (diagnostic builds, wrong results):
+what do the strip flush, the gathers and the weight loads cost on the level-0 96->96 layer?"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from box2mask_amd import synth, functional as F_
+from box2mask_amd.sparse import CoordinateManager
+b = synth.make_batch(int(os.environ.get('BS', '4')), seed0=0)
+m = CoordinateManager(b['vox_coords'], reorder=True)
+rb = m.rulebook_same(0, 3)
+x = torch.randn(rb.n_in, 96, device='cuda'); w = torch.randn(27, 96, 96, device='cuda') * 0.05
+wp = F_.weight_pack(w)
+fl = 2.0 * rb.pairs * 96 * 96
+def t(n=5):
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    F_.conv_raw(x, None, wp, 27, None, rb, rb.n_out, 96); s.record()
+    for _ in range(n): F_.conv_raw(x, None, wp, 27, None, rb, rb.n_out, 96)
+    e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n
+for rnd in range(2):
+    for name, env in [('old kernel', {'B2M_CONV_PIPE': '0'}), ('pipe 4 waves/wg', {'B2M_PIPE_WPB': '4'}), ('pipe', {}), ('pipe depth 3', {'B2M_CONV_PIPE': '3'}), ('pipe -gathers', {'B2M_PIPE_DBG': '2'}),
+                      ('pipe -weights', {'B2M_PIPE_DBG': '4'}), ('pipe -gathers -weights', {'B2M_PIPE_DBG': '6'})]:
+        for k in ('B2M_CONV_PIPE', 'B2M_PIPE_DBG', 'B2M_PIPE_WPB'): os.environ.pop(k, None)
+        os.environ.update(env)
+        ms = t()
+        print('%-26s %.3f ms  %.1f TFLOP/s' % (name, ms, fl / ms / 1e9))

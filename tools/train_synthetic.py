@@ -77,7 +77,6 @@ def main(argv=None):
         opt.zero_grad()
         losses = model.compute_loss(batch, epoch=step)
         losses['optimization_loss'].backward()
-        model.sync_gradients()
         opt.step()
         if step % 10 == 0 or step == args.steps - 1:
             history.append((step, float(losses['optimization_loss'].detach())))
