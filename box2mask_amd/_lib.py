@@ -34,17 +34,18 @@ PROTOTYPES = {
     'b2m_conv_fwd': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],
     'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
     'b2m_weight_pack_run': [P, I32, I64, P],
-    'b2m_conv_wgrad': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P],
+    'b2m_conv_wgrad': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P, P],
     'b2m_bn_stats': [P, I64, I64, I32, P, P, P],
-    'b2m_bn_finalize': [P, F64, I32, P, P, F32, F32, P, P, P, P, P, P, P],
+    'b2m_bn_finalize': [P, F64, P, I32, P, P, F32, F32, P, P, P, P, P, P, P],
     'b2m_bn_apply': [P, I64, I64, I32, P, P, P, I64, I32, P, I64, P],
     'b2m_bn_bwd_reduce': [P, I64, P, I64, P, I64, I64, I32, P, P, I32, P, P, P, P, P, P, P],
     'b2m_bn_stats_finalize': [P, I64, I64, I32, P, P, P, P, F32, F32, P, P, P, P, P, P, P],
-    'b2m_bn_bwd_apply': [P, I64, P, I64, P, I64, I64, I32, P, P, P, P, F64, I32, P, P, P, I64, P, I64, P],
+    'b2m_bn_bwd_apply': [P, I64, P, I64, P, I64, I64, I32, P, P, P, P, F64, P, I32, P, P, P, I64, P, I64, P],
     'b2m_relu_fwd': [P, I64, P, P],
     'b2m_relu_bwd': [P, P, I64, P, P],
     'b2m_add': [P, P, I64, P, P],
     'b2m_segment_pool_fwd': [P, I64, I64, I32, P, I64, I32, P, P, P, P, P],
+    'b2m_segment_mean_sorted': [P, I64, I64, I32, P, P, I64, P, P, P],
     'b2m_segment_pool_bwd': [P, I64, I32, P, I64, I32, P, P, P, I64, P],
     'b2m_nmc': [P, I32, F32, I32, P, P, P, P, P, P],
     'b2m_mask_project': [P, I32, P, I32, P, P, I64, F32, P, I64, P],
@@ -68,6 +69,7 @@ PROTOTYPES = {
 }
 PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_device_ok': (C.c_int, []),
          'b2m_weight_pack_size': (C.c_int64, [I32, I32, I32]),
+         'b2m_conv_wgrad_workspace': (C.c_int64, [I32, I32, I32]),
          'b2m_unique_insert': (C.c_int64, [P, I64, P, I64, P, P, P, P]),
          'b2m_weight_pack_plan_size': (C.c_int32, []),
          'b2m_weight_pack_plan': (C.c_int64, [I32, P, P, P, P, P, P, P, P, P, P, P])}

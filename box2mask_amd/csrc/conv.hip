@@ -568,7 +568,8 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     // (more, smaller slices were measured too: 2-6x as many waves lose 0-60 % to the atomic combine)
     // 6144 rather than one wave per SIMD slot (4096): a map with ~4.3k items ran 1.05 rounds of waves at 50 TFLOP/s;
     // as 4 in-LDS-combined slices it runs at 61
-    const int64_t target = env_flag("B2M_CONV_TARGET", 6144);
+    // B2M_DETERMINISTIC=1: never split (the split-K combine of more than 4 slices adds with fp32 atomics)
+    const int64_t target = env_flag("B2M_DETERMINISTIC", 0) ? 0 : env_flag("B2M_CONV_TARGET", 6144);
     if (items0 < target && K > 1) {
         nslice = (int)cdiv64(target, items0);
         if (nslice > 16) nslice = 16;
@@ -686,6 +687,7 @@ struct WgradArgs {
     int64_t nwg, xcd_per;    // XCD-aware workgroup order (wg_index); work item = (k fastest, block group, tile chunk)
     int nz;                  // block groups of 4 (ci,co) blocks
     int pipe;                // software-pipelined kernel (real rulebook, fast32)
+    float* partial;          // deterministic mode: per tile-chunk partial dW (dense [chunk][K][cin][cout]), plain stores
 };
 
 template <int MI, int NJ>
@@ -801,9 +803,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 const int ci = ci0 + 16 * m + 4 * q + r, co = co0 + 16 * nn + i;
                 if (ci < a.cin && co < a.cout) {
                     const float v = acc[m][nn][r];
-                    if (v != 0.f) atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)ci * a.lddw + co], v);
+                    if (a.partial) a.partial[(((int64_t)chunk * a.K + k) * a.cin + ci) * a.cout + co] = v;
+                    else if (v != 0.f) atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)ci * a.lddw + co], v);
                 }
             }
+}
+// deterministic mode: dW += sum over the tile chunks of the partial blocks, in chunk order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int K, int cin, int cout,
+                                    float* __restrict__ dw, int64_t lddw, int64_t dw_kstride) {
+    const int64_t per = (int64_t)K * cin * cout;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) s += partial[(int64_t)ch * per + e];
+        const int co = (int)(e % cout); const int64_t e1 = e / cout;
+        const int ci = (int)(e1 % cin); const int k = (int)(e1 / cin);
+        dw[(int64_t)k * dw_kstride + (int64_t)ci * lddw + co] += s;
+    }
 }
 
 // Software-pipelined variant for the common case (real rulebook, complete blocks, 32-bit addressable operands).
@@ -973,9 +988,15 @@ static int pick_blk(int c) {      // 16-column sub-tiles per wave block
     return 4;
 }
 
+// tile chunks of the deterministic path: few, so that the partial buffer stays small
+#define B2M_WGRAD_DET_CHUNKS 32
+extern "C" int64_t b2m_conv_wgrad_workspace(int32_t K, int32_t cin, int32_t cout) {
+    return (int64_t)B2M_WGRAD_DET_CHUNKS * K * cin * cout;
+}
 extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
                               int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
-                              int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, void* stream) {
+                              int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace,
+                              void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(x && dy && dw && cin > 0 && cout > 0 && K >= 1 && K <= 65535 && n_in >= 0, "bad pointers/sizes");
     B2M_CHECK_ARG((rb_in == nullptr) == (rb_out == nullptr) && (rb_in == nullptr) == (rb_cnt == nullptr),
@@ -1003,6 +1024,10 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     int64_t tpc = cdiv64(a.ntiles, want_chunks);
     if (tpc < env_flag("B2M_WGRAD_MIN_TILES", 4)) tpc = env_flag("B2M_WGRAD_MIN_TILES", 4);
     if (tpc > 64) tpc = 64;
+    // Deterministic mode (workspace given): at most B2M_WGRAD_DET_CHUNKS tile chunks, every chunk stores its partial
+    // blocks plainly and a second kernel adds them up in chunk order -- no atomics, the same bits on every run.
+    a.partial = workspace;
+    if (workspace) tpc = cdiv64(a.ntiles, B2M_WGRAD_DET_CHUNKS);
     a.tiles_per_chunk = (int)tpc;
     a.nz = (a.nmb * a.nnb + 3) / 4;
     a.nwg = (int64_t)K * cdiv64(a.ntiles, tpc) * a.nz;
@@ -1020,9 +1045,15 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
                 env_flag("B2M_WGRAD_FAST32", 1)) ? 1 : 0;
     // A/B on one box (tools/bench_conv.py): +8..26 % on the 32/96/128-channel layers; the 64x64 blocks of the
     // 64-channel layers drop to 2 waves per SIMD and lose 10 %, they stay on the plain kernel
-    a.pipe = (a.fast32 && rb_in != nullptr && !(MI * NJ >= 16 && cin <= 64 && cout <= 64) &&
+    a.pipe = (a.fast32 && rb_in != nullptr && !(MI * NJ >= 16 && cin <= 64 && cout <= 64) && !workspace &&
               env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
     launch_wgrad(MI, NJ, grid, st, a);
+    if (workspace) {
+        const int nchunks = (int)cdiv64(a.ntiles, tpc);
+        const int64_t per = (int64_t)K * cin * cout;
+        wgrad_reduce_kernel<<<(unsigned)(cdiv64(per, 256) > 4096 ? 4096 : cdiv64(per, 256)), 256, 0, st>>>(
+            workspace, nchunks, K, cin, cout, dw, lddw, dw_kstride);
+    }
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -94,13 +94,15 @@ extern "C" int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, d
     return B2M_OK;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, int c, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count_host, const double* __restrict__ count_dev,
+                                   int c, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
                                    float* __restrict__ shift) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c) return;
+    const double count = count_dev ? *count_dev : count_host;      // SyncBN: the all-reduced row count stays on the device
     double m, var;
     if (stats) {
         m = stats[j] / count;
@@ -172,14 +174,14 @@ extern "C" int b2m_bn_stats_finalize(const float* x, int64_t ldx, int64_t n, int
     return B2M_OK;
 }
 
-extern "C" int b2m_bn_finalize(const double* stats, double count, int32_t c, const float* gamma, const float* beta,
+extern "C" int b2m_bn_finalize(const double* stats, double count, const double* count_dev, int32_t c, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var, float* mean,
                                float* invstd, float* scale, float* shift, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(c > 0 && scale && shift, "bad arguments");
     B2M_CHECK_ARG(stats || (running_mean && running_var), "eval mode needs running statistics");
-    B2M_CHECK_ARG(!stats || count >= 1, "count must be >= 1");
-    bn_finalize_kernel<<<(c + 255) / 256, 256, 0, st>>>(stats, count, c, gamma, beta, eps, momentum, running_mean,
+    B2M_CHECK_ARG(!stats || count_dev || count >= 1, "count must be >= 1 (or given on the device)");
+    bn_finalize_kernel<<<(c + 255) / 256, 256, 0, st>>>(stats, count, count_dev, c, gamma, beta, eps, momentum, running_mean,
                                                         running_var, mean, invstd, scale, shift);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
@@ -284,13 +286,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
-                                                           const double* __restrict__ sums, double count, int relu,
+                                                           const double* __restrict__ sums, double count_host,
+                                                           const double* __restrict__ count_dev, int relu,
                                                            const float* __restrict__ mscale,
                                                            const float* __restrict__ mshift,
                                                            float* __restrict__ dx, int64_t lddx,
                                                            float* __restrict__ dres, int64_t lddres) {
     const int c4 = c >> 2;
-    const float inv_n = (float)(1.0 / count);
+    const float inv_n = (float)(1.0 / (count_dev ? *count_dev : count_host));
     const int nslots = 256 / c4;
     const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
     if (rs >= nslots) return;
@@ -328,19 +331,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 extern "C" int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
                                 int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd,
-                                const float* gamma, const double* sums, double count, int32_t relu,
-                                const float* mask_scale, const float* mask_shift, float* dx, int64_t lddx, float* dres,
+                                const float* gamma, const double* sums, double count, const double* count_dev,
+                                int32_t relu, const float* mask_scale, const float* mask_shift, float* dx, int64_t lddx, float* dres,
                                 int64_t lddres, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y || (mask_scale && mask_shift)),
                   "NULL argument (relu needs y, or mask_scale and mask_shift)");
     B2M_CHECK_ARG(c > 0 && c % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || ldy % 4 == 0) &&
-                      (!dres || lddres % 4 == 0) && count >= 1,
+                      (!dres || lddres % 4 == 0) && (count_dev || count >= 1),
                   "c and leading dimensions must be multiples of 4");
     if (n == 0) return B2M_OK;
     B2M_CHECK_ARG(c <= 1024, "c <= 1024");
     bn_bwd_apply_kernel<<<row_grid(n, c / 4), 256, 0, st>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, sums,
-                                                             count, relu, y ? nullptr : mask_scale,
+                                                             count, count_dev, relu, y ? nullptr : mask_scale,
                                                              y ? nullptr : mask_shift, dx, lddx, dres, lddres);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
@@ -412,6 +415,39 @@ __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__
         atomicAdd(&out[cur * c + col], acc);
         if (col == 0) atomicAdd(&counts[cur], len);
     }
+}
+// Deterministic segment mean (B2M_DETERMINISTIC=1): rows arrive grouped by segment through `order` (stable sort of
+// the ids, done by the caller), one workgroup per segment, thread = channel, four interleaved partial sums combined
+// in a fixed association -- no atomics, the same bits on every run.
+__global__ __launch_bounds__(256) void pool_mean_sorted_kernel(const float* __restrict__ x, int64_t ldx, int c,
+                                                               const int64_t* __restrict__ order,
+                                                               const int64_t* __restrict__ seg_start,
+                                                               float* __restrict__ out, int32_t* __restrict__ counts) {
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = seg_start[s], r1 = seg_start[s + 1];
+    if (threadIdx.x == 0) counts[s] = (int32_t)(r1 - r0);
+    for (int col = threadIdx.x; col < c; col += blockDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            const int64_t i0 = order[r], i1 = order[r + 1], i2 = order[r + 2], i3 = order[r + 3];
+            a0 += x[i0 * ldx + col]; a1 += x[i1 * ldx + col]; a2 += x[i2 * ldx + col]; a3 += x[i3 * ldx + col];
+        }
+        for (; r < r1; ++r) a0 += x[order[r] * ldx + col];
+        const float sum = (a0 + a1) + (a2 + a3);
+        out[s * c + col] = r1 > r0 ? sum / (float)(r1 - r0) : 0.f;
+    }
+}
+extern "C" int b2m_segment_mean_sorted(const float* x, int64_t ldx, int64_t n, int32_t c, const int64_t* order,
+                                       const int64_t* seg_start, int64_t n_seg, float* out, int32_t* counts,
+                                       void* stream) {
+    B2M_CHECK_ARG(x && order && seg_start && out && counts && c > 0 && ldx >= c && n >= 0 && n_seg >= 0, "bad arguments");
+    if (n_seg == 0) return B2M_OK;
+    B2M_CHECK_ARG(n_seg < (1ll << 31), "too many segments");
+    pool_mean_sorted_kernel<<<(unsigned)n_seg, (unsigned)(c >= 256 ? 256 : (c + 63) / 64 * 64), 0, (hipStream_t)stream>>>(
+        x, ldx, c, order, seg_start, out, counts);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
 }
 __global__ void pool_div_kernel(float* __restrict__ out, const int32_t* __restrict__ counts, int64_t n_seg, int c) {
     const int64_t total = n_seg * c;

@@ -6,6 +6,7 @@ the MinkowskiEngine operator the reference calls (file:line cited per function; 
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -17,6 +18,27 @@ from .sparse import Rulebook
 
 _call = _lib.call
 _ptr = _lib.ptr
+
+
+def deterministic() -> bool:
+    """B2M_DETERMINISTIC=1: every order-dependent reduction of the path takes its ordered form -- two-stage weight-gradient
+    combine, un-split forward/data-gradient maps (no atomic split-K combine), sorted segment mean.  Same bits on every
+    run; slower on the small deep-level maps.  The library reads the same variable (csrc/conv.hip)."""
+    return os.environ.get('B2M_DETERMINISTIC', '0') == '1'
+
+
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(K, cin, cout, device):
+    """Partial-dW buffer of the deterministic weight gradient (grown on demand, shared by all layers: launches on one
+    stream run in order)."""
+    need = _lib.load().b2m_conv_wgrad_workspace(K, cin, cout)
+    ws = _wgrad_ws.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=device)
+        _wgrad_ws[device] = ws
+    return ws
 
 
 def _f32c(t):
@@ -157,8 +179,9 @@ def wgrad_raw(x, dy, rb: Rulebook | None, K: int, dw3, ci0: int, cin: int | None
         rbi = rbo = rbc = None
     else:
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
+    ws = _wgrad_workspace(K, cin, cout, x.device) if deterministic() else None
     _call('b2m_conv_wgrad', x.data_ptr(), x.stride(0), cin, x.shape[0], dy.data_ptr(), dy.stride(0), cout, rbi, rbo, rbc,
-          n_out, K, dw3.data_ptr() + 4 * ci0 * cout, cout, cin_total * cout)
+          n_out, K, dw3.data_ptr() + 4 * ci0 * cout, cout, cin_total * cout, _ptr(ws))
 
 
 class _SparseConv(torch.autograd.Function):
@@ -233,38 +256,16 @@ def _sync_group():
     return dist.group.WORLD if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
-def merge_bn_sums(local_sums: torch.Tensor, local_count: float, group=None, global_count: float | None = None):
-    """SyncBN statistics exchange: all-reduce (sum x, sum x^2[, count]) over the data-parallel group.
+def merge_bn_sums(local_sums: torch.Tensor, local_count: float, group=None):
+    """SyncBN statistics exchange: ONE all-reduce of (sum x, sum x^2, row count) over the data-parallel group.
     Device-agnostic (used by the world_size-2 gloo tests).  Replaces the per-layer collectives of
     torch.nn.SyncBatchNorm that ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm installs
-    (/root/reference/models/model.py:25).  When the caller already knows the global row count (it is the
-    same for every BN layer of a level, see `global_rows`) only the sums travel and no host sync is needed."""
-    if group is None:
-        return local_sums, float(local_count)
-    if global_count is not None:
-        dist.all_reduce(local_sums, op=dist.ReduceOp.SUM, group=group)
-        return local_sums, float(global_count)
+    (/root/reference/models/model.py:25).  Returns (global sums, global count) as tensors on the sums' device: the
+    count is consumed there (b2m_bn_finalize / b2m_bn_bwd_apply read it through a pointer), no host sync."""
     packed = torch.cat([local_sums, local_sums.new_tensor([float(local_count)])])
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-    return packed[:-1], float(packed[-1].item())
-
-
-_global_rows_cache = {}
-
-
-def global_rows(n_local: int, key, group):
-    """Number of rows over all ranks for a tensor family identified by `key` (e.g. (manager id, level)):
-    one small all-reduce + host read per key instead of one per BatchNorm layer."""
-    if group is None:
-        return float(n_local)
-    if key not in _global_rows_cache:
-        if len(_global_rows_cache) > 64:
-            _global_rows_cache.clear()
-        t = torch.tensor([float(n_local)], dtype=torch.float64,
-                         device='cuda' if torch.cuda.is_available() and dist.get_backend(group) == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        _global_rows_cache[key] = float(t.item())
-    return _global_rows_cache[key]
+    if group is not None:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed[:-1], packed[-1:]
 
 
 class _BatchNorm(torch.autograd.Function):
@@ -279,7 +280,7 @@ class _BatchNorm(torch.autograd.Function):
         dev = x.device
         scale = torch.empty(c, dtype=torch.float32, device=dev)
         shift = torch.empty(c, dtype=torch.float32, device=dev)
-        mean = invstd = None
+        mean = invstd = count_dev = None
         count = float(n)
         if training:
             partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
@@ -291,22 +292,25 @@ class _BatchNorm(torch.autograd.Function):
                       _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
                       invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
             else:
-                stats = torch.empty(2 * c, dtype=torch.float64, device=dev)
+                # SyncBN: local column sums and the local row count travel in one packed all-reduce; the global count
+                # is read by the kernels from device memory (no .item(), no per-level count exchange)
+                stats = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
                 _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), stats.data_ptr())
-                gcount = global_rows(n, count_key, group) if count_key is not None else None
-                stats, count = merge_bn_sums(stats, count, group, gcount)
-                _call('b2m_bn_finalize', stats.data_ptr(), count, c, _ptr(gamma), _ptr(beta), eps, momentum,
-                      _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
-                      shift.data_ptr())
+                stats[2 * c:].fill_(float(n))
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+                count_dev = stats[2 * c:]
+                _call('b2m_bn_finalize', stats.data_ptr(), 0.0, count_dev.data_ptr(), c, _ptr(gamma), _ptr(beta), eps,
+                      momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
+                      scale.data_ptr(), shift.data_ptr())
         else:
-            _call('b2m_bn_finalize', None, 1.0, c, _ptr(gamma), _ptr(beta), eps, momentum, running_mean.data_ptr(),
+            _call('b2m_bn_finalize', None, 1.0, None, c, _ptr(gamma), _ptr(beta), eps, momentum, running_mean.data_ptr(),
                   running_var.data_ptr(), None, None, scale.data_ptr(), shift.data_ptr())
         if residual is not None:
             residual = _f32c(residual)
         y = torch.empty_like(x)
         _call('b2m_bn_apply', x.data_ptr(), x.stride(0), n, c, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
               residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
-        ctx.training, ctx.relu, ctx.count, ctx.sync = training, relu, count, sync
+        ctx.training, ctx.relu, ctx.count, ctx.sync, ctx.count_dev = training, relu, count, sync, count_dev
         ctx.has_res = residual is not None
         if training:
             # without a fused residual the ReLU mask is the sign of fmaf(x, scale, shift): the backward recomputes it
@@ -349,7 +353,7 @@ class _BatchNorm(torch.autograd.Function):
             dist.all_reduce(gsums, op=dist.ReduceOp.SUM, group=group)
         _call('b2m_bn_bwd_apply', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), gsums.data_ptr(),
-              count, relu, _ptr(mscale), _ptr(mshift), dx.data_ptr(), dx.stride(0), _ptr(dres),
+              count, _ptr(ctx.count_dev), relu, _ptr(mscale), _ptr(mshift), dx.data_ptr(), dx.stride(0), _ptr(dres),
               dres.stride(0) if dres is not None else 0)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
                 None, None, None, None, None, dres, None, None, None)
@@ -399,8 +403,15 @@ class _SegmentPool(torch.autograd.Function):
         if mode == 1:
             argmax = torch.empty(max(n_seg * c, 1), dtype=torch.int32, device=dev)
             scratch = torch.empty(max(n_seg * c, 1), dtype=torch.int64, device=dev)
-        _call('b2m_segment_pool_fwd', x.data_ptr(), x.stride(0), n, c, ids.data_ptr(), n_seg, mode, out.data_ptr(),
-              counts.data_ptr(), _ptr(argmax), _ptr(scratch))
+        if mode == 0 and deterministic() and n_seg > 0:
+            order = torch.argsort(ids, stable=True)
+            seg_start = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(torch.bincount(ids, minlength=n_seg), 0, out=seg_start[1:])
+            _call('b2m_segment_mean_sorted', x.data_ptr(), x.stride(0), n, c, order.data_ptr(), seg_start.data_ptr(),
+                  n_seg, out.data_ptr(), counts.data_ptr())
+        else:
+            _call('b2m_segment_pool_fwd', x.data_ptr(), x.stride(0), n, c, ids.data_ptr(), n_seg, mode, out.data_ptr(),
+                  counts.data_ptr(), _ptr(argmax), _ptr(scratch))
         ctx.save_for_backward(ids, counts, argmax)
         ctx.n, ctx.c, ctx.n_seg, ctx.mode = n, c, n_seg, mode
         return out

@@ -149,9 +149,13 @@ int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int
  * Replaces [ME] ConvolutionBackward (weight part).  x: n_in rows indexed by rb_in (ldx, cin columns used),
  * dy: rows indexed by tile*TILE+rb_out.  dw element (k,ci,co) lives at dw[k*dw_kstride + ci*lddw + co]
  * (so a channel sub-block of a wider weight tensor can be targeted); the caller zeroes it. */
+/* workspace: NULL = the tile chunks add their dW blocks with fp32 atomics (fast, order-dependent last bits);
+ * non-NULL (b2m_conv_wgrad_workspace(K,cin,cout) floats) = deterministic two-stage combine: every chunk stores its
+ * partial blocks, a second kernel adds them in chunk order. */
+int64_t b2m_conv_wgrad_workspace(int32_t K, int32_t cin, int32_t cout);
 int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy, int32_t cout,
                    const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
-                   int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, void* stream);
+                   int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------- batch norm / elementwise (fp32, HBM-bound) */
 
@@ -170,8 +174,9 @@ int b2m_bn_stats_finalize(const float* x, int64_t ldx, int64_t n, int32_t c, dou
 
 /* From (possibly all-reduced) sums: scale/shift for the apply kernel, saved mean/invstd, and the
  * running-statistics update (momentum, unbiased variance), all on device.
- * count = number of rows the sums cover (global count under SyncBN). */
-int b2m_bn_finalize(const double* stats, double count, int32_t c, const float* gamma, const float* beta,
+ * count = number of rows the sums cover.  Under SyncBN the global count travels with the sums through the
+ * all-reduce and never visits the host: pass it as count_dev (device pointer to one double; overrides count). */
+int b2m_bn_finalize(const double* stats, double count, const double* count_dev, int32_t c, const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var,
                     float* mean, float* invstd, float* scale, float* shift, void* stream);
 
@@ -194,7 +199,7 @@ int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy
  * b2m_bn_bwd_reduce. */
 int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
                      int64_t n, int32_t c, const float* mean, const float* invstd, const float* gamma,
-                     const double* sums, double count, int32_t relu, const float* mask_scale,
+                     const double* sums, double count, const double* count_dev, int32_t relu, const float* mask_scale,
                      const float* mask_shift, float* dx, int64_t lddx, float* dres, int64_t lddres, void* stream);
 
 /* out = relu(a) (b == NULL) or a + b, optional relu; grad helper: dx = dy * (y > 0). */
@@ -213,6 +218,12 @@ int b2m_add(const float* a, const float* b, int64_t n_elem, float* out, void* st
 int b2m_segment_pool_fwd(const float* x, int64_t ldx, int64_t n, int32_t c, const int64_t* ids, int64_t n_seg,
                          int32_t mode, float* out, int32_t* counts, int32_t* argmax, uint64_t* scratch,
                          void* stream);
+
+/* Deterministic segment mean: `order` = row indices grouped by segment (stable sort of the ids), seg_start[s] ..
+ * seg_start[s+1] = the rows of segment s inside `order`.  One workgroup per segment, fixed summation order, no
+ * atomics.  counts[s] = rows of segment s.  (Same result as mode 0 of b2m_segment_pool_fwd up to summation order.) */
+int b2m_segment_mean_sorted(const float* x, int64_t ldx, int64_t n, int32_t c, const int64_t* order,
+                            const int64_t* seg_start, int64_t n_seg, float* out, int32_t* counts, void* stream);
 int b2m_segment_pool_bwd(const float* dout, int64_t n, int32_t c, const int64_t* ids, int64_t n_seg,
                          int32_t mode, const int32_t* counts, const int32_t* argmax,
                          float* dx, int64_t lddx, void* stream);

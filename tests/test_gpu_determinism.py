@@ -1,0 +1,62 @@
+"""B2M_DETERMINISTIC=1: every order-dependent reduction of the path takes its ordered form (two-stage weight-gradient
+combine, un-split maps instead of the atomic split-K combine, sorted segment mean), so two runs of the same training
+step give the same BITS; and the ordered forms agree with the fast (atomic) ones to rounding."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(seed):
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    torch.manual_seed(seed)
+    model = Model(scannet_config(), *synth.scannet_tables())
+    model.train()
+    # scenes large enough that levels 2.. take the split-K path and every weight-gradient launch has several tile chunks
+    batch = synth.make_batch(4, seed0=21, target_voxels=20000, pts_per_m2=8000.0)
+    losses = model.compute_loss(batch, 150)
+    losses['optimization_loss'].backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().cpu().clone() for n, p in model.detection_model.named_parameters() if p.grad is not None}
+    return float(losses['optimization_loss']), grads
+
+
+def test_two_runs_give_the_same_bits(monkeypatch):
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    l1, g1 = _step(5)
+    l2, g2 = _step(5)
+    assert l1 == l2
+    assert g1.keys() == g2.keys() and len(g1) > 300
+    bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+    assert not bad, 'gradients differ between two deterministic runs: %s' % bad[:5]
+
+
+def test_ordered_forms_agree_with_the_fast_ones(monkeypatch):
+    """Operator level (no BatchNorm amplification in between): weight gradient, split-K forward, segment mean."""
+    from box2mask_amd import functional as F_, synth
+    from box2mask_amd.sparse import CoordinateManager
+    b = synth.make_batch(2, seed0=2, target_voxels=6000, pts_per_m2=6000.0)
+    m = CoordinateManager(b['vox_coords'], reorder=True)
+    rb = m.rulebook_same(0, 3)
+    n = rb.n_out
+    torch.manual_seed(0)
+    x = torch.randn(n, 96, device='cuda'); w = torch.randn(27, 96, 96, device='cuda') * 0.05; dy = torch.randn(n, 96, device='cuda')
+    ids = torch.randint(0, 300, (n,), device='cuda')
+
+    def run():
+        dw = torch.zeros_like(w)
+        F_.wgrad_raw(x, dy, rb, 27, dw, 0)
+        y = F_.conv_raw(x, None, F_.weight_pack(w), 27, None, rb, n, 96)
+        p = F_.segment_pool(x, ids, 300, 'avg')
+        torch.cuda.synchronize()
+        return dw, y, p
+    fast = run()
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    det1, det2 = run(), run()
+    for a, b_, c, what in zip(fast, det1, det2, ('wgrad', 'forward', 'segment mean')):
+        assert torch.equal(b_, c), what + ': two deterministic runs differ'
+        err = float((a - b_).abs().max()) / float(b_.abs().max())
+        assert err < 1e-5, (what, err)

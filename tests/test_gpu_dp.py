@@ -16,19 +16,20 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend='gloo'):
+    local = rank if backend == 'nccl' else 0
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0')
+                      LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY='0')
     import torch.distributed as dist
     from box2mask_amd import synth
     from box2mask_amd.config import scannet_config
     from box2mask_amd.model import Model
     from box2mask_amd.parallel import init_distributed, shard_scenes
-    torch.cuda.set_device(0)
-    init_distributed('gloo')
+    torch.cuda.set_device(local)
+    init_distributed(backend)
     cfg = scannet_config(multigpu=True)
     torch.manual_seed(0)
-    model = Model(cfg, *synth.scannet_tables(), device='cuda:0')      # parameters broadcast from rank 0
+    model = Model(cfg, *synth.scannet_tables(), device='cuda:%d' % local)      # parameters broadcast from rank 0
     mine = shard_scenes(8, rank, world)
     batch = synth.collate([synth.make_scene(100 + s, target_voxels=2000, pts_per_m2=6000.0) for s in mine])
     model.train()
@@ -43,11 +44,24 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
+def test_syncbn_and_gradient_mean_two_ranks_rccl():
+    """The same check over the real transport: backend "nccl" (RCCL), one rank per GPU.  Needs two devices; the
+    single-GPU test box skips it, an 8-GPU node runs it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs')
+    _two_rank_check('nccl')
+
+
+@pytest.mark.timeout(600)
 def test_syncbn_and_gradient_mean_two_ranks():
+    _two_rank_check('gloo')
+
+
+def _two_rank_check(backend):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs: p.start()
     res = dict(q.get(timeout=500) for _ in range(2))
     for p in procs:
