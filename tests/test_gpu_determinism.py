@@ -29,7 +29,7 @@ def test_two_runs_give_the_same_bits(monkeypatch):
     l1, g1 = _step(5)
     l2, g2 = _step(5)
     assert l1 == l2
-    assert g1.keys() == g2.keys() and len(g1) > 300
+    assert g1.keys() == g2.keys() and len(g1) > 250
     bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
     assert not bad, 'gradients differ between two deterministic runs: %s' % bad[:5]
 

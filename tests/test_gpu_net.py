@@ -85,7 +85,7 @@ def test_network_forward_backward_matches_oracle(monkeypatch):
     assert min(t.shape[0] for t in net._trace.values()) >= 8
     errs = {h: _rel(out[h].F, o32[h]) for h in heads}
     print('forward rel errors', errs)
-    assert max(errs.values()) < 1e-3, errs                      # north_star: conv features within 1e-3 fp32
+    assert max(errs.values()) < 3e-4, errs                      # north_star: within 1e-3 fp32; observed 4e-5 .. 8e-5
     # Gradients: BatchNorm over the 8-row deepest levels makes the backward pass ill-conditioned in fp32
     # (the fp32 oracle itself is ~2e-2 away from the fp64 oracle), so every gradient is judged against the
     # fp64 truth and must be no worse than a small multiple of the fp32 oracle's own error.
@@ -101,9 +101,10 @@ def test_network_forward_backward_matches_oracle(monkeypatch):
     for r in sorted(rows, reverse=True)[:5]:
         print('   worst: gpu %.3e oracle32 %.3e %s' % r)
     # the error DISTRIBUTION of the GPU gradients must be no worse than that of the fp32 oracle
-    assert q(e_gpu, .5) <= 2.0 * q(e_o32, .5) + 1e-4
-    assert q(e_gpu, .9) <= 2.0 * q(e_o32, .9) + 1e-3
-    assert e_gpu[-1] <= 3.0 * e_o32[-1] + 1e-3
+    # (deterministic mode: observed ratios gpu / oracle32 = 0.75 median, 0.74 p90, 0.48 max)
+    assert q(e_gpu, .5) <= 1.25 * q(e_o32, .5)
+    assert q(e_gpu, .9) <= 1.25 * q(e_o32, .9)
+    assert e_gpu[-1] <= 1.25 * e_o32[-1]
     # running statistics were updated like BatchNorm1d
     sd = net.state_dict()
     assert int(sd['bn0.bn.num_batches_tracked']) == 1
@@ -232,7 +233,8 @@ def test_training_trajectory_matches_oracle(monkeypatch):
     packed weights, gradient accumulation, state carried between steps).  BatchNorm over the 8 rows of the deepest
     levels amplifies rounding noise into the gradient direction (the fp32 oracle drifts 2 % from the fp64 one in
     three steps, and two runs of the device path -- atomics order -- differ by as much), so this is a check of the
-    loop, not of the last digits: same first loss, every later loss within 15 % of the fp64 oracle, and it trains."""
+    loop, not of the last digits: same first loss, every later loss within 4 % of the fp64 oracle (the run is in
+    deterministic mode, so the numbers are reproducible), and it trains."""
     from box2mask_amd.detection_net import SelectionNet
     from box2mask_amd import nn as ME
     from oracle import unet_ref, sparse_ref
@@ -285,7 +287,7 @@ def test_training_trajectory_matches_oracle(monkeypatch):
 
     o32, o64 = oracle_run(torch.float32), oracle_run(torch.float64)
     print('losses device', dev, 'oracle32', o32, 'oracle64', o64)
-    assert abs(dev[0] - o64[0]) <= 1e-4 * abs(o64[0])
-    assert dev[-1] < dev[0] and o64[-1] < o64[0]                 # it trains
+    assert abs(dev[0] - o64[0]) <= 1e-5 * abs(o64[0])
+    assert all(x > y for x, y in zip(dev, dev[1:])) and o64[-1] < o64[0]       # it trains, every step
     for a, c in zip(dev, o64):
-        assert abs(a - c) <= 0.15 * abs(c), (dev, o32, o64)
+        assert abs(a - c) <= 0.04 * abs(c), (dev, o32, o64)     # deterministic mode: observed 1.0 % / 1.7 % (fp32 oracle: 1.7 %)

@@ -9,14 +9,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_synthetic_scenes_are_learned():
+def test_synthetic_scenes_are_learned(monkeypatch):
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')           # ordered reductions: the same trajectory on every run
     spec = importlib.util.spec_from_file_location('train_synthetic', os.path.join(ROOT, 'tools', 'train_synthetic.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     history, avg = mod.main(['--scenes', '3', '--voxels', '12000', '--steps', '200', '--eval-every', '0'])
     first, last = history[0][1], history[-1][1]
-    assert last < 0.15 * first, history                    # 40 -> ~1 in the first hundred steps
-    assert avg['all_ap_25%'] > 0.02, avg                   # instances start to come out (AP25 ~0.3 here, AP50 0.7 after 800 steps)
+    print('loss %.3f -> %.3f, AP25 %.3f' % (first, last, avg['all_ap_25%']))
+    assert last < 0.1 * first, history                     # 40 -> ~1 in the first hundred steps
+    assert avg['all_ap_25%'] > 0.05, avg                   # instances start to come out (AP25 ~0.3 here, AP50 0.7 after 800 steps)
 
 
 def test_forward_follows_a_fused_optimizer_step():
