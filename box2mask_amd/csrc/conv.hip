@@ -95,10 +95,20 @@ __device__ __forceinline__ int cs_index(int row, int col) {
     return TW == 2 ? row * 32 + (col ^ ((row & 1) << 4)) : row * (16 * TW) + col;
 }
 
-// Packed weight image (b2m_weight_pack): blocks of 64 lanes x 2*KS floats, ordered [k][strip][chunk]; lane
-// (q,i) of a block holds B[chunk*KC + KS*q + s][strip*SW + 16*t + i] at float TW*s + t (SW = 16*TW columns per
-// strip, TW = 3 when cout is a multiple of 48, else 2).  One to three 16-byte loads per lane per chunk, contiguous
-// over the wave, zero padded: no predicates, no address arithmetic.
+// Packed weight image (b2m_weight_pack): blocks of 64 lanes x TW*KS floats, ordered [k][strip][chunk]; lane
+// (q,i) of a block owns B[chunk*KC + KS*q + s][strip*SW + 16*t + i] as its float f = TW*s + t (SW = 16*TW columns per
+// strip, TW = 3 when cout is a multiple of 48, else 2).  Inside a block the floats are stored [f / 4][lane][f % 4]
+// when TW*KS is a multiple of 4 -- the u-th 16-byte load of a wave reads ONE contiguous KiB (8 cache lines; stored
+// lane-major, every load instruction of a 48-byte-per-lane block touched all 24 lines of the block) -- and lane-major
+// [lane][f] otherwise (KC = 8 with 48-column strips: 6 floats per lane).  Zero padded: no predicates.
+__host__ __device__ __forceinline__ int pack_pos(int lane, int f, int FPL) {
+    return (FPL % 4 == 0) ? (f >> 2) * 256 + lane * 4 + (f & 3) : lane * FPL + f;
+}
+// inverse: position inside a block -> (lane, f)
+__host__ __device__ __forceinline__ void pack_unpos(int pos, int FPL, int& lane, int& f) {
+    if (FPL % 4 == 0) { lane = (pos & 255) >> 2; f = (pos >> 8) * 4 + (pos & 3); }
+    else { lane = pos / FPL; f = pos % FPL; }
+}
 template <int KC, bool IDENT, bool ASCALAR, int NPF, int TW>
 __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_kernel(ConvArgs a) {
     constexpr int KS = KC / 4;                // k-steps per chunk == floats per lane per gathered row
@@ -209,7 +219,9 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 
         // packed weights of (k, strip): wave-uniform base (scalar registers) + a 32-bit lane offset
         const char* wbase = (const char*)(a.wp + ((int64_t)k * a.nstrips + strip) * nchunk * LW);
-        const uint32_t wlo = (uint32_t)lane * (TW * KS * 4);
+        constexpr bool WLIN = (TW * KS) % 4 == 0;     // [u][lane][4] block layout, see pack_pos()
+        const uint32_t wlo = WLIN ? (uint32_t)lane * 16u : (uint32_t)lane * (TW * KS * 4);
+        constexpr uint32_t WU = WLIN ? 1024u : 16u;    // byte distance between a lane's consecutive 16-byte pieces
 
         // one source tensor: chunks [c_lo, c_hi) of the concatenated input channels.  NPF chunks of loads are
         // issued back to back before the first MFMA block (memory-level parallelism per wave); the loads are
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
                         float wv[TW * KS];
 #pragma unroll
                         for (int u = 0; u < TW * KS / 4; ++u) {
-                            const f32x4 w4 = *(const f32x4*)(wbase + (size_t)c * (LW * 4) + (wlo + 16 * u));
+                            const f32x4 w4 = *(const f32x4*)(wbase + (size_t)c * (LW * 4) + (wlo + WU * u));
                             wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
                         }
                         if constexpr ((TW * KS) % 4 != 0) {         // TW == 3, KS == 2: 6 floats = 4 + 2
@@ -391,6 +403,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 }
 
 #include "conv_fwd_pipe.h"
+#include "conv_fwd_flow.h"
 
 static int env_flag(const char* name, int dflt);
 static inline int conv_kc(int cin) { return cin >= 16 ? 16 : 8; }
@@ -413,8 +426,9 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, int64_t ldw, int
     const int nchunk = (CI + KC - 1) / KC, nstrip = (CO + SW - 1) / SW;
     const int64_t total = (int64_t)K * nstrip * nchunk * LW;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(e % (TW * KS)); const int64_t e1 = e / (TW * KS);
-        const int lane = (int)(e1 % 64); const int64_t blk = e1 / 64;
+        int lane, f;
+        pack_unpos((int)(e % LW), TW * KS, lane, f);
+        const int64_t blk = e / LW;
         const int chunk = (int)(blk % nchunk); const int64_t b2 = blk / nchunk;
         const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
         const int s = f / TW, t = f % TW, q = lane >> 4, i = lane & 15;
@@ -517,7 +531,8 @@ __global__ __launch_bounds__(256) void weight_pack_batch_kernel(const PackDesc* 
         __syncthreads();
         float* out = d.wp + pb * LW;
         for (int e = threadIdx.x; e < LW; e += 256) {
-            const int f = e % (d.TW * KS), lane = e / (d.TW * KS);
+            int lane, f;
+            pack_unpos(e, d.TW * KS, lane, f);
             const int s_ = f / d.TW, t = f % d.TW, q = lane >> 4, i = lane & 15;
             out[e] = tile[(KS * q + s_) * SW + 16 * t + i];
         }
@@ -612,6 +627,29 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
         if (depth > 3) depth = 3;
         if (depth == 3 && nc % 3 != 0) depth = 2;
         if (depth >= 2 && !ident && fast && KC == 16 && nslice == 1 && a.fast32 && nc % depth == 0 && nc >= depth) {
+            if (env_flag("B2M_CONV_FLOW", 1)) {
+                // conv_fwd_flow_kernel: one wave per workgroup, per-offset specialisation, static load counts
+                a.nwg = items;
+                const XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips);
+                a.xcd_per = fo.chunk;
+                const int dbg = env_flag("B2M_PIPE_DBG", 0);      // diagnostic builds, wrong results: tools/pipe_breakdown.py
+                if (dbg && TW == 3 && depth == 2) {
+                    switch (dbg) {
+                        case 1: conv_fwd_flow_kernel<2, 3, 1><<<fo.grid, 64, 0, st>>>(a); break;
+                        case 2: conv_fwd_flow_kernel<2, 3, 2><<<fo.grid, 64, 0, st>>>(a); break;
+                        case 4: conv_fwd_flow_kernel<2, 3, 4><<<fo.grid, 64, 0, st>>>(a); break;
+                        default: conv_fwd_flow_kernel<2, 3, 6><<<fo.grid, 64, 0, st>>>(a); break;
+                    }
+                } else if (depth == 2) {
+                    if (TW == 3) conv_fwd_flow_kernel<2, 3><<<fo.grid, 64, 0, st>>>(a);
+                    else conv_fwd_flow_kernel<2, 2><<<fo.grid, 64, 0, st>>>(a);
+                } else {
+                    if (TW == 3) conv_fwd_flow_kernel<3, 3><<<fo.grid, 64, 0, st>>>(a);
+                    else conv_fwd_flow_kernel<3, 2><<<fo.grid, 64, 0, st>>>(a);
+                }
+                B2M_LAUNCH_CHECK();
+                return B2M_OK;
+            }
             const int wpb = env_flag("B2M_PIPE_WPB", 1) == 4 ? 4 : 1;      // waves per workgroup (1: every item frees its slot alone)
             a.nwg = cdiv64(items, wpb);
             const XcdOrder po = xcd_order(a.nwg, xcd_tiles * a.nstrips / wpb);

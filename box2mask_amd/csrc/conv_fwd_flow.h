@@ -1,0 +1,274 @@
+// conv_fwd_flow_kernel: forward / data-gradient kernel for the shapes that carry the FLOPs (real rulebook, 16-channel
+// chunks, 32-bit addressable operands, un-split maps).  Included by conv.hip.
+//
+// Work decomposition as in conv_fwd_kernel -- one wave owns (tile of 64 output rows, strip of 16*TW output channels),
+// walks the tile's active offsets, accumulates an offset over all input-channel chunks in registers and adds the
+// result into its private LDS strip -- with three changes that the s_memtime stamps of round 2 asked for
+// (profiles/r02_conv_analysis.md: a wave of the first pipelined kernel spent 32 % of its life in its own MFMAs, the
+// rest in load issue, waits, flushes and accumulator copies, and two waves per SIMD cannot fill the pipe from that):
+//
+//  * the walk over (offset, chunk) steps is one flat software pipeline, D steps deep, ACROSS offset boundaries: while
+//    the last chunks of an offset multiply, the first chunks of the next one are in flight; pair lists are fetched two
+//    offsets ahead;
+//  * the row-group count G of an offset is a template parameter of the code that handles the whole offset (one
+//    wave-uniform switch per offset, not per step), so the accumulators are locals of that code: the MFMAs update them
+//    in place (the per-step switch made hipcc keep two copies of the accumulator file and move between them: 196
+//    VGPRs).  <= 168 VGPRs -> three waves per SIMD;
+//  * every step issues the same number of vector loads (4 gathers + TW weight pieces; row groups an offset does not
+//    have gather row 0, an L1 hit), so the compiler's counted waits are exact: vmcnt((D-1)*(4+TW)) in front of an MFMA
+//    block.  With gathers skipped for absent row groups the counts were conservative and every MFMA block also waited
+//    for most of the step issued after it.
+//
+// Operand roles are swapped against conv_fwd_kernel: the weights are the MFMA "A" operand and the gathered rows the
+// "B" operand (the register images of both are identical for 16x16x4, so the packed weight image is unchanged).  The
+// result tile is then D[channel][pair]: a lane holds FOUR CONSECUTIVE CHANNELS of ONE pair, and the add into the LDS
+// strip is one 16-byte read-modify-write per (row group, 16-column tile); the lane needs only the output row of its own
+// pair.  Pair lists: lane L of the wave loads slot L of the offset (input row + output row, packed into one word: rows
+// < 2^24), and the four words a lane needs (pairs i, 16+i, 32+i, 48+i) come from a cross-lane permute.
+#pragma once
+#include <type_traits>
+
+// DBG (diagnostic builds of tools/pipe_breakdown.py only, results are WRONG): 1 = no strip flush, 2 = no gathers inside
+// the loop, 4 = no weight loads inside the loop -- each removes one component so that its cost shows in the launch time
+template <int D, int TW, int DBG = 0>
+__global__ __launch_bounds__(64, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
+    constexpr int KS = 4;                     // k-steps per 16-channel chunk == floats per lane per gathered row
+    constexpr int SW = 16 * TW;               // output channels per strip
+    constexpr int LW = 64 * TW * KS;          // floats per packed weight block
+    constexpr int PITCH = SW + 4;             // strip row pitch in floats: 16-byte multiples that do not alias banks
+    __shared__ float Cs[B2M_TILE * PITCH];    // 13 KiB (TW = 3): twelve one-wave workgroups per CU
+    const int lane = threadIdx.x;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t wg = wg_index(a.nwg, a.xcd_per);
+    if (wg < 0) return;
+    const int64_t tile = wg / a.nstrips;
+    const int strip = (int)(wg % a.nstrips);
+    if (tile >= a.ntiles) return;             // whole wave leaves; there is no barrier in this kernel
+    const int col0 = strip * SW;
+    const int nch1 = a.c1 >> 4, NC = (a.c1 + a.c2) >> 4;      // chunks of the first source / in all (NC % D == 0)
+    const int64_t ldr = a.ntiles * B2M_TILE;
+    const int64_t row0 = tile * B2M_TILE;
+
+    // ---- init the strip: 0 | Y (accumulate) | + bias
+    for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+        const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int64_t grow = row0 + row;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int col = col0 + c4 + u;
+            if (col < a.cout) {
+                float t = a.bias ? a.bias[col] : 0.f;
+                if (a.accumulate && grow < a.n_out) t += a.y[grow * a.ldy + col];
+                v[u] = t;
+            }
+        }
+        *(f32x4*)&Cs[row * PITCH + c4] = v;
+    }
+
+    // ---- active offsets (K <= 128): lane k holds the pair count of offset k / k + 64
+    int cnt0 = 0, cnt1 = 0;
+    if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
+    if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
+    const uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
+    auto next_active = [&](int k) -> int {    // first active offset after k, or -1 (scalar)
+        int kk = k + 1;
+        if (kk < 64) {
+            const uint64_t r = m0 >> kk;
+            if (r) return kk + __builtin_ctzll(r);
+            kk = 64;
+        }
+        if (kk < 128) {
+            const uint64_t r = m1 >> (kk - 64);
+            if (r) return kk + __builtin_ctzll(r);
+        }
+        return -1;
+    };
+    auto groups_of = [&](int k) -> int {
+        const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
+        return (n + 15) >> 4;
+    };
+
+    int kC = next_active(-1);
+    if (kC >= 0) {
+        // pair list of an offset: slot `lane` -> word = input row | output row << 24 (padded slot: row 0, output row 64)
+        auto list_load = [&](int k, int& r_in, int& r_out) {
+            const int64_t base = (int64_t)k * ldr + row0 + lane;
+            r_in = a.rb_in[base];
+            r_out = a.rb_out[base];
+        };
+        auto list_words = [&](int r_in, int r_out, uint32_t (&w)[NG]) {
+            const uint32_t word = r_in < 0 ? ((uint32_t)B2M_TILE << 24) : ((uint32_t)r_in | ((uint32_t)r_out << 24));
+#pragma unroll
+            for (int g = 0; g < NG; ++g) w[g] = (uint32_t)__builtin_amdgcn_ds_bpermute((16 * g + i) << 2, (int)word);
+        };
+
+        const uint32_t wlo = (uint32_t)lane * 16u;         // packed block layout [u][lane][4 floats]: pack_pos()
+        const uint32_t q16 = (uint32_t)q * 16u;
+        const uint32_t ld1 = (uint32_t)a.ldx1 * 4u, ld2 = (uint32_t)a.ldx2 * 4u;
+        const uint32_t wstrip = (uint32_t)strip * (uint32_t)NC;
+        const uint32_t wkstride = (uint32_t)a.nstrips * (uint32_t)NC;
+        float av[D][NG][KS], bv[D][KS][TW];
+        // loads of step (offset k, chunk c) into register buffer j: NG gathers + TW weight pieces, always
+        auto src_of = [&](int c, uint32_t& ld4) -> const char* {
+            const bool first = c < nch1;                                        // wave-uniform source select
+            ld4 = first ? ld1 : ld2;
+            return (const char*)(first ? a.x1 + (c << 4) : a.x2 + ((c - nch1) << 4));
+        };
+        auto gather = [&](int j, int g, const char* src, uint32_t ld4, uint32_t word) {
+            const uint32_t off = __umul24(word & 0xFFFFFFu, ld4) + q16;
+            const f32x4 v = *(const f32x4*)(src + off);
+            av[j][g][0] = v[0]; av[j][g][1] = v[1]; av[j][g][2] = v[2]; av[j][g][3] = v[3];
+        };
+        auto weights = [&](int j, int k, int c) {
+            const uint32_t blk = (uint32_t)k * wkstride + wstrip + (uint32_t)c;     // wave-uniform
+            const char* wsrc = (const char*)a.wp + (size_t)blk * (size_t)(LW * 4);
+            float wv[TW * KS];
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                const f32x4 w4 = *(const f32x4*)(wsrc + (wlo + 1024u * u));
+                wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < TW; ++t) bv[j][s][t] = wv[TW * s + t];
+        };
+
+        // ---- prologue: lists of the first three offsets, operands of the first D steps
+        uint32_t wC[NG], wN[NG];
+        int rawi, rawo;
+        int kN = next_active(kC);
+        int kNc = kN < 0 ? kC : kN;
+        int kNN = kN < 0 ? -1 : next_active(kN);
+        {
+            int r0i, r0o, r1i, r1o;
+            list_load(kC, r0i, r0o);
+            list_load(kNc, r1i, r1o);
+            list_words(r0i, r0o, wC);
+            list_words(r1i, r1o, wN);
+        }
+        int GC = groups_of(kC);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            uint32_t ld4;
+            const char* src = src_of(j, ld4);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) gather(j, g, src, ld4, wC[g]);
+            weights(j, kC, j);
+        }
+        list_load(kNN < 0 ? kNc : kNN, rawi, rawo);       // behind the step loads, as in the steady state
+
+        f32x4 acc[NG][TW];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int t = 0; t < TW; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // The 4*TW MFMAs of (row group g, chunk step in buffer j) as ONE asm statement with the accumulators tied
+        // (in place).  Written with the builtin, hipcc un-tied the accumulators around the wave-uniform branches on the
+        // group count (two copies of the accumulator file, v_mov chains, 196 VGPRs) and hoisted MFMA blocks over the loads
+        // that refill their operand buffer.  k-step outermost: an accumulator is reused every TW MFMAs (>= 64 cycles
+        // apart; the dependent latency is 40).  The hardware interlocks MFMA -> MFMA on the same accumulator; the one
+        // software-visible hazard, a non-MFMA read of a fresh result, is covered by the s_nop in front of the flush.
+        auto mfma_group = [&](int j, int g) {
+            if constexpr (TW == 3) {
+                asm volatile(
+                    "v_mfma_f32_16x16x4_f32 %0, %7, %3, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %3, %1\n\tv_mfma_f32_16x16x4_f32 %2, %9, %3, %2\n\t"
+                    "v_mfma_f32_16x16x4_f32 %0, %10, %4, %0\n\tv_mfma_f32_16x16x4_f32 %1, %11, %4, %1\n\tv_mfma_f32_16x16x4_f32 %2, %12, %4, %2\n\t"
+                    "v_mfma_f32_16x16x4_f32 %0, %13, %5, %0\n\tv_mfma_f32_16x16x4_f32 %1, %14, %5, %1\n\tv_mfma_f32_16x16x4_f32 %2, %15, %5, %2\n\t"
+                    "v_mfma_f32_16x16x4_f32 %0, %16, %6, %0\n\tv_mfma_f32_16x16x4_f32 %1, %17, %6, %1\n\tv_mfma_f32_16x16x4_f32 %2, %18, %6, %2"
+                    : "+v"(acc[g][0]), "+v"(acc[g][1]), "+v"(acc[g][2])
+                    : "v"(av[j][g][0]), "v"(av[j][g][1]), "v"(av[j][g][2]), "v"(av[j][g][3]),
+                      "v"(bv[j][0][0]), "v"(bv[j][0][1]), "v"(bv[j][0][2]), "v"(bv[j][1][0]), "v"(bv[j][1][1]), "v"(bv[j][1][2]),
+                      "v"(bv[j][2][0]), "v"(bv[j][2][1]), "v"(bv[j][2][2]), "v"(bv[j][3][0]), "v"(bv[j][3][1]), "v"(bv[j][3][2])
+                    : "memory");
+            } else {
+                asm volatile(
+                    "v_mfma_f32_16x16x4_f32 %0, %6, %2, %0\n\tv_mfma_f32_16x16x4_f32 %1, %7, %2, %1\n\t"
+                    "v_mfma_f32_16x16x4_f32 %0, %8, %3, %0\n\tv_mfma_f32_16x16x4_f32 %1, %9, %3, %1\n\t"
+                    "v_mfma_f32_16x16x4_f32 %0, %10, %4, %0\n\tv_mfma_f32_16x16x4_f32 %1, %11, %4, %1\n\t"
+                    "v_mfma_f32_16x16x4_f32 %0, %12, %5, %0\n\tv_mfma_f32_16x16x4_f32 %1, %13, %5, %1"
+                    : "+v"(acc[g][0]), "+v"(acc[g][1])
+                    : "v"(av[j][g][0]), "v"(av[j][g][1]), "v"(av[j][g][2]), "v"(av[j][g][3]),
+                      "v"(bv[j][0][0]), "v"(bv[j][0][1]), "v"(bv[j][1][0]), "v"(bv[j][1][1]),
+                      "v"(bv[j][2][0]), "v"(bv[j][2][1]), "v"(bv[j][3][0]), "v"(bv[j][3][1])
+                    : "memory");
+            }
+        };
+
+        for (;;) {
+            for (int c0 = 0; c0 < NC; c0 += D) {
+                // the D prefetches of this round target one offset: the current one, or -- in its last round -- the next
+                const bool wrap = c0 + D >= NC;
+                const int kT = wrap ? kNc : kC;
+                const int cT = wrap ? c0 + D - NC : c0 + D;
+                uint32_t wT[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) wT[g] = wrap ? wN[g] : wC[g];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    // step in buffer j: the MFMAs of row group g, then at once the gather that refills the group's
+                    // operand registers for step + D (the matrix pipe still works off the queued MFMAs meanwhile);
+                    // absent row groups skip their MFMAs only -- every step issues NG + TW loads
+                    uint32_t ld4;
+                    const char* src = src_of(cT + j, ld4);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (g < GC) mfma_group(j, g);                        // wave-uniform
+                        if constexpr (!(DBG & 2)) gather(j, g, src, ld4, wT[g]);
+                    }
+                    if constexpr (!(DBG & 4)) weights(j, kT, cT + j);
+                }
+            }
+            // ---- add the offset's result into the strip: lane (i,q) holds channels 16t + 4q .. +3 of pair 16g + i;
+            // padded pairs (output row 64) take no part
+            asm volatile("s_nop 15" ::: "memory");        // MFMA result -> VALU read: >= 11 wait states (8-pass MFMA)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g < GC) {
+                    if constexpr (!(DBG & 1)) {
+                        const uint32_t orow = wC[g] >> 24;
+                        if (orow < B2M_TILE) {
+                            float* rowp = Cs + orow * PITCH + 4 * q;
+                            f32x4 old[TW];
+#pragma unroll
+                            for (int t = 0; t < TW; ++t) old[t] = *(const f32x4*)(rowp + 16 * t);
+#pragma unroll
+                            for (int t = 0; t < TW; ++t) *(f32x4*)(rowp + 16 * t) = old[t] + acc[g][t];
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (kN < 0) break;
+            // ---- advance: next offset becomes current; the list fetched an offset ago becomes next; fetch one more
+            kC = kN;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) wC[g] = wN[g];
+            kN = kNN; kNc = kN < 0 ? kC : kN;
+            GC = groups_of(kC);
+            list_words(rawi, rawo, wN);
+            kNN = kN < 0 ? -1 : next_active(kN);
+            list_load(kNN < 0 ? kNc : kNN, rawi, rawo);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+
+    // ---- write the strip (rows of the strip are 16-byte aligned: coalesced vector stores)
+    for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+        const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
+        const int64_t grow = row0 + row;
+        if (grow >= a.n_out) continue;
+        const f32x4 v = *(const f32x4*)&Cs[row * PITCH + c4];
+        const int col = col0 + c4;
+        float* dst = a.y + grow * a.ldy + col;
+        if (a.vec_store && col + 3 < a.cout) {
+            *(f32x4*)dst = v;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (col + u < a.cout) dst[u] = v[u];
+        }
+    }
+}

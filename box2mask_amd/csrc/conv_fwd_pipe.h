@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv_fwd_pipe_kernel(ConvArgs a) 
             for (int g = 0; g < NG; ++g) w[g] = (uint32_t)__builtin_amdgcn_ds_bpermute((16 * g + i) << 2, (int)word);
         };
 
-        const uint32_t wlo = (uint32_t)lane * (TW * KS * 4);
+        const uint32_t wlo = (uint32_t)lane * 16u;         // block layout [u][lane][4]: pack_pos()
         const uint32_t q16 = (uint32_t)q * 16u;
         const uint32_t ld1 = (uint32_t)a.ldx1 * 4u, ld2 = (uint32_t)a.ldx2 * 4u;
         float av[D][NG][KS], bv[D][KS][TW];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv_fwd_pipe_kernel(ConvArgs a) 
             if (!((DBG & 4) && in_loop)) {
 #pragma unroll
                 for (int u = 0; u < TW * KS / 4; ++u) {
-                    const f32x4 w4 = *(const f32x4*)(wsrc + (wlo + 16 * u));
+                    const f32x4 w4 = *(const f32x4*)(wsrc + (wlo + 1024 * u));
                     wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
                 }
 #pragma unroll
