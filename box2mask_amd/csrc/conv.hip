@@ -402,7 +402,6 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 #endif
 }
 
-#include "conv_fwd_pipe.h"
 #include "conv_fwd_flow.h"
 
 static int env_flag(const char* name, int dflt);
@@ -619,67 +618,44 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     a.xcd_per = xo.chunk;
     const unsigned grid = xo.grid;
     const bool ident = rb_in == nullptr;
-    // The shapes that carry the FLOPs -- real rulebook, whole 16-channel chunks, un-split map, 32-bit addressable --
-    // take the never-draining pipelined kernel (conv_fwd_pipe.h), D steps deep (B2M_CONV_PIPE = depth, 0 = off).
+    // Real rulebook, whole 16-channel chunks, 32-bit addressable: the flat-pipeline kernel (conv_fwd_flow.h), D steps
+    // deep (B2M_CONV_PIPE = depth, 0 = off) -- un-split maps with one wave per workgroup, split maps with the four
+    // waves of a workgroup as four slices that combine in LDS.
     {
         const int nc = cin / 16;
         int depth = env_flag("B2M_CONV_PIPE", 2);
         if (depth > 3) depth = 3;
-        if (depth == 3 && nc % 3 != 0) depth = 2;
-        if (depth >= 2 && !ident && fast && KC == 16 && nslice == 1 && a.fast32 && nc % depth == 0 && nc >= depth) {
-            if (env_flag("B2M_CONV_FLOW", 1)) {
-                // conv_fwd_flow_kernel: one wave per workgroup, per-offset specialisation, static load counts
-                a.nwg = items;
-                const XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips);
-                a.xcd_per = fo.chunk;
-                const int dbg = env_flag("B2M_PIPE_DBG", 0);      // diagnostic builds, wrong results: tools/pipe_breakdown.py
-                if (dbg && TW == 3 && depth == 2) {
-                    switch (dbg) {
-                        case 1: conv_fwd_flow_kernel<2, 3, 1><<<fo.grid, 64, 0, st>>>(a); break;
-                        case 2: conv_fwd_flow_kernel<2, 3, 2><<<fo.grid, 64, 0, st>>>(a); break;
-                        case 4: conv_fwd_flow_kernel<2, 3, 4><<<fo.grid, 64, 0, st>>>(a); break;
-                        default: conv_fwd_flow_kernel<2, 3, 6><<<fo.grid, 64, 0, st>>>(a); break;
-                    }
-                } else if (depth == 2) {
-                    if (TW == 3) conv_fwd_flow_kernel<2, 3><<<fo.grid, 64, 0, st>>>(a);
-                    else conv_fwd_flow_kernel<2, 2><<<fo.grid, 64, 0, st>>>(a);
-                } else {
-                    if (TW == 3) conv_fwd_flow_kernel<3, 3><<<fo.grid, 64, 0, st>>>(a);
-                    else conv_fwd_flow_kernel<3, 2><<<fo.grid, 64, 0, st>>>(a);
-                }
-                B2M_LAUNCH_CHECK();
-                return B2M_OK;
-            }
-            const int wpb = env_flag("B2M_PIPE_WPB", 1) == 4 ? 4 : 1;      // waves per workgroup (1: every item frees its slot alone)
+        if (depth == 3 && (nc / ncs) % 3 != 0) depth = 2;
+        const bool split_ok = nslice == 1 || (a.wg_combine && env_flag("B2M_CONV_FLOW_SPLIT", 1));
+        if (depth >= 2 && !ident && fast && KC == 16 && split_ok && a.fast32 && nc % ncs == 0 && (nc / ncs) % depth == 0 &&
+            nc / ncs >= depth) {
+            const int wpb = nslice == 1 ? 1 : 4;
             a.nwg = cdiv64(items, wpb);
-            const XcdOrder po = xcd_order(a.nwg, xcd_tiles * a.nstrips / wpb);
-            a.xcd_per = po.chunk;
-            const unsigned pgrid = po.grid;
-            const int skipg = env_flag("B2M_PIPE_SKIPG", 1);               // no gathers for absent row groups
-#define B2M_PIPE_LAUNCH(DV)                                                                                \
-            do {                                                                                           \
-                if (wpb == 4) {                                                                            \
-                    if (TW == 3) conv_fwd_pipe_kernel<DV, 3, 0, 4, false><<<pgrid, 256, 0, st>>>(a);       \
-                    else conv_fwd_pipe_kernel<DV, 2, 0, 4, false><<<pgrid, 256, 0, st>>>(a);               \
-                } else if (skipg) {                                                                        \
-                    if (TW == 3) conv_fwd_pipe_kernel<DV, 3, 0, 1, true><<<pgrid, 64, 0, st>>>(a);         \
-                    else conv_fwd_pipe_kernel<DV, 2, 0, 1, true><<<pgrid, 64, 0, st>>>(a);                 \
-                } else {                                                                                   \
-                    if (TW == 3) conv_fwd_pipe_kernel<DV, 3, 0, 1, false><<<pgrid, 64, 0, st>>>(a);        \
-                    else conv_fwd_pipe_kernel<DV, 2, 0, 1, false><<<pgrid, 64, 0, st>>>(a);                \
-                }                                                                                          \
-            } while (0)
-            const int dbg = env_flag("B2M_PIPE_DBG", 0);          // diagnostic builds, wrong results: tools/pipe_breakdown.py
-            if (dbg && TW == 3 && wpb == 1) {
-                switch (dbg) {
-                    case 2: conv_fwd_pipe_kernel<2, 3, 2><<<pgrid, 64, 0, st>>>(a); break;
-                    case 4: conv_fwd_pipe_kernel<2, 3, 4><<<pgrid, 64, 0, st>>>(a); break;
-                    default: conv_fwd_pipe_kernel<2, 3, 6><<<pgrid, 64, 0, st>>>(a); break;
+            const XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
+            a.xcd_per = fo.chunk;
+            const int dbg = env_flag("B2M_PIPE_DBG", 0);      // diagnostic builds, wrong results: tools/pipe_breakdown.py
+            if (wpb == 4) {
+                if (depth == 2) {
+                    if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4><<<fo.grid, 256, 0, st>>>(a);
+                    else conv_fwd_flow_kernel<2, 2, 0, 4><<<fo.grid, 256, 0, st>>>(a);
+                } else {
+                    if (TW == 3) conv_fwd_flow_kernel<3, 3, 0, 4><<<fo.grid, 256, 0, st>>>(a);
+                    else conv_fwd_flow_kernel<3, 2, 0, 4><<<fo.grid, 256, 0, st>>>(a);
                 }
-            } else
-            if (depth == 2) B2M_PIPE_LAUNCH(2);
-            else B2M_PIPE_LAUNCH(3);
-#undef B2M_PIPE_LAUNCH
+            } else if (dbg && TW == 3 && depth == 2) {
+                switch (dbg) {
+                    case 1: conv_fwd_flow_kernel<2, 3, 1><<<fo.grid, 64, 0, st>>>(a); break;
+                    case 2: conv_fwd_flow_kernel<2, 3, 2><<<fo.grid, 64, 0, st>>>(a); break;
+                    case 4: conv_fwd_flow_kernel<2, 3, 4><<<fo.grid, 64, 0, st>>>(a); break;
+                    default: conv_fwd_flow_kernel<2, 3, 6><<<fo.grid, 64, 0, st>>>(a); break;
+                }
+            } else if (depth == 2) {
+                if (TW == 3) conv_fwd_flow_kernel<2, 3><<<fo.grid, 64, 0, st>>>(a);
+                else conv_fwd_flow_kernel<2, 2><<<fo.grid, 64, 0, st>>>(a);
+            } else {
+                if (TW == 3) conv_fwd_flow_kernel<3, 3><<<fo.grid, 64, 0, st>>>(a);
+                else conv_fwd_flow_kernel<3, 2><<<fo.grid, 64, 0, st>>>(a);
+            }
             B2M_LAUNCH_CHECK();
             return B2M_OK;
         }

@@ -30,22 +30,40 @@
 
 // DBG (diagnostic builds of tools/pipe_breakdown.py only, results are WRONG): 1 = no strip flush, 2 = no gathers inside
 // the loop, 4 = no weight loads inside the loop -- each removes one component so that its cost shows in the launch time
-template <int D, int TW, int DBG = 0>
-__global__ __launch_bounds__(64, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
+// WPB = 4: split maps (deep U-Net levels).  The four waves of a workgroup are four slices of ONE (tile, strip): the
+// tile's active offsets are dealt round-robin to nslice / ncs slices and the input-channel chunks to ncs parts; the
+// waves add their strips up in LDS behind one barrier and wave 0 writes (plain stores for exactly 4 slices, else fp32
+// atomics into the pre-zeroed Y).
+template <int D, int TW, int DBG = 0, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
     constexpr int KS = 4;                     // k-steps per 16-channel chunk == floats per lane per gathered row
     constexpr int SW = 16 * TW;               // output channels per strip
     constexpr int LW = 64 * TW * KS;          // floats per packed weight block
     constexpr int PITCH = SW + 4;             // strip row pitch in floats: 16-byte multiples that do not alias banks
-    __shared__ float Cs[B2M_TILE * PITCH];    // 13 KiB (TW = 3): twelve one-wave workgroups per CU
-    const int lane = threadIdx.x;
+    constexpr int STRIP = B2M_TILE * PITCH;   // 13 KiB per wave (TW = 3): twelve waves per CU
+    __shared__ float smem[WPB * STRIP];
+    const int lane = threadIdx.x & 63;
+    const int wave = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
     const int64_t wg = wg_index(a.nwg, a.xcd_per);
     if (wg < 0) return;
-    const int64_t tile = wg / a.nstrips;
-    const int strip = (int)(wg % a.nstrips);
-    if (tile >= a.ntiles) return;             // whole wave leaves; there is no barrier in this kernel
+    const int nch1 = a.c1 >> 4, NC = (a.c1 + a.c2) >> 4;      // chunks of the first source / in all
+    int64_t item = wg;
+    int slice = 0, nks = 1, cb = 0, ce = NC;                  // offset slice of nks, chunk range [cb, ce): (ce - cb) % D == 0
+    bool lead = true;
+    if constexpr (WPB > 1) {
+        const int64_t witem = wg * WPB + wave;
+        const int sl = (int)(witem % a.nslice), cslice = sl % a.ncs;
+        item = witem / a.nslice;
+        slice = sl / a.ncs; nks = a.nslice / a.ncs;
+        cb = NC / a.ncs * cslice; ce = cb + NC / a.ncs;
+        lead = sl == 0;
+    }
+    const int64_t tile = item / a.nstrips;
+    const int strip = (int)(item % a.nstrips);
+    if (tile >= a.ntiles) return;             // the whole workgroup leaves (its waves share the item)
     const int col0 = strip * SW;
-    const int nch1 = a.c1 >> 4, NC = (a.c1 + a.c2) >> 4;      // chunks of the first source / in all (NC % D == 0)
+    float* Cs = smem + wave * STRIP;
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int64_t row0 = tile * B2M_TILE;
 
@@ -58,8 +76,8 @@ __global__ __launch_bounds__(64, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow
         for (int u = 0; u < 4; ++u) {
             const int col = col0 + c4 + u;
             if (col < a.cout) {
-                float t = a.bias ? a.bias[col] : 0.f;
-                if (a.accumulate && grow < a.n_out) t += a.y[grow * a.ldy + col];
+                float t = (a.bias && lead) ? a.bias[col] : 0.f;
+                if (a.accumulate && a.nslice == 1 && grow < a.n_out) t += a.y[grow * a.ldy + col];
                 v[u] = t;
             }
         }
@@ -70,7 +88,12 @@ __global__ __launch_bounds__(64, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow
     int cnt0 = 0, cnt1 = 0;
     if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
     if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
-    const uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
+    uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
+    if constexpr (WPB > 1) {                  // keep the active offsets whose rank among the active ones is ours
+        const int r0 = prefix_popc(m0), r1 = __builtin_popcountll(m0) + prefix_popc(m1);
+        m0 = __ballot(cnt0 > 0 && r0 % nks == slice);
+        m1 = __ballot(cnt1 > 0 && r1 % nks == slice);
+    }
     auto next_active = [&](int k) -> int {    // first active offset after k, or -1 (scalar)
         int kk = k + 1;
         if (kk < 64) {
@@ -152,10 +175,10 @@ __global__ __launch_bounds__(64, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             uint32_t ld4;
-            const char* src = src_of(j, ld4);
+            const char* src = src_of(cb + j, ld4);
 #pragma unroll
             for (int g = 0; g < NG; ++g) gather(j, g, src, ld4, wC[g]);
-            weights(j, kC, j);
+            weights(j, kC, cb + j);
         }
         list_load(kNN < 0 ? kNc : kNN, rawi, rawo);       // behind the step loads, as in the steady state
 
@@ -198,11 +221,11 @@ __global__ __launch_bounds__(64, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow
         };
 
         for (;;) {
-            for (int c0 = 0; c0 < NC; c0 += D) {
+            for (int c0 = cb; c0 < ce; c0 += D) {
                 // the D prefetches of this round target one offset: the current one, or -- in its last round -- the next
-                const bool wrap = c0 + D >= NC;
+                const bool wrap = c0 + D >= ce;
                 const int kT = wrap ? kNc : kC;
-                const int cT = wrap ? c0 + D - NC : c0 + D;
+                const int cT = wrap ? cb : c0 + D;
                 uint32_t wT[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) wT[g] = wrap ? wN[g] : wC[g];
@@ -257,6 +280,33 @@ __global__ __launch_bounds__(64, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow
     }
 
     // ---- write the strip (rows of the strip are 16-byte aligned: coalesced vector stores)
+    if constexpr (WPB > 1) {
+        __syncthreads();
+        if (wave != 0) return;
+        const bool plain = a.nslice == WPB && !a.accumulate;
+        for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+            const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
+            const int64_t grow = row0 + row;
+            if (grow >= a.n_out) continue;
+            f32x4 v = *(const f32x4*)&smem[row * PITCH + c4];
+#pragma unroll
+            for (int w = 1; w < WPB; ++w) v += *(const f32x4*)&smem[w * STRIP + row * PITCH + c4];
+            const int col = col0 + c4;
+            float* dst = a.y + grow * a.ldy + col;
+            if (plain && a.vec_store && col + 3 < a.cout) {
+                *(f32x4*)dst = v;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (col + u < a.cout) {
+                        if (plain) dst[u] = v[u];
+                        else if (v[u] != 0.f) atomicAdd(dst + u, v[u]);
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
