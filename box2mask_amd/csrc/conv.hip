@@ -835,14 +835,20 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchun
     }
 }
 
-// Software-pipelined variant for the common case (real rulebook, complete blocks, 32-bit addressable operands).
-// conv_wgrad_kernel above handles a slot as  list -> wait -> gathers -> wait -> 36..64 MFMAs : two exposed memory
-// round trips per ~1.2k cycles of MFMA work, MFMA pipe 54 % busy at 4 waves per SIMD.  Here the walk over the
-// non-empty slots of the chunk is flat and three stages deep: while the MFMAs of slot s run, the gathers of slot s+1
-// and the pair list of slot s+2 are in flight.  All loads are unconditional (padded pairs read row 0 and their B
-// values are zeroed by a select), so the waits are counted.
+// conv_wgrad_flow_kernel: the common case (real rulebook, complete blocks, 32-bit addressable operands).
+// conv_wgrad_kernel above handles a slot as  list -> wait -> gathers -> wait -> 36..64 MFMAs.  Here the walk over the
+// non-empty 16-pair slots of the chunk is flat and pipelined: the pair list is fetched two slots ahead, the operands one
+// slot ahead.  Differences to the first pipelined form (round 1):
+//  * a k-step (one MFMA per block element) covers the four CONSECUTIVE pairs 4s .. 4s+3 of the slot (lane quarter q
+//    supplies pair 4s + q; the words come from a cross-lane permute of the list), so a slot with n pairs needs only
+//    ceil(n/4) k-steps: the MFMAs of the empty ones are skipped (before: always 4; useful share of the executed
+//    MFMAs 0.8 -> 0.97);
+//  * every MFMA is an asm statement with the accumulator tied (in place).  With the builtin, hipcc kept the
+//    accumulators in AGPRs and copied all of them to VGPRs and back around every slot (108 moves per 36 MFMAs);
+//  * each slot issues the same number of loads (k-steps without pairs gather row 0: L1 hits), so the counted waits
+//    in front of the MFMAs are exact; the loads that refill a k-step's registers follow its MFMAs directly.
 template <int MI, int NJ>
-__global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
@@ -864,89 +870,104 @@ __global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(WgradArgs a) {
     if (live == 0) return;
 
     // flat walk: position = (tile index ti, group g); advance() returns false past the end
-    auto groups_of = [&](int ti) { return (__builtin_amdgcn_readlane(cnt, ti) + 15) >> 4; };
+    auto pairs_of = [&](int ti, int g) { const int n = __builtin_amdgcn_readlane(cnt, ti) - 16 * g; return n > 16 ? 16 : n; };
     auto advance = [&](int& ti, int& g) {
-        if (g + 1 < groups_of(ti)) { ++g; return true; }
+        if (16 * (g + 1) < __builtin_amdgcn_readlane(cnt, ti)) { ++g; return true; }
         const uint64_t rest_mask = ti >= 63 ? 0ull : (live >> (ti + 1));
         if (rest_mask == 0) return false;
         ti = ti + 1 + __builtin_ctzll(rest_mask); g = 0;
         return true;
     };
-    const int64_t kbase = (int64_t)k * ldr;
-    auto load_list = [&](int ti, int g, i32x4& rin, uint32_t& o4) {
-        const int64_t base = kbase + (t0 + ti) * B2M_TILE + 16 * g + 4 * q;
-        rin = *(const i32x4*)(a.rb_in + base);
-        o4 = *(const uint32_t*)(a.rb_out + base);
+    const int64_t kbase = (int64_t)k * ldr + t0 * B2M_TILE;
+    // list of a slot: lane (i, .) loads entry i; word = input row | row inside the tile << 24, bit 31 = no pair
+    auto load_list = [&](int ti, int g, int& r_in, int& r_out) {
+        const int64_t base = kbase + (int64_t)ti * B2M_TILE + 16 * g + i;
+        r_in = a.rb_in[base];
+        r_out = a.rb_out[base];
+    };
+    // the word of pair 4s + q for k-step s
+    auto words = [&](int r_in, int r_out, uint32_t (&w)[4]) {
+        const uint32_t word = r_in < 0 ? 0x80000000u : ((uint32_t)r_in | ((uint32_t)r_out << 24));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w[s] = (uint32_t)__builtin_amdgcn_ds_bpermute((4 * s + q) << 2, (int)word);
     };
     const uint32_t ldx4 = (uint32_t)a.ldx * 4u, lddy4 = (uint32_t)a.lddy * 4u;
     const uint32_t cxb = (uint32_t)(ci0 + i) * 4u, cyb = (uint32_t)(co0 + i) * 4u;
-    auto gather = [&](int ti, const i32x4& rin, uint32_t o4, float (&av)[4][MI], float (&bv)[4][NJ], int (&ok)[4]) {
+    float av[4][MI], bv[4][NJ];
+    // operands of k-step s of the slot in tile ti (MI + NJ loads, always)
+    auto gather = [&](int s, int ti, uint32_t word) {
         const uint32_t row0 = (uint32_t)((t0 + ti) * B2M_TILE);
+        const uint32_t bx = __umul24(word & 0xFFFFFFu, ldx4) + cxb;
+        const uint32_t by = __umul24(row0 + ((word >> 24) & 63u), lddy4) + cyb;
+        const char* px = (const char*)a.x + bx;
+        const char* py = (const char*)a.dy + by;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int r = rin[s];
-            ok[s] = r;
-            const uint32_t bx = __umul24((uint32_t)(r < 0 ? 0 : r), ldx4) + cxb;
-            const uint32_t by = __umul24(row0 + ((o4 >> (8 * s)) & 255), lddy4) + cyb;
-            const char* px = (const char*)a.x + bx;
-            const char* py = (const char*)a.dy + by;
+        for (int m = 0; m < MI; ++m) av[s][m] = *(const float*)(px + 64 * m);
 #pragma unroll
-            for (int m = 0; m < MI; ++m) av[s][m] = *(const float*)(px + 64 * m);
-#pragma unroll
-            for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = *(const float*)(py + 64 * nn);
-        }
+        for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = *(const float*)(py + 64 * nn);
     };
     f32x4 acc[MI][NJ];
 #pragma unroll
     for (int m = 0; m < MI; ++m)
 #pragma unroll
         for (int n = 0; n < NJ; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mfma = [&](const float (&av)[4][MI], const float (&bv)[4][NJ], const int (&ok)[4]) {
+
+    // prologue: list + operands of slot 0, list of slot 1, list load of slot 2
+    int tiC = __builtin_ctzll(live), gC = 0;
+    uint32_t wC[4], wN[4];
+    int rawi, rawo;
+    int tiN = tiC, gN = gC;
+    bool hasN = advance(tiN, gN);
+    {
+        int r0i, r0o, r1i, r1o;
+        load_list(tiC, gC, r0i, r0o);
+        load_list(hasN ? tiN : tiC, hasN ? gN : gC, r1i, r1o);
+        words(r0i, r0o, wC);
+        words(r1i, r1o, wN);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) gather(s, tiC, wC[s]);
+    int tiNN = tiN, gNN = gN;
+    bool hasNN = hasN && advance(tiNN, gNN);
+    load_list(hasNN ? tiNN : tiN, hasNN ? gNN : gN, rawi, rawo);
+    if (!hasN) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wN[s] = 0x80000000u;       // no next slot: the refills gather row 0 and are never used
+    }
+    int nkC = (pairs_of(tiC, gC) + 3) >> 2;
+
+    for (;;) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            float bz[NJ];
+            if (s < nkC) {                                       // wave-uniform
+                float bz[NJ];
 #pragma unroll
-            for (int nn = 0; nn < NJ; ++nn) bz[nn] = ok[s] >= 0 ? bv[s][nn] : 0.f;     // padded pair: contributes 0
+                for (int nn = 0; nn < NJ; ++nn) bz[nn] = (int)wC[s] >= 0 ? bv[s][nn] : 0.f;      // no pair: contributes 0
 #pragma unroll
-            for (int m = 0; m < MI; ++m)
+                for (int m = 0; m < MI; ++m)
 #pragma unroll
-                for (int nn = 0; nn < NJ; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][m], bz[nn], acc[m][nn], 0, 0, 0);
+                    for (int nn = 0; nn < NJ; ++nn)
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(av[s][m]), "v"(bz[nn]));
+            }
+            asm volatile("" ::: "memory");                       // the refill stays behind the MFMAs that read the registers
+            gather(s, tiN, wN[s]);
         }
-    };
-
-    // prologue: slot 0 list + gathers, slot 1 list
-    int ti = __builtin_ctzll(live), g = 0;
-    i32x4 l0, l1, l2; uint32_t o0, o1, o2;
-    float PA[4][MI], PB[4][NJ], QA[4][MI], QB[4][NJ];
-    int Pok[4], Qok[4];
-    load_list(ti, g, l0, o0);
-    int ti1 = ti, g1 = g;
-    bool has1 = advance(ti1, g1);
-    load_list(has1 ? ti1 : ti, has1 ? g1 : g, l1, o1);
-    gather(ti, l0, o0, PA, PB, Pok);
-    for (;;) {
-        // P holds slot s (in flight), l1 the list of slot s+1 (in flight)
-        int ti2 = ti1, g2 = g1;
-        const bool has2 = has1 && advance(ti2, g2);
-        load_list(has2 ? ti2 : ti1, has2 ? g2 : g1, l2, o2);
-        gather(ti1, l1, o1, QA, QB, Qok);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(PA, PB, Pok);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!has1) break;
-        // Q holds slot s+1, l2 the list of slot s+2
-        int ti3 = ti2, g3 = g2;
-        const bool has3 = has2 && advance(ti3, g3);
-        load_list(has3 ? ti3 : ti2, has3 ? g3 : g2, l0, o0);
-        gather(ti2, l2, o2, PA, PB, Pok);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(QA, QB, Qok);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!has2) break;
-        // rotate: P = slot s+2, its successor's list is in l0
-        ti1 = ti3; g1 = g3; has1 = has3; l1 = l0; o1 = o0;
+        if (!hasN) break;
+        // next slot becomes current; its successor's list has arrived; fetch one more
+        tiC = tiN; gC = gN;
+        nkC = (pairs_of(tiC, gC) + 3) >> 2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wC[s] = wN[s];
+        hasN = hasNN; tiN = tiNN; gN = gNN;
+        words(rawi, rawo, wN);
+        if (!hasN) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wN[s] = 0x80000000u;
+        }
+        hasNN = hasN && advance(tiNN, gNN);
+        load_list(hasNN ? tiNN : tiN, hasNN ? gNN : gN, rawi, rawo);
     }
+    asm volatile("s_nop 15" ::: "memory");          // MFMA result -> VALU / memory read: >= 12 wait states
 #pragma unroll
     for (int m = 0; m < MI; ++m)
 #pragma unroll
@@ -965,10 +986,10 @@ template <int MI>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
     if (a.pipe) {
         switch (NJ) {
-            case 1: conv_wgrad_pipe_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
-            case 2: conv_wgrad_pipe_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
-            case 3: conv_wgrad_pipe_kernel<MI, 3><<<grid, 256, 0, st>>>(a); break;
-            default: conv_wgrad_pipe_kernel<MI, 4><<<grid, 256, 0, st>>>(a); break;
+            case 1: conv_wgrad_flow_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
+            case 2: conv_wgrad_flow_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
+            case 3: conv_wgrad_flow_kernel<MI, 3><<<grid, 256, 0, st>>>(a); break;
+            default: conv_wgrad_flow_kernel<MI, 4><<<grid, 256, 0, st>>>(a); break;
         }
         return;
     }
