@@ -8,7 +8,7 @@
 Workload = BASELINE.json configs[1]: ScanNet 2 cm voxels, batch_size 8 per GPU, ~150 k voxels per scene,
 synthetic scenes (box2mask_amd/synth.py), random-init weights, fp32.  One JSON line on rank 0.
 `roofline` is measured live with HIP events around every launch of the dominant kernel
-(conv_fwd_kernel, forward + data-gradient) inside the timed region; `cpu_baseline` times the CPU
+(b2m_conv_fwd: conv_fwd_flow_kernel, forward + data-gradient) inside the timed region; `cpu_baseline` times the CPU
 oracle (kind "port": MinkowskiEngine itself is unavailable) on a bounded sample on rank 0 at N=1.
 """
 from __future__ import annotations
@@ -267,9 +267,9 @@ def main():
     fwd = agg.get('b2m_conv_fwd', dict(ms=0.0, flops=0.0, launches=0))
     wg = agg.get('b2m_conv_wgrad', dict(ms=0.0, flops=0.0, launches=0))
     roofline = roof(fwd, 'conv_fwd_kernel')
-    roofline['kernel'] = 'conv_fwd_kernel<16> (forward + data gradient)'
+    roofline['kernel'] = 'b2m_conv_fwd: conv_fwd_flow_kernel (+ conv_fwd_kernel for 1x1 / 6-channel layers), forward + data gradient'
     roofline_wgrad = roof(wg, 'conv_wgrad_kernel')
-    roofline_wgrad['kernel'] = 'conv_wgrad_kernel + conv_wgrad_pipe_kernel'
+    roofline_wgrad['kernel'] = 'b2m_conv_wgrad: conv_wgrad_flow_kernel (+ conv_wgrad_kernel for 1x1 layers)'
 
     value = scenes / elapsed
     result = {
@@ -285,7 +285,8 @@ def main():
                                '(BASELINE configs[1])' % args.batch_size,
                    'global_batch': world * args.batch_size, 'voxels_per_scene': n_vox // args.batch_size,
                    'voxels_per_gpu_batch': n_vox, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 4),
-                   'scene_gen_s': round(gen_s, 1), 'setup_steps': SETUP_STEPS},
+                   'scene_gen_s': round(gen_s, 1), 'setup_steps': SETUP_STEPS,
+                   'steps_executed': SETUP_STEPS + args.warmup + args.steps + 1 + args.steps},
         'roofline': roofline, 'roofline_wgrad': roofline_wgrad,
         # an HBM-bound kernel of the path, same live HIP-event method: BatchNorm apply (+residual, +ReLU) streams
         # 2-3 tensors per launch; small deep-level layers (launch-latency bound) are part of the average
@@ -365,11 +366,68 @@ def votes_leg(model, batch, cfg, cpu):
         res = model.pred2mask(cpu_batch, pred, 'eval')
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    # one more pass with HIP events around every kernel of the leg (own pass: the events serialise the stream)
+    from box2mask_amd import _lib
+    rec = []
+
+    def hook(name, a):
+        # algorithmic bytes per launch (every operand once)
+        if name == 'b2m_nmc_batch':        # boxes, desc, n_scenes, max_n, th, ...: boxes once + the heat-map rows written
+            nb = None                      # filled below from the results (needs the cluster counts)
+        elif name == 'b2m_mask_project':   # heat, n_fg, sel, ksel, fg_slot, seg2vox, n_vox, th, bits, words
+            nb = 12.0 * a[6] + 4.0 * a[3] * a[1] + 8.0 * a[3] * a[9]
+        elif name == 'b2m_mask_nms':       # bits, k, words, th, inter, keep, n_keep
+            nb = 8.0 * a[1] * a[2] + 4.0 * a[1] * a[1]
+        elif name == 'b2m_label_hist':     # bits, words, rows, k, sem, n_vox, n_class, labels
+            nb = 8.0 * a[3] * a[1] + 4.0 * a[5]
+        elif name == 'b2m_mask_gather':    # bits, words, rows, k, index, n_pts, out
+            nb = 8.0 * a[3] * a[1] + 8.0 * a[5] + 1.0 * a[3] * a[5]
+        else:
+            return None
+        s_ = torch.cuda.Event(enable_timing=True); e_ = torch.cuda.Event(enable_timing=True)
+        s_.record()
+
+        def done():
+            e_.record()
+            rec.append((name, s_, e_, nb))
+        return done
+    _lib.set_hook(hook)
+    model.pred2mask(cpu_batch, pred, 'eval')
+    torch.cuda.synchronize()
+    _lib.set_hook(None)
+    kern = {}
+    for name, s_, e_, nb in rec:
+        k_ = kern.setdefault(name[4:], dict(ms=0.0, bytes=0.0, launches=0))
+        k_['ms'] += s_.elapsed_time(e_); k_['launches'] += 1
+        if nb is not None:
+            k_['bytes'] += nb
     n_scenes = len(batch['scene'])
     fg_votes = int(is_fg(valid[sem_idx].long()).sum())
+    # the clustering launch: 28 B per foreground vote read + one fp32 heat-map row per cluster written (the cluster
+    # count per scene is read from the kernel's own output by re-running the stage alone)
+    from box2mask_amd import iou_nms
+    from box2mask_amd.util import to_bbs_min_max
+    bbs = to_bbs_min_max(cpu_batch['input_location'], pred[cfg.mlp_offsets], pred[cfg.mlp_bounds],
+                         torch.sigmoid(pred[cfg.mlp_bb_scores]))
+    fg_all = is_fg(valid[sem_idx].long())
+    per_scene = [bbs[(cpu_batch['batch_ids'] == b) & fg_all].float().cuda() for b in range(n_scenes)]
+    rs = iou_nms.nmc_device_batch(per_scene, float(cfg.eval_ths[0]))
+    if 'nmc_batch' in kern:
+        kern['nmc_batch']['bytes'] = float(sum(28 * r.n + 4 * r.k * r.n for r in rs if r is not None))
+        kern['nmc_batch']['clusters'] = int(sum(r.k for r in rs if r is not None))
+    table = {k: {'launches': v['launches'], 'ms': round(v['ms'], 4), 'algorithmic_bytes': int(v['bytes']),
+                 'gb_per_s': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 2)} for k, v in kern.items()}
+    dom = max(kern, key=lambda k: kern[k]['ms']) if kern else None
     out = {'value': round(n_scenes / dt, 2), 'unit': 'scenes/s', 'ms_per_scene': round(dt / n_scenes * 1e3, 3),
            'scenes': n_scenes, 'segments': int(S), 'foreground_votes': fg_votes,
            'instances': int(sum(len(r['conf']) for r in res.values())),
+           'kernels': table,
+           # the leg's dominant kernel against the HBM roofline.  nmc_kernel is K sequential IoU sweeps of one workgroup
+           # per scene over a few hundred boxes: latency-bound by construction, the fraction says so
+           'roofline': None if dom is None else {
+               'bound': 'hbm', 'kernel': dom, 'achieved': table[dom]['gb_per_s'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+               'frac': round(table[dom]['gb_per_s'] / PEAK_HBM_GBS, 6), 'traffic': None,
+               'device_ms_all_kernels': round(sum(v['ms'] for v in kern.values()), 3)},
            'flow': "Model.pred2mask(batch, pred, 'eval') with eval_ths %s; pred on the host as in "
                    "evaluation.py:86, masks returned to the host" % (list(cfg.eval_ths),)}
     # "mAP@0.5 vs ref" half of the metric: ScanNet AP of the device path's masks against the scenes' own instances
@@ -430,6 +488,27 @@ def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
         items, batch = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    # device time of the leg's kernels alone (HIP events around every b2m_* launch; own pass): the figure without the
+    # two host reads per scene (voxel and segment counts size the next allocations)
+    from box2mask_amd import _lib
+    rec = []
+
+    def hook(name, a):
+        s_ = torch.cuda.Event(enable_timing=True); e_ = torch.cuda.Event(enable_timing=True)
+        s_.record()
+
+        def done():
+            e_.record()
+            rec.append((name, s_, e_))
+        return done
+    _lib.set_hook(hook)
+    run()
+    torch.cuda.synchronize()
+    _lib.set_hook(None)
+    kernels_ms = sum(s_.elapsed_time(e_) for _, s_, e_ in rec)
+    by_kernel = {}
+    for name, s_, e_ in rec:
+        by_kernel[name[4:]] = round(by_kernel.get(name[4:], 0.0) + s_.elapsed_time(e_) / n_scenes, 4)
     pts = sum(int(sc['positions'].shape[0]) for sc in raw)
     nvox = int(batch['vox_coords'].shape[0])
     # bytes every correct implementation moves per scene: positions (24 B/pt) read by the key pass and by the two
@@ -440,7 +519,11 @@ def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
            'points': pts, 'voxels': nvox, 'points_per_s': round(pts / dt, 1),
            'roofline': {'bound': 'hbm', 'achieved': round(algo / dt / 1e9, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round(algo / dt / 1e9 / PEAK_HBM_GBS, 4), 'traffic': None,
-                        'note': 'whole leg incl. 2 host syncs per scene (voxel and segment counts)'}}
+                        'note': 'whole leg incl. 2 host syncs per scene (voxel and segment counts)',
+                        'kernels_only': {'ms_per_scene': round(kernels_ms / n_scenes, 3),
+                                         'achieved': round(algo / (kernels_ms * 1e-3) / 1e9, 2),
+                                         'frac': round(algo / (kernels_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                         'ms_per_scene_by_entry': by_kernel}}}
     if cpu:
         from oracle import prepare_ref
         sc = raw[0]

@@ -48,6 +48,7 @@ PROTOTYPES = {
     'b2m_segment_mean_sorted': [P, I64, I64, I32, P, P, I64, P, P, P],
     'b2m_segment_pool_bwd': [P, I64, I32, P, I64, I32, P, P, P, I64, P],
     'b2m_nmc': [P, I32, F32, I32, P, P, P, P, P, P],
+    'b2m_nmc_batch': [P, P, I32, I32, F32, P, P, P, P, P, P],
     'b2m_mask_project': [P, I32, P, I32, P, P, I64, F32, P, I64, P],
     'b2m_mask_nms': [P, I32, I64, F32, P, P, P, P],
     'b2m_label_hist': [P, I64, P, I32, P, I64, I32, P, P],
@@ -66,6 +67,9 @@ PROTOTYPES = {
     'b2m_seg_centroid': [P, P, I64, I64, F64, P, P, P, P, P],
     'b2m_box_membership': [P, I64, P, P, P, I32, P, P, P, P],
     'b2m_seg_box_vote': [P, I64, P, P, I64, I64, P, P, P, P, I32, P, P, P, P, P],
+    'b2m_obb_membership': [P, I64, P, P, P, I32, P, P, P],
+    'b2m_seg_rank': [P, I64, P, P, I64, P, P],
+    'b2m_seg_mode': [P, P, I64, I64, I32, P, P, P],
 }
 PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_device_ok': (C.c_int, []),
          'b2m_weight_pack_size': (C.c_int64, [I32, I32, I32]),

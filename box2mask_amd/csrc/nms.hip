@@ -65,10 +65,11 @@ __device__ __forceinline__ void bitonic_sort(P keys, int npad) {
     }
 }
 
-__global__ __launch_bounds__(NMC_THREADS) void nmc_kernel(const float* __restrict__ boxes, int n, float th, int max_k,
-                                                          int32_t* __restrict__ reps, int32_t* __restrict__ assign,
-                                                          float* __restrict__ heat, int32_t* __restrict__ k_out,
-                                                          uint64_t* __restrict__ order, int npad) {
+// one workgroup clusters the n boxes of one scene
+__device__ __forceinline__ void nmc_scene(const float* __restrict__ boxes, int n, float th, int max_k,
+                                          int32_t* __restrict__ reps, int32_t* __restrict__ assign,
+                                          float* __restrict__ heat, int32_t* __restrict__ k_out,
+                                          uint64_t* __restrict__ order, int npad) {
     __shared__ uint64_t skeys[NMC_LDS_SORT];
     __shared__ uint32_t alive[NMC_MAX_N / 32];
     __shared__ int s_first;
@@ -136,6 +137,40 @@ __global__ __launch_bounds__(NMC_THREADS) void nmc_kernel(const float* __restric
         __syncthreads();
     }
     if (tid == 0) *k_out = kc;
+}
+__global__ __launch_bounds__(NMC_THREADS) void nmc_kernel(const float* __restrict__ boxes, int n, float th, int max_k,
+                                                          int32_t* __restrict__ reps, int32_t* __restrict__ assign,
+                                                          float* __restrict__ heat, int32_t* __restrict__ k_out,
+                                                          uint64_t* __restrict__ order, int npad) {
+    nmc_scene(boxes, n, th, max_k, reps, assign, heat, k_out, order, npad);
+}
+// all scenes of a batch in one launch: workgroup s clusters scene s (descriptor row s = box_off, n, npad, max_k,
+// heat_off, order_off; boxes / reps / assign are the per-scene arrays back to back)
+#define NMC_DESC 6
+__global__ __launch_bounds__(NMC_THREADS) void nmc_batch_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ desc,
+                                                                float th, int32_t* __restrict__ reps,
+                                                                int32_t* __restrict__ assign, float* __restrict__ heat,
+                                                                int32_t* __restrict__ k_out, uint64_t* __restrict__ order) {
+    const int64_t* d = desc + (int64_t)blockIdx.x * NMC_DESC;
+    const int64_t box_off = d[0];
+    const int n = (int)d[1], npad = (int)d[2], max_k = (int)d[3];
+    if (n == 0) {
+        if (threadIdx.x == 0) k_out[blockIdx.x] = 0;
+        return;
+    }
+    nmc_scene(boxes + box_off * 7, n, th, max_k, reps + box_off, assign + box_off, heat + d[4], k_out + blockIdx.x,
+              order + d[5], npad);
+}
+extern "C" int b2m_nmc_batch(const float* boxes, const int64_t* desc, int32_t n_scenes, int32_t max_n, float cluster_th,
+                             int32_t* reps, int32_t* assign, float* heat, int32_t* k_out, uint64_t* order, void* stream) {
+    B2M_CHECK_ARG(n_scenes >= 0 && max_n >= 0 && max_n <= NMC_MAX_N, "every scene must have <= 262144 boxes");
+    B2M_CHECK_ARG(cluster_th > 0.f && cluster_th < 1.f, "cluster_th must be in (0,1)");   // iou_nms.py:71
+    if (n_scenes == 0) return B2M_OK;
+    B2M_CHECK_ARG(desc && k_out && (max_n == 0 || (boxes && reps && assign && order)), "NULL argument");
+    nmc_batch_kernel<<<(unsigned)n_scenes, NMC_THREADS, 0, (hipStream_t)stream>>>(boxes, desc, cluster_th, reps, assign, heat,
+                                                                                  k_out, order);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
 }
 
 extern "C" int b2m_nmc(const float* boxes, int32_t n, float cluster_th, int32_t max_k, int32_t* reps, int32_t* assign,

@@ -451,3 +451,102 @@ extern "C" int b2m_seg_box_vote(const int64_t* segments, int64_t n_pts, const ui
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
+
+// ------------------------------------------------------------------ the other association branches
+// Oriented boxes (ARKitScenes.approx_association, dataloader.py:545-557): point p is in box b iff
+// -h_b <= R_b (p - c_b) <= h_b on every axis (closed).  fp64, products summed x, y, z without contraction.
+#define OBB_CHUNK 256
+__global__ void obb_membership_kernel(const double* __restrict__ pos, int64_t n, const double* __restrict__ centers,
+                                      const double* __restrict__ rot, const double* __restrict__ half, int32_t nb,
+                                      int32_t* __restrict__ count, int32_t* __restrict__ first_bb) {
+#pragma clang fp contract(off)
+    __shared__ double sc[OBB_CHUNK * 3], sr[OBB_CHUNK * 9], sh[OBB_CHUNK * 3];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double x = 0, y = 0, z = 0;
+    if (p < n) { x = pos[3 * p]; y = pos[3 * p + 1]; z = pos[3 * p + 2]; }
+    int c = 0, first = -1;
+    for (int b0 = 0; b0 < nb; b0 += OBB_CHUNK) {
+        const int m = nb - b0 < OBB_CHUNK ? nb - b0 : OBB_CHUNK;
+        __syncthreads();
+        for (int e = threadIdx.x; e < m * 3; e += blockDim.x) { sc[e] = centers[(int64_t)b0 * 3 + e]; sh[e] = half[(int64_t)b0 * 3 + e]; }
+        for (int e = threadIdx.x; e < m * 9; e += blockDim.x) sr[e] = rot[(int64_t)b0 * 9 + e];
+        __syncthreads();
+        for (int b = 0; b < m; ++b) {
+            const double dx = x - sc[3 * b], dy = y - sc[3 * b + 1], dz = z - sc[3 * b + 2];
+            bool in = true;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double v = (sr[9 * b + 3 * j] * dx + sr[9 * b + 3 * j + 1] * dy) + sr[9 * b + 3 * j + 2] * dz;
+                in = in && v >= -sh[3 * b + j] && v <= sh[3 * b + j];
+            }
+            if (in) {
+                if (c == 0) first = b0 + b;
+                ++c;
+            }
+        }
+    }
+    if (p < n) { count[p] = c; first_bb[p] = first; }
+}
+extern "C" int b2m_obb_membership(const double* pos, int64_t n_pts, const double* centers, const double* rotations,
+                                  const double* half_sizes, int32_t n_boxes, int32_t* count, int32_t* first_bb,
+                                  void* stream) {
+    B2M_CHECK_ARG(pos && count && first_bb && n_pts >= 0 && n_boxes >= 0, "bad arguments");
+    B2M_CHECK_ARG(n_boxes == 0 || (centers && rotations && half_sizes), "NULL boxes");
+    if (n_pts > 0)
+        obb_membership_kernel<<<(unsigned)cdiv64(n_pts, 256), 256, 0, (hipStream_t)stream>>>(pos, n_pts, centers, rotations,
+                                                                                             half_sizes, n_boxes, count, first_bb);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// rank of every point's segment among the voxel-level segments (-1: the segment has no voxel)
+__global__ void seg_rank_kernel(const int64_t* __restrict__ segments, int64_t n, const uint64_t* __restrict__ tkeys,
+                                const int32_t* __restrict__ tvals, int64_t mask, int32_t* __restrict__ seg_of_point) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t s = b2m_find(tkeys, mask, (uint64_t)segments[p]);
+    seg_of_point[p] = s < 0 ? -1 : tvals[s];
+}
+extern "C" int b2m_seg_rank(const int64_t* segments, int64_t n_pts, const uint64_t* tkeys, const int32_t* tvals,
+                            int64_t cap, int32_t* seg_of_point, void* stream) {
+    B2M_CHECK_ARG(segments && tkeys && tvals && seg_of_point && pow2(cap) && n_pts >= 0, "bad arguments");
+    if (n_pts > 0)
+        seg_rank_kernel<<<(unsigned)cdiv64(n_pts, 256), 256, 0, (hipStream_t)stream>>>(segments, n_pts, tkeys, tvals, cap - 1,
+                                                                                       seg_of_point);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// Majority vote per segment (scipy.stats.mode over the points of a segment, dataloader.py:262-270, 913-921):
+// the most frequent class, the LOWEST class index on ties (classes are numbered in ascending order of their value, which is
+// scipy's tie rule).  hist: int32[n_seg * n_class] scratch.
+__global__ void seg_class_hist_kernel(const int32_t* __restrict__ seg_of_point, const int32_t* __restrict__ cls, int64_t n,
+                                      int32_t n_class, int32_t* __restrict__ hist) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t r = seg_of_point[p];
+    if (r >= 0) atomicAdd(&hist[(int64_t)r * n_class + cls[p]], 1);
+}
+__global__ void seg_mode_pick_kernel(const int32_t* __restrict__ hist, int64_t n_seg, int32_t n_class,
+                                     int32_t* __restrict__ mode_cls) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    int best = 0, bc = -1;
+    for (int c = 0; c < n_class; ++c) {
+        const int v = hist[s * n_class + c];
+        if (v > bc) { bc = v; best = c; }
+    }
+    mode_cls[s] = best;
+}
+extern "C" int b2m_seg_mode(const int32_t* seg_of_point, const int32_t* cls, int64_t n_pts, int64_t n_seg, int32_t n_class,
+                            int32_t* hist, int32_t* mode_cls, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(seg_of_point && cls && hist && mode_cls && n_pts >= 0 && n_seg >= 0 && n_class >= 1, "bad arguments");
+    if (n_seg == 0) return B2M_OK;
+    B2M_HIP(hipMemsetAsync(hist, 0, (size_t)n_seg * n_class * sizeof(int32_t), st));
+    if (n_pts > 0)
+        seg_class_hist_kernel<<<(unsigned)cdiv64(n_pts, 256), 256, 0, st>>>(seg_of_point, cls, n_pts, n_class, hist);
+    seg_mode_pick_kernel<<<(unsigned)cdiv64(n_seg, 256), 256, 0, st>>>(hist, n_seg, n_class, mode_cls);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}

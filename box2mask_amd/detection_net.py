@@ -203,81 +203,112 @@ class SelectionNet(ResNetBase):
             pred_semantics = self.semantic_valid_class_ids.to(pdev)[pred_semantics].long()
         n_class = int(max(int(self.semantic_valid_class_ids.max()) + 1, 1))
         batch_ids = batch['batch_ids'].to(pdev)
-        results = {}
+        # The reference walks the scenes one by one (detection_net.py:390-477).  Here every stage runs for ALL scenes
+        # before its (small) results are read back ONCE: clusters of the whole batch in one launch, then the score
+        # filter, the mask NMS flags and the labels -- four host reads per batch instead of about ten per scene.
+        # ---------- stage 0: per-scene inputs
+        sc = []
         vox_start = 0
         for scene_idx, scene in enumerate(batch['scene']):
             scene_mask = batch_ids == scene_idx
             seg2vox = torch.as_tensor(batch['seg2vox'][scene_idx]).long()
             n_vox = seg2vox.shape[0]
+            s2v = seg2vox.to(dev)
             if not self.requires_voxel_outputs:
                 scene_pred_semantics = pred_semantics[scene_mask]
                 scene_pred_fg = self.is_foreground(scene_pred_semantics)
-                sem_vox = scene_pred_semantics.to(dev)[seg2vox.to(dev)]
+                sem_vox = scene_pred_semantics.to(dev)[s2v]
             else:
                 # S3DIS flow (detection_net.py:398-415): per-voxel semantics, majority vote per segment
                 sem_vox_all = pred_semantics[vox_start:vox_start + n_vox] if pred_semantics.shape[0] != n_vox \
                     else pred_semantics
                 sem_vox = sem_vox_all.to(dev)
-                s2v = seg2vox.to(dev)
                 n_seg = int(s2v.max()) + 1
                 votes = torch.bincount(s2v * n_class + sem_vox, minlength=n_seg * n_class).reshape(n_seg, n_class)
                 scene_pred_fg = self.is_foreground(torch.argmax(votes, 1)).to(pdev)
             vox_start += n_vox
             scene_pred_bbs = pred_bbs[scene_mask][scene_pred_fg]
             boxes = scene_pred_bbs.detach().to(dev, torch.float32).contiguous()
-            n_fg = boxes.shape[0]
-
-            # ---------- instance clusters (iou_nms.py:68-105)
-            r = iou_nms.nmc_device(boxes, cluster_th)
-            reps = r.reps[:r.k].long()
-            scores = boxes[reps, 0]
-            # ---------- score filter (detection_net.py:427-432)
-            sel = torch.nonzero(scores > score_th).reshape(-1) if score_filtering else torch.arange(r.k, device=dev)
-            ksel = sel.shape[0]
-            # ---------- heat-maps -> voxel masks (436-446): zero-padded background, seg2vox projection
+            if boxes.shape[0] == 0:
+                # the reference crashes on a scene without foreground votes (torch.stack([]), iou_nms.py:103)
+                raise ValueError('NMS_clustering needs at least one box (the reference raises on n == 0 as well)')
             fg_dev = scene_pred_fg.to(dev)
             fg_slot = torch.where(fg_dev, torch.cumsum(fg_dev.int(), 0) - 1, torch.full_like(fg_dev.int(), -1)).int()
-            s2v = seg2vox.to(dev)
-            words = (n_vox + 63) // 64
-            bits = torch.empty((max(ksel, 1), max(words, 1)), dtype=torch.int64, device=dev)
-            sel32 = sel.int().contiguous()
-            _call('b2m_mask_project', r.heat.data_ptr(), n_fg, sel32.data_ptr(), ksel, fg_slot.data_ptr(),
-                  s2v.data_ptr(), n_vox, float(mask_bin_th), bits.data_ptr(), words)
-            # ---------- duplicate removal (448): mask NMS, skipped for per-voxel predictions (449-451)
+            sc.append(dict(name=scene['name'], idx=scene_idx, s2v=s2v, n_vox=n_vox, sem32=sem_vox.int().contiguous(),
+                           fg=scene_pred_fg, fg_dev=fg_dev, fg_slot=fg_slot, bbs=scene_pred_bbs, boxes=boxes,
+                           n_fg=boxes.shape[0], words=(n_vox + 63) // 64))
+        if not sc:
+            return {}
+        # ---------- stage 1: instance clusters (iou_nms.py:68-105), all scenes in one launch
+        rs = iou_nms.nmc_device_batch([d['boxes'] for d in sc], cluster_th)
+        # ---------- stage 2: score filter (detection_net.py:427-432) on the host from one read of the representatives' scores
+        rep_scores = torch.cat([d['boxes'][r.reps[:r.k].long(), 0] for d, r in zip(sc, rs)]).cpu().numpy()
+        reps_host = torch.cat([r.reps[:r.k] for r in rs]).cpu().numpy().astype(np.int64)
+        o = 0
+        for d, r in zip(sc, rs):
+            d['reps'] = reps_host[o:o + r.k]
+            scores = rep_scores[o:o + r.k]
+            o += r.k
+            sel = np.nonzero(scores > np.float32(score_th))[0] if score_filtering else np.arange(r.k)
+            d['sel'] = sel.astype(np.int64)
+            d['sel32'] = torch.from_numpy(sel.astype(np.int32)).to(dev)
+        # ---------- heat-maps -> voxel masks (436-446): zero-padded background, seg2vox projection; duplicate removal
+        # (448): mask NMS, skipped for per-voxel predictions (449-451)
+        for d, r in zip(sc, rs):
+            ksel = d['sel'].shape[0]
+            d['bits'] = torch.empty((max(ksel, 1), max(d['words'], 1)), dtype=torch.int64, device=dev)
+            _call('b2m_mask_project', r.heat.data_ptr(), d['n_fg'], d['sel32'].data_ptr(), ksel, d['fg_slot'].data_ptr(),
+                  d['s2v'].data_ptr(), d['n_vox'], float(mask_bin_th), d['bits'].data_ptr(), d['words'])
+            d['keep'] = None
             if not self.requires_voxel_outputs and ksel > 0:
-                keep, _ = iou_nms.mask_nms_device(bits, ksel, words, mask_nms_th)
-                kept = torch.nonzero(keep).reshape(-1)
+                d['keep'], _ = iou_nms.mask_nms_device(d['bits'], ksel, d['words'], mask_nms_th)
+        flags = [d['keep'] for d in sc if d['keep'] is not None]
+        keep_host = torch.cat(flags).cpu().numpy() if flags else np.zeros(0, np.int32)
+        o = 0
+        for d in sc:
+            ksel = d['sel'].shape[0]
+            if d['keep'] is not None:
+                d['kept'] = np.nonzero(keep_host[o:o + ksel])[0].astype(np.int64)
+                o += ksel
             else:
-                kept = torch.arange(ksel, device=dev)
-            kk = kept.shape[0]
-            kept32 = kept.int().contiguous()
-            # ---------- label per instance: argmax of the label histogram inside the mask (461-466)
-            labels = torch.zeros(max(kk, 1), dtype=torch.int32, device=dev)
-            sem32 = sem_vox.int().contiguous()
-            _call('b2m_label_hist', bits.data_ptr(), words, kept32.data_ptr(), kk, sem32.data_ptr(), n_vox, n_class,
-                  labels.data_ptr())
-            instance_labels = labels[:kk].cpu().numpy().astype('int32')
-            final_rows = sel[kept]                       # cluster row of every surviving instance
-            bb_scores = scene_pred_bbs[reps[final_rows].to(pdev), 0]
+                d['kept'] = np.arange(ksel, dtype=np.int64)
+            d['kept32'] = torch.from_numpy(d['kept'].astype(np.int32)).to(dev)
+        # ---------- label per instance: argmax of the label histogram inside the mask (461-466)
+        for d in sc:
+            kk = d['kept'].shape[0]
+            d['labels'] = torch.zeros(max(kk, 1), dtype=torch.int32, device=dev)
+            _call('b2m_label_hist', d['bits'].data_ptr(), d['words'], d['kept32'].data_ptr(), kk, d['sem32'].data_ptr(),
+                  d['n_vox'], n_class, d['labels'].data_ptr())
+        labels_host = torch.cat([d['labels'][:d['kept'].shape[0]] for d in sc]).cpu().numpy().astype('int32')
+        results = {}
+        o = 0
+        for d, r in zip(sc, rs):
+            kk = d['kept'].shape[0]
+            instance_labels = labels_host[o:o + kk]
+            o += kk
+            final_rows = d['sel'][d['kept']]             # cluster row of every surviving instance
+            rep_rows = torch.from_numpy(d['reps'][final_rows]).to(pdev)
+            bb_scores = d['bbs'][rep_rows, 0]
             if mode == 'eval':
-                v2p = torch.as_tensor(batch['vox2point'][scene_idx]).long().to(dev)
+                v2p = torch.as_tensor(batch['vox2point'][d['idx']]).long().to(dev)
                 n_pts = v2p.shape[0]
                 out = torch.empty((kk, n_pts), dtype=torch.uint8, device=dev)
-                _call('b2m_mask_gather', bits.data_ptr(), words, kept32.data_ptr(), kk, v2p.data_ptr(), n_pts,
+                _call('b2m_mask_gather', d['bits'].data_ptr(), d['words'], d['kept32'].data_ptr(), kk, v2p.data_ptr(), n_pts,
                       out.data_ptr())
-                results[scene['name']] = {'conf': bb_scores, 'label_id': instance_labels,
-                                          'mask': out.bool().to(pdev)}
+                results[d['name']] = {'conf': bb_scores, 'label_id': instance_labels, 'mask': out.bool().to(pdev)}
             else:
-                out = torch.empty((kk, n_vox), dtype=torch.uint8, device=dev)
-                _call('b2m_mask_gather', bits.data_ptr(), words, kept32.data_ptr(), kk, None, n_vox, out.data_ptr())
-                heat_w_bg = torch.zeros((kk, fg_dev.shape[0]), device=dev)
-                heat_w_bg[:, fg_dev] = r.heat[final_rows]
-                results[scene['name']] = {
+                out = torch.empty((kk, d['n_vox']), dtype=torch.uint8, device=dev)
+                _call('b2m_mask_gather', d['bits'].data_ptr(), d['words'], d['kept32'].data_ptr(), kk, None, d['n_vox'],
+                      out.data_ptr())
+                fr = torch.from_numpy(final_rows).to(dev)
+                heat_w_bg = torch.zeros((kk, d['fg_dev'].shape[0]), device=dev)
+                heat_w_bg[:, d['fg_dev']] = r.heat[fr]
+                results[d['name']] = {
                     'conf': bb_scores, 'label_id': instance_labels, 'mask': out.bool().to(pdev),
-                    'cluster_representatives': reps[final_rows].to(pdev),
-                    'cluster_heatmaps': heat_w_bg[:, s2v].to(pdev),
-                    'bbs': scene_pred_bbs[reps[final_rows].to(pdev)],
-                    'pred_fg': scene_pred_fg,
+                    'cluster_representatives': rep_rows,
+                    'cluster_heatmaps': heat_w_bg[:, d['s2v']].to(pdev),
+                    'bbs': d['bbs'][rep_rows],
+                    'pred_fg': d['fg'],
                 }
         return results
 

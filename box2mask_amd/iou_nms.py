@@ -75,6 +75,54 @@ def nmc_device(boxes_dev: torch.Tensor, cluster_th: float, max_k: int | None = N
     return res
 
 
+def nmc_device_batch(boxes_list, cluster_th: float):
+    """Cluster the boxes of every scene of a batch in ONE launch (one workgroup per scene) and read the cluster counts
+    back once.  `boxes_list`: per scene an (n_s, 7) fp32 device tensor (n_s may be 0).  Returns a list of NMCResult
+    (None for an empty scene), each identical to nmc_device() on that scene alone."""
+    assert 0 < cluster_th < 1
+    S = len(boxes_list)
+    if S == 0:
+        return []
+    dev = boxes_list[0].device
+    ns = [int(b.shape[0]) for b in boxes_list]
+    desc = np.zeros((S, 6), np.int64)
+    box_off = heat_off = order_off = 0
+    for s, n in enumerate(ns):
+        npad = 2
+        while npad < n:
+            npad <<= 1
+        mk = min(n, 256)
+        desc[s] = (box_off, n, npad, mk, heat_off, order_off)
+        box_off += n; heat_off += mk * n; order_off += npad
+    boxes = torch.cat([b.reshape(-1, 7) for b in boxes_list], 0).contiguous() if box_off else \
+        torch.zeros((1, 7), dtype=torch.float32, device=dev)
+    reps = torch.empty(max(box_off, 1), dtype=torch.int32, device=dev)
+    assign = torch.empty(max(box_off, 1), dtype=torch.int32, device=dev)
+    heat = torch.empty(max(heat_off, 1), dtype=torch.float32, device=dev)
+    order = torch.empty(max(order_off, 1), dtype=torch.int64, device=dev)
+    kout = torch.zeros(S, dtype=torch.int32, device=dev)
+    desc_dev = torch.from_numpy(desc).to(dev)
+    _call('b2m_nmc_batch', boxes.data_ptr(), desc_dev.data_ptr(), S, max(ns), float(cluster_th), reps.data_ptr(),
+          assign.data_ptr(), heat.data_ptr(), kout.data_ptr(), order.data_ptr())
+    ks = kout.cpu().tolist()                                    # the one host read of the stage
+    out = []
+    for s, n in enumerate(ns):
+        if n == 0:
+            out.append(None)
+            continue
+        bo, _, npad, mk, ho, oo = (int(v) for v in desc[s])
+        if ks[s] > mk:                                          # rare: more clusters than heat rows reserved
+            out.append(nmc_device(boxes[bo:bo + n], cluster_th, max_k=ks[s]))
+            continue
+        r = NMCResult()
+        r.n, r.k = n, ks[s]
+        r.reps, r.assign = reps[bo:bo + n], assign[bo:bo + n]
+        r.order = order[oo:oo + npad]
+        r.heat = heat[ho:ho + mk * n].reshape(mk, n)[:ks[s]]
+        out.append(r)
+    return out
+
+
 def NMS_clustering(boxes, cluster_th=0.5, get_heatmaps=True):
     """Greedy non-maximum clustering (iou_nms.py:68-105).  Returns
     (representatives int64 (K,), clusters list[K] of index tensors, heatmaps (K,n) fp32)."""

@@ -243,6 +243,14 @@ int b2m_segment_pool_bwd(const float* dout, int64_t n, int32_t c, const int64_t*
 int b2m_nmc(const float* boxes, int32_t n, float cluster_th, int32_t max_k,
             int32_t* reps, int32_t* assign, float* heat, int32_t* k_out, uint64_t* order, void* stream);
 
+/* The same for all scenes of a batch in ONE launch (one workgroup per scene; the per-scene loop of
+ * SelectionNet.detection2mask, models/detection_net.py:390-425).  boxes / reps / assign hold the scenes back to back;
+ * desc (device, int64[n_scenes][6]) = {first box row, n, npow2(n) (>= 2), max_k, first heat element, first order
+ * element} per scene; k_out[n_scenes].  max_n = the largest n (<= 262144).  Scene s gets exactly what b2m_nmc returns
+ * for its boxes. */
+int b2m_nmc_batch(const float* boxes, const int64_t* desc, int32_t n_scenes, int32_t max_n, float cluster_th,
+                  int32_t* reps, int32_t* assign, float* heat, int32_t* k_out, uint64_t* order, void* stream);
+
 /* Heat-map rows -> voxel bit masks.  For selected cluster rows sel[0:ksel] of heat (k x n_fg):
  * value(v) = fg_slot[seg2vox[v]] >= 0 ? heat[sel[r], fg_slot[seg2vox[v]]] : 0;
  * bit v of bits[r*words + v/64] = value(v) > mask_bin_th.  Replaces models/detection_net.py:436-446

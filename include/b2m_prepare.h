@@ -83,6 +83,25 @@ int b2m_seg_box_vote(const int64_t* segments, int64_t n_pts, const uint64_t* tke
                      const int64_t* instance_ids, int32_t smallest_bb_heuristic, uint64_t* best,
                      int32_t* seg_of_point, int64_t* inst_per_seg, int64_t* inst_per_point, void* stream);
 
+/* ---- the other association branches ---- */
+
+/* Oriented boxes of ARKitScenes.approx_association (dataloader.py:545-557): count[p] = number of boxes b with
+ * -half[b] <= R_b (pos[p] - centers[b]) <= half[b] on every axis (closed; R_b row-major 3x3, everything fp64),
+ * first_bb[p] = the lowest such b or -1. */
+int b2m_obb_membership(const double* pos, int64_t n_pts, const double* centers, const double* rotations,
+                       const double* half_sizes, int32_t n_boxes, int32_t* count, int32_t* first_bb, void* stream);
+
+/* seg_of_point[p] = rank of point p's segment among the voxel-level segments (table of b2m_unique_rank), -1 when the
+ * segment has no voxel: the `seg_id == scene['segments']` masks of dataloader.py:265, 281, 866, 914 in one pass. */
+int b2m_seg_rank(const int64_t* segments, int64_t n_pts, const uint64_t* tkeys, const int32_t* tvals, int64_t cap,
+                 int32_t* seg_of_point, void* stream);
+
+/* mode_cls[s] = most frequent class among the points of segment s, lowest class index on ties: scipy.stats.mode of
+ * dataloader.py:267 (majority_vote) and :916-917 (S3DIS) when the classes are numbered in ascending order of their
+ * value.  cls[p] in [0, n_class); hist: int32[n_seg * n_class] scratch. */
+int b2m_seg_mode(const int32_t* seg_of_point, const int32_t* cls, int64_t n_pts, int64_t n_seg, int32_t n_class,
+                 int32_t* hist, int32_t* mode_cls, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

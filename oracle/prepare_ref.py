@@ -140,3 +140,124 @@ def bbs_supervision(item, labels, inst_per_seg):
     gt_semantics[gt_unlabeled] = 0                                                   # :200
     return {'fg_instances': fg, 'gt_bb_bounds': gt_bb_bounds, 'gt_bb_offsets': gt_bb_offsets,
             'gt_semantics': gt_semantics}
+
+
+# ------------------------------------------------------------------ the other association branches
+def _mode(values):
+    """scipy.stats.mode(values, None)[0][0] of the reference's SciPy (< 1.11): the most frequent value, the smallest
+    one on ties."""
+    u, c = np.unique(values, return_counts=True)
+    return u[np.argmax(c)]
+
+
+def _scannet_boxes(labels):
+    semantics = np.asarray(labels['per_instance_semantics'])
+    scene_fg = (semantics > 2) & (semantics != 22)                                   # dataloader.py:207-208
+    centers = np.asarray(labels['per_instance_bb_centers'])[scene_fg]
+    bounds = np.asarray(labels['per_instance_bb_bounds'])[scene_fg] + 0.005
+    return centers - bounds, centers + bounds, np.asarray(labels['unique_instances'])[scene_fg], np.prod(2 * bounds, axis=1)
+
+
+def _occupancy(positions, min_corner, max_corner):
+    return (np.all(positions[None] >= min_corner[:, None], axis=-1) &
+            np.all(positions[None] <= max_corner[:, None], axis=-1))                 # utils/util.py:91-92, (B, P)
+
+
+def approx_association_points(positions, segments, labels, unique_segs, smallest_bb_heuristic, majority_vote):
+    """dataloader.py:241-272: the point_association (majority_vote=False -> (inst_per_point, None)) and the
+    majority_vote branch of ScanNet.approx_association (no dropout / noise)."""
+    min_corner, max_corner, instance_ids, bb_volume = _scannet_boxes(labels)
+    occ = _occupancy(positions, min_corner, max_corner)
+    num = occ.sum(axis=0)
+    inst_per_point = np.full(len(positions), -1, np.int64)                           # :244
+    for i in range(len(positions)):
+        if num[i] == 1:
+            inst_per_point[i] = instance_ids[np.nonzero(occ[:, i])[0][0]]            # :246-248
+        elif num[i] > 1:
+            if not smallest_bb_heuristic:
+                inst_per_point[i] = -2                                               # :250-251
+            else:
+                box_ids = np.nonzero(occ[:, i])[0]
+                inst_per_point[i] = instance_ids[box_ids[np.argmin(bb_volume[box_ids])]]   # :253-256
+    if not majority_vote:
+        return inst_per_point, None                                                  # :258-259
+    segments = np.asarray(segments)
+    pooled = np.full(len(positions), -2, np.int64)                                   # :263-264
+    per_seg = np.full(len(unique_segs), -2, np.int64)
+    for i, seg_id in enumerate(unique_segs):                                         # :265-270
+        m = seg_id == segments
+        per_seg[i] = _mode(inst_per_point[m])
+        pooled[m] = per_seg[i]
+    return pooled, per_seg
+
+
+def arkit_association(positions, segments, labels, unique_segs, point_association):
+    """ARKitScenes.approx_association, dataloader.py:539-621: oriented boxes, point or segment association."""
+    instance_ids = np.asarray(labels['unique_instances'])
+    centers = np.asarray(labels['per_instance_bb_centers'])
+    bounds = np.asarray(labels['per_instance_bb_bounds']) + 0.05                     # :547
+    rotations = np.asarray(labels['per_instance_bb_rotations'])
+    occ = np.zeros([rotations.shape[0], positions.shape[0]], dtype=bool)
+    for i in range(rotations.shape[0]):                                              # :553-557
+        pc = positions - centers[i]
+        rot = np.reshape(rotations[i], [3, 3])
+        q = (rot @ pc.T).T
+        occ[i] = np.all(q >= -bounds[i, :], axis=-1) & np.all(q <= bounds[i, :], axis=-1)
+    num = occ.sum(axis=0)
+    if point_association:                                                            # :568-578
+        inst_per_point = np.full(len(positions), -1, np.int64)
+        one = num == 1
+        inst_per_point[one] = instance_ids[np.argmax(occ[:, one], axis=0)]
+        inst_per_point[num > 1] = -2
+        return inst_per_point, None
+    segments = np.asarray(segments)
+    pooled = np.full(len(positions), -2, np.int64)                                   # :599-600
+    per_seg = np.full(len(unique_segs), -2, np.int64)
+    for i, seg_id in enumerate(unique_segs):                                         # :601-616
+        idx = np.nonzero(seg_id == segments)[0]
+        n_on = num[idx]
+        m = n_on.min()
+        if m == 1:
+            p = idx[np.nonzero(n_on == 1)[0][0]]
+            per_seg[i] = instance_ids[np.nonzero(occ[:, p])[0][0]]
+            pooled[idx] = per_seg[i]
+        elif m == 0:
+            per_seg[i] = -1
+            pooled[idx] = -1
+    return pooled, per_seg
+
+
+def s3dis_association(positions, segments, labels, unique_segs, point_association, ignore_wall_ceiling_floor):
+    """S3DIS.approx_association, dataloader.py:805-927."""
+    semantics = np.asarray(labels['per_instance_semantics'])
+    scene_fg = (semantics > 2) if ignore_wall_ceiling_floor else (semantics >= 0)    # dataprocessing/s3dis.py:79-82
+    inst = np.full(len(positions), -1, np.int64)
+    sem = np.full(len(positions), -1, np.int64)
+    for part, sel in enumerate((scene_fg, ~scene_fg)):                               # :813-852, :871-900
+        ids = np.asarray(labels['unique_instances'])[sel]
+        sids = semantics[sel]
+        centers = np.asarray(labels['per_instance_bb_centers'])[sel]
+        bounds = np.asarray(labels['per_instance_bb_bounds'])[sel] + 0.0001
+        occ = _occupancy(positions, centers - bounds, centers + bounds)
+        num = occ.sum(axis=0)
+        open_ = (inst == -1) if part == 1 else np.ones(len(positions), bool)
+        for b in range(len(ids)):
+            m = occ[b] & (num == 1) & open_
+            inst[m] = ids[b]
+            sem[m] = sids[b]
+        inst[(num > 1) & open_] = -2
+        sem[(num > 1) & open_] = -100
+    inst[inst == -1] = -2                                                            # :901-902
+    sem[sem == -1] = -100
+    if point_association:
+        return inst, sem
+    segments = np.asarray(segments)
+    pooled = np.full(len(positions), -1, np.int64)                                   # :857
+    per_seg = np.full(len(unique_segs), -2, np.int64)
+    sem_seg = np.full(len(unique_segs), -100, np.int64)
+    for i, seg_id in enumerate(unique_segs):                                         # :913-921
+        m = seg_id == segments
+        per_seg[i] = _mode(inst[m])
+        sem_seg[i] = _mode(sem[m])
+        pooled[m] = per_seg[i]
+    return pooled, sem, per_seg, sem_seg

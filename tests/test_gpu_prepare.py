@@ -257,3 +257,117 @@ def test_box_supervision_dropout_and_noise_match_reference_golden(gold):
     assert np.array_equal(it['pseudo_inst'][0].cpu().numpy(), gold['s1_noisy_inst_per_point'])
     for k in ('fg_instances', 'gt_bb_bounds', 'gt_semantics'):
         assert np.array_equal(it[k].cpu().numpy(), gold['s1_noisy_%s' % k]), k
+
+
+# ---------------------------------------------------------------- the other dataset branches (tests/golden/prepare2.npz)
+def _close(got, want, name):
+    got = got.cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    if want.dtype.kind == 'f':
+        # offsets / locations inherit the segment centroid's few-ulp difference (integer sums vs numpy's running mean)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12), name
+    else:
+        assert np.array_equal(got, want), name
+
+
+def test_other_dataset_branches_match_reference_golden(golden_dir):
+    """ScanNet majority_vote / point_association / mask_supervision, ARKitScenes 4 cm voxelisation + oriented-box
+    association, S3DIS two-stage box association + mask supervision: device path == outputs of the REAL dataset classes
+    (tools/gen_golden.py prepare2): instance ids, masks and integer targets bit-exact, fp64 targets to 1e-12."""
+    import sys
+    from types import SimpleNamespace
+    from box2mask_amd import prepare
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_scenes import prepare2_scenes
+    g = np.load(os.path.join(golden_dir, 'prepare2.npz'))
+    TGT = ('fg_instances', 'gt_bb_bounds', 'gt_bb_offsets', 'gt_semantics', 'gt_per_vox_semantics', 'instance_ids',
+           'vox_instances')
+
+    def check(tag, it):
+        n = 0
+        for k in TGT:
+            if '%s_%s' % (tag, k) in g.files:
+                _close(it[k], g['%s_%s' % (tag, k)], tag + ' ' + k)
+                n += 1
+        for j in (0, 1):
+            if '%s_pseudo%d' % (tag, j) in g.files:
+                _close(it['pseudo_inst'][j], g['%s_pseudo%d' % (tag, j)], tag + ' pseudo')
+                n += 1
+        assert n >= 3, tag
+
+    for i, sc in enumerate(prepare2_scenes()):
+        lab, vs = sc['labels'], sc['voxel_size']
+        for h in (1, 0):
+            cfg = SimpleNamespace(smallest_bb_heuristic=bool(h), point_association=False, majority_vote=True)
+            check('s%d_scannet_majority_h%d' % (i, h), prepare.box_supervision(prepare.voxelize_scene(sc, vs), lab, cfg))
+            cfg = SimpleNamespace(smallest_bb_heuristic=bool(h), point_association=True, majority_vote=False)
+            it = prepare.box_supervision(prepare.voxelize_scene(sc, vs, do_segment_pooling=False), lab, cfg)
+            check('s%d_scannet_point_h%d' % (i, h), it)
+            _close(it['input_location'], g['s%d_scannet_point_h%d_input_location' % (i, h)], 'input_location')
+            with pytest.raises(RuntimeError):                  # dataloader.py:173-174
+                prepare.box_supervision(prepare.voxelize_scene(sc, vs), lab, cfg)
+        for pool in (1, 0):
+            it = prepare.mask_supervision(prepare.voxelize_scene(sc, vs, do_segment_pooling=bool(pool)), lab, None)
+            check('s%d_scannet_mask_p%d' % (i, pool), it)
+        # ---- ARKitScenes: 4 cm voxels, oriented boxes
+        it = prepare.voxelize_scene(sc, 0.04)
+        for k in ('vox2point', 'point2vox', 'vox_segments', 'seg2vox', 'seg2point'):
+            _close(it[k], g['s%d_arkit_%s' % (i, k)], 'arkit ' + k)
+        assert np.array_equal(it['vox_coords'][:, 1:].cpu().numpy(), g['s%d_arkit_vox_coords' % i].astype(np.int32))
+        assert np.array_equal(it['vox_features'].cpu().numpy(), g['s%d_arkit_vox_features' % i].astype(np.float32))
+        _close(it['input_location'], g['s%d_arkit_input_location' % i], 'arkit input_location')
+        cfg = SimpleNamespace(point_association=False)
+        check('s%d_arkit_seg' % i, prepare.box_supervision(it, lab, cfg, 'arkitscenes'))
+        pp, none = prepare.approx_association(prepare.voxelize_scene(sc, 0.04), lab, SimpleNamespace(point_association=True),
+                                              'arkitscenes')
+        assert none is None
+        _close(pp, g['s%d_arkit_point_pseudo0' % i], 'arkit point')
+        check('s%d_arkit_mask' % i, prepare.mask_supervision(prepare.voxelize_scene(sc, 0.04), lab, None, 'arkitscenes'))
+        # ---- S3DIS: foreground boxes, then background boxes; majority vote per segment
+        for ign in (1, 0):
+            cfg = SimpleNamespace(point_association=False, ignore_wall_ceiling_floor=bool(ign))
+            it = prepare.voxelize_scene(sc, vs)
+            a = prepare.approx_association(it, lab, cfg, 's3dis')
+            for j in range(4):
+                _close(a[j], g['s%d_s3dis_i%d_assoc%d' % (i, ign, j)], 's3dis assoc %d' % j)
+            check('s%d_s3dis_i%d' % (i, ign), prepare.box_supervision(it, lab, cfg, 's3dis'))
+            cfg = SimpleNamespace(point_association=True, ignore_wall_ceiling_floor=bool(ign))
+            a = prepare.approx_association(prepare.voxelize_scene(sc, vs), lab, cfg, 's3dis')
+            _close(a[0], g['s%d_s3dis_i%d_point0' % (i, ign)], 's3dis point inst')
+            _close(a[1], g['s%d_s3dis_i%d_point1' % (i, ign)], 's3dis point sem')
+        cfg = SimpleNamespace(ignore_wall_ceiling_floor=True)
+        check('s%d_s3dis_mask' % i, prepare.mask_supervision(prepare.voxelize_scene(sc, vs), lab, cfg, 's3dis'))
+
+
+def test_segment_mode_and_oriented_boxes_on_a_large_scene():
+    """b2m_seg_mode / b2m_obb_membership against the oracle on a 300 k-point scene with many overlapping rotated boxes."""
+    from types import SimpleNamespace
+    from box2mask_amd import prepare, synth
+    from oracle import prepare_ref as R
+    sc = synth.make_scene(9, target_voxels=30000, points_only=True, pts_per_m2=9000.0)
+    lab = dict(sc['labels'])
+    n_inst = len(lab['unique_instances'])
+    rng = np.random.default_rng(3)
+    ang = rng.uniform(0, np.pi, n_inst)
+    rot = np.zeros((n_inst, 3, 3))
+    rot[:, 0, 0] = np.cos(ang); rot[:, 0, 1] = -np.sin(ang); rot[:, 1, 0] = np.sin(ang); rot[:, 1, 1] = np.cos(ang); rot[:, 2, 2] = 1
+    lab['per_instance_bb_rotations'] = rot.reshape(n_inst, 9)
+    lab['per_instance_bb_bounds'] = lab['per_instance_bb_bounds'] * np.float32(1.5)
+    it = prepare.voxelize_scene(sc, 0.04)
+    ref = R.voxelize_scene(sc['positions'], sc['colors'], sc['normals'], sc['segments'], 0.04)
+    useg = ref['unique_vox_segments']
+    for pa in (False, True):
+        got = prepare.approx_association(it, lab, SimpleNamespace(point_association=pa), 'arkitscenes')
+        want = R.arkit_association(sc['positions'], sc['segments'], lab, useg, pa)
+        assert np.array_equal(got[0].cpu().numpy(), want[0])
+        if not pa:
+            assert np.array_equal(got[1].cpu().numpy(), want[1])
+    it2 = prepare.voxelize_scene(sc, 0.02)
+    ref2 = R.voxelize_scene(sc['positions'], sc['colors'], sc['normals'], sc['segments'], 0.02)
+    got = prepare.approx_association(it2, lab, SimpleNamespace(point_association=False, majority_vote=True,
+                                                               smallest_bb_heuristic=True), 'scannet')
+    want = R.approx_association_points(sc['positions'], sc['segments'], lab, ref2['unique_vox_segments'], True, True)
+    assert np.array_equal(got[0].cpu().numpy(), want[0]) and np.array_equal(got[1].cpu().numpy(), want[1])
+    got = prepare.approx_association(it2, lab, SimpleNamespace(point_association=False, ignore_wall_ceiling_floor=True), 's3dis')
+    want = R.s3dis_association(sc['positions'], sc['segments'], lab, ref2['unique_vox_segments'], False, True)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.cpu().numpy(), b)

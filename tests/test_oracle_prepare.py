@@ -78,3 +78,44 @@ def test_box_supervision_bit_exact(gold):
         for k, v in gt.items():
             want = gold['s%d_%s' % (i, k)]
             assert v.dtype == want.dtype and np.array_equal(v, want), (i, k)
+
+
+# ---------------------------------------------------------------- the other association branches (prepare2.npz)
+def _p2():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_scenes import prepare2_scenes
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'prepare2.npz'), allow_pickle=True), \
+        prepare2_scenes()
+
+
+def test_oracle_other_association_branches_match_reference():
+    """oracle/prepare_ref.py's majority-vote / point / oriented-box / S3DIS associations == the real dataset classes
+    (tools/gen_golden.py prepare2), bit for bit."""
+    g, scenes = _p2()
+    for i, sc in enumerate(scenes):
+        pos, seg, lab = sc['positions'], sc['segments'], sc['labels']
+        for vs, tag in ((sc['voxel_size'], 'scannet'), (0.04, 'arkit')):
+            v = R.voxelize_scene(pos, sc['colors'], sc['normals'], seg, vs)
+            useg = v['unique_vox_segments']
+            if tag == 'scannet':
+                for h in (1, 0):
+                    pp, ps = R.approx_association_points(pos, seg, lab, useg, bool(h), True)
+                    assert np.array_equal(pp, g['s%d_scannet_majority_h%d_pseudo0' % (i, h)])
+                    assert np.array_equal(ps, g['s%d_scannet_majority_h%d_pseudo1' % (i, h)])
+                    pp, _ = R.approx_association_points(pos, seg, lab, useg, bool(h), False)
+                    assert np.array_equal(pp, g['s%d_scannet_point_h%d_pseudo0' % (i, h)])
+                for ign in (1, 0):
+                    a = R.s3dis_association(pos, seg, lab, useg, False, bool(ign))
+                    for j in range(4):
+                        assert np.array_equal(a[j], g['s%d_s3dis_i%d_assoc%d' % (i, ign, j)]), (i, ign, j)
+                    a = R.s3dis_association(pos, seg, lab, useg, True, bool(ign))
+                    assert np.array_equal(a[0], g['s%d_s3dis_i%d_point0' % (i, ign)])
+                    assert np.array_equal(a[1], g['s%d_s3dis_i%d_point1' % (i, ign)])
+            else:
+                for k in ('vox_coords', 'vox2point', 'point2vox', 'vox_segments', 'seg2vox', 'seg2point'):
+                    assert np.array_equal(v[k], g['s%d_arkit_%s' % (i, k)]), k
+                pp, ps = R.arkit_association(pos, seg, lab, useg, False)
+                assert np.array_equal(pp, g['s%d_arkit_seg_pseudo0' % i]) and np.array_equal(ps, g['s%d_arkit_seg_pseudo1' % i])
+                pp, _ = R.arkit_association(pos, seg, lab, useg, True)
+                assert np.array_equal(pp, g['s%d_arkit_point_pseudo0' % i])

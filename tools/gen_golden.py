@@ -384,6 +384,110 @@ def gen_prepare():
     print('prepare.npz: %d arrays, %s voxels' % (len(out), [len(it['vox_coords']) for it in items]))
 
 
+def _dataloader_module():
+    """models/dataloader.py of the reference behind stand-ins for the modules that only LOAD data (see gen_prepare)."""
+    _install_stubs()
+    sys.modules['MinkowskiEngine'].utils = SimpleNamespace(
+        batched_coordinates=lambda c, dtype=None: synth.batched_coordinates(c))
+    tc = types.ModuleType('numpy.lib.type_check'); tc._is_type_dispatcher = None
+    sys.modules['numpy.lib.type_check'] = tc
+    dp = types.ModuleType('dataprocessing'); dp.__path__ = []
+    sys.modules['dataprocessing'] = dp
+    for n in ('scannet', 'arkitscenes', 's3dis'):
+        m = types.ModuleType('dataprocessing.' + n); sys.modules['dataprocessing.' + n] = m; setattr(dp, n, m)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import models.dataloader as D
+    if not hasattr(np, 'int'):
+        np.int = int                      # dataloader.py still spells np.int (removed from numpy 1.24 on)
+    # dataloader.py:267,592,868,916 index stats.mode(x, None)[0][0]: the array-valued result of SciPy < 1.11.  The SciPy
+    # of this image returns scalars; keepdims=True is that old behaviour (same values, same tie rule).
+    import scipy.stats as st
+    D.stats = SimpleNamespace(mode=lambda a, axis=0: st.mode(a, axis, keepdims=True))
+    # the one function of dataprocessing/s3dis.py the dataset class calls (s3dis.py:79-82, two comparisons)
+    D.s3dis.semantics_to_forground_mask = lambda semantics, cfg=None: (semantics > 2) if cfg.ignore_wall_ceiling_floor \
+        else (semantics >= 0)
+    return D
+
+
+def gen_prepare2():
+    """The remaining branches of the dataset classes from the REAL reference: ScanNet
+    majority_vote / point_association / mask_supervision (dataloader.py:138-272), ARKitScenes.__getitem__ at 4 cm with
+    oriented-box association (:385-621) and S3DIS box / mask supervision (:737-927), on the two labelled scenes of
+    prepare2_scenes()."""
+    D = _dataloader_module()
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from golden_scenes import prepare2_scenes
+    scenes = prepare2_scenes()
+    out = {}
+
+    def run(cls, mod, sc, mode, **cfgkw):
+        mod.process_scene = lambda name, m, cfg, do_augmentations=False, subsample_rate=None, _sc=sc: (_sc, _sc['labels'])
+        ds = cls.__new__(cls)
+        ds.cfg = SimpleNamespace(voxel_size=sc['voxel_size'], use_normals_input=True, dropout_boxes=None, noisy_boxes=None,
+                                 **cfgkw)
+        ds.mode = mode; ds.do_augmentations = False; ds.data_list = [sc['name']]; ds.data_class = mod
+        ds.subsample_rate = None
+        return ds[0]
+
+    def put(tag, ret, keys):
+        for k in keys:
+            if k == 'pseudo_inst':
+                for j, v in enumerate(ret.get(k, ())):
+                    if v is not None:
+                        out['%s_pseudo%d' % (tag, j)] = np.asarray(v)
+            elif k in ret:
+                out['%s_%s' % (tag, k)] = np.asarray(ret[k])
+    TGT = ('pseudo_inst', 'fg_instances', 'gt_bb_bounds', 'gt_bb_offsets', 'gt_semantics', 'gt_per_vox_semantics',
+           'instance_ids', 'vox_instances')
+    for i, sc in enumerate(scenes):
+        out['s%d_rotations' % i] = sc['labels']['per_instance_bb_rotations']
+        # ---- ScanNet
+        for heur in (True, False):
+            r = run(D.ScanNet, D.scannet, sc, 'train', do_segment_pooling=True, bb_supervision=True, point_association=False,
+                    majority_vote=True, smallest_bb_heuristic=heur)
+            put('s%d_scannet_majority_h%d' % (i, heur), r, TGT)
+            r = run(D.ScanNet, D.scannet, sc, 'train', do_segment_pooling=False, bb_supervision=True, point_association=True,
+                    majority_vote=False, smallest_bb_heuristic=heur)
+            put('s%d_scannet_point_h%d' % (i, heur), r, TGT + ('input_location',))
+        for pool in (True, False):
+            r = run(D.ScanNet, D.scannet, sc, 'train', do_segment_pooling=pool, bb_supervision=False)
+            put('s%d_scannet_mask_p%d' % (i, pool), r, TGT)
+        # ---- ARKitScenes (4 cm voxels as configs/arkitscenes.txt)
+        sc4 = dict(sc, voxel_size=0.04)
+        r = run(D.ARKitScenes, D.arkitscenes, sc4, 'test', do_segment_pooling=True)
+        put('s%d_arkit' % i, r, ('vox_coords', 'vox2point', 'point2vox', 'vox_segments', 'vox_features', 'seg2vox',
+                                 'seg2point', 'input_location'))
+        r = run(D.ARKitScenes, D.arkitscenes, sc4, 'train', do_segment_pooling=True, bb_supervision=True,
+                point_association=False)
+        out['s%d_arkit_seg_pseudo0' % i], out['s%d_arkit_seg_pseudo1' % i] = (np.asarray(v) for v in
+                                                                                 D.ARKitScenes.approx_association(
+            SimpleNamespace(cfg=SimpleNamespace()), sc['labels'], sc, False, np.unique(r['vox_segments'])))
+        put('s%d_arkit_seg' % i, r, TGT)
+        # (the item itself cannot be made with point_association: :550 takes len(unique_segs) of None without segment
+        # pooling and :511 raises with it -- only the association is pinned)
+        out['s%d_arkit_point_pseudo0' % i] = np.asarray(D.ARKitScenes.approx_association(
+            SimpleNamespace(cfg=SimpleNamespace()), sc['labels'], sc, True, np.unique(r['vox_segments']))[0])
+        r = run(D.ARKitScenes, D.arkitscenes, sc4, 'train', do_segment_pooling=True, bb_supervision=False)
+        put('s%d_arkit_mask' % i, r, TGT)
+        # ---- S3DIS
+        for ign in (True, False):
+            r = run(D.S3DIS, D.s3dis, sc, 'train', do_segment_pooling=True, bb_supervision=True, point_association=False,
+                    ignore_wall_ceiling_floor=ign)
+            a = D.S3DIS.approx_association(SimpleNamespace(cfg=SimpleNamespace(ignore_wall_ceiling_floor=ign)),
+                                           sc['labels'], sc, False, np.unique(r['vox_segments']))
+            for j, v in enumerate(a):
+                out['s%d_s3dis_i%d_assoc%d' % (i, ign, j)] = np.asarray(v)
+            put('s%d_s3dis_i%d' % (i, ign), r, TGT)
+            a = D.S3DIS.approx_association(SimpleNamespace(cfg=SimpleNamespace(ignore_wall_ceiling_floor=ign)),
+                                           sc['labels'], sc, True, np.unique(r['vox_segments']))
+            out['s%d_s3dis_i%d_point0' % (i, ign)], out['s%d_s3dis_i%d_point1' % (i, ign)] = (np.asarray(v) for v in a)
+        r = run(D.S3DIS, D.s3dis, sc, 'val', do_segment_pooling=True, bb_supervision=False, ignore_wall_ceiling_floor=True)
+        put('s%d_s3dis_mask' % i, r, TGT)
+    np.savez_compressed(os.path.join(OUT, 'prepare2.npz'), **out)
+    print('prepare2.npz: %d arrays, %.1f kB' % (len(out), os.path.getsize(os.path.join(OUT, 'prepare2.npz')) / 1e3))
+
+
 def gen_eval():
     """AP evaluation: assign_instances_for_scan / evaluate_matches / compute_averages of the real
     /root/reference/utils/eval_metric.py on synthetic predictions (noisy copies of the ground-truth instances,
@@ -455,7 +559,7 @@ def gen_eval():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['iou_nms', 'detection2mask', 'losses', 'prepare', 'eval']
+    which = sys.argv[1:] or ['iou_nms', 'detection2mask', 'losses', 'prepare', 'prepare2', 'eval']
     if 'iou_nms' in which:
         gen_iou_nms()
     if 'detection2mask' in which:
@@ -464,5 +568,7 @@ if __name__ == '__main__':
         gen_losses()
     if 'prepare' in which:
         gen_prepare()
+    if 'prepare2' in which:
+        gen_prepare2()
     if 'eval' in which:
         gen_eval()
