@@ -140,6 +140,11 @@ class SelectionNet(ResNetBase):
                 tr[name] = t.F
             return t
 
+        # all 8 coordinate maps and every kernel map of the U-Net now, before the first convolution is enqueued (their row
+        # counts are host reads: see CoordinateManager.prefetch)
+        mgr = getattr(x, 'manager', None)
+        if mgr is not None:
+            mgr.prefetch(8, same=[(0, 5)] + [(l, 3) for l in range(8)], strided=True)
         out_p1 = T('out_p1', cbr(self.conv0p1s1, self.bn0, x))
         out_b1p2 = T('block1', self.block1(T('down1', cbr(self.conv1p1s2, self.bn1, out_p1))))
         out_b2p4 = T('block2', self.block2(T('down2', cbr(self.conv2p2s2, self.bn2, out_b1p2))))

@@ -79,19 +79,27 @@ class Model:
         """model.py:38-225: same loss terms, keys and weights."""
         device = self.device
         cfg = self.cfg
+        on_fg = cfg.loss_on_fg_instances or cfg.bb_supervision
+        # The reference selects the foreground rows with a boolean mask in every loss term (model.py:65-66 ...): each such
+        # indexing is a host read of the row count.  Here the row list is made ONCE, BEFORE the forward pass is enqueued (the
+        # host still has nothing to wait for), and every term gathers with it: same rows, same order, no host read while
+        # the device works through the network -- the backward pass is enqueued behind the forward without a stall.
+        fg = fg_rows = None
+        if 'fg_instances' in batch:
+            fg = batch['fg_instances'].to(device)
+            if on_fg:
+                fg_rows = torch.nonzero(fg).reshape(-1)
         sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=device)
         n_seg = batch['input_location'].shape[0] if cfg.do_segment_pooling else None
         pred = self.detection_model(sin, batch['pooling_ids'].to(device), n_seg)
         for mlp_head, sparse_tensor in pred.items():
             pred[mlp_head] = sparse_tensor.F
         losses_dict = {'optimization_loss': 0}
-        fg = batch['fg_instances'].to(device) if 'fg_instances' in batch else None
-        on_fg = cfg.loss_on_fg_instances or cfg.bb_supervision
 
         if cfg.mlp_offsets in cfg.network_heads:                     # model.py:62-73
             gt_offsets, pred_offsets = batch['gt_bb_offsets'].to(device), pred[cfg.mlp_offsets]
             if on_fg:
-                pred_offsets, gt_offsets = pred_offsets[fg], gt_offsets[fg]
+                pred_offsets, gt_offsets = pred_offsets[fg_rows], gt_offsets[fg_rows]
             offset_loss_per_pred = torch.sum(torch.abs(pred_offsets - gt_offsets), axis=1)
             offset_loss = torch.mean(offset_loss_per_pred)
             losses_dict['optimization_loss'] += cfg.loss_weight_bb_offsets * offset_loss
@@ -100,7 +108,7 @@ class Model:
         if cfg.mlp_bounds in cfg.network_heads:                      # model.py:76-88
             gt_bounds, pred_bounds = batch['gt_bb_bounds'].to(device), pred[cfg.mlp_bounds]
             if on_fg:
-                pred_bounds, gt_bounds = pred_bounds[fg], gt_bounds[fg]
+                pred_bounds, gt_bounds = pred_bounds[fg_rows], gt_bounds[fg_rows]
             bounds_loss = torch.mean(torch.sum(torch.abs(pred_bounds - gt_bounds), axis=1))
             losses_dict['optimization_loss'] += cfg.loss_weight_bb_bounds * bounds_loss
             losses_dict['bounds_loss'] = bounds_loss.detach()
@@ -110,8 +118,8 @@ class Model:
             loc = batch['input_location'].to(device)
             gt_offsets, gt_bounds = batch['gt_bb_offsets'].to(device), batch['gt_bb_bounds'].to(device)
             if on_fg:
-                pred_bounds, pred_offsets = pred_bounds[fg], pred_offsets[fg]
-                gt_bounds, gt_offsets, loc = gt_bounds[fg], gt_offsets[fg], loc[fg]
+                pred_bounds, pred_offsets = pred_bounds[fg_rows], pred_offsets[fg_rows]
+                gt_bounds, gt_offsets, loc = gt_bounds[fg_rows], gt_offsets[fg_rows], loc[fg_rows]
             pred_bounds = torch.clamp(pred_bounds, min=cfg.min_bb_size)
             ious = _paired_box_iou(to_bbs_min_max_(pred_offsets + loc, pred_bounds, device),
                                    to_bbs_min_max_(gt_offsets + loc, gt_bounds, device))
@@ -128,8 +136,8 @@ class Model:
             loc = batch['input_location'].to(device)
             gt_offsets, gt_bounds = batch['gt_bb_offsets'].to(device), batch['gt_bb_bounds'].to(device)
             if on_fg:
-                pred_scores, pred_bounds, pred_offsets = pred_scores[fg], pred_bounds[fg], pred_offsets[fg]
-                loc, gt_offsets, gt_bounds = loc[fg], gt_offsets[fg], gt_bounds[fg]
+                pred_scores, pred_bounds, pred_offsets = pred_scores[fg_rows], pred_bounds[fg_rows], pred_offsets[fg_rows]
+                loc, gt_offsets, gt_bounds = loc[fg_rows], gt_offsets[fg_rows], gt_bounds[fg_rows]
             gt_bbs = to_bbs_min_max_(gt_offsets + loc, gt_bounds, device)
             pred_bounds = torch.clamp(pred_bounds, min=cfg.min_bb_size)
             pred_bbs = to_bbs_min_max_(pred_offsets + loc, pred_bounds, device)
@@ -144,7 +152,7 @@ class Model:
             pred_scores = pred[cfg.mlp_center_scores].reshape(-1)
             gt_scores = offset_loss_per_pred.detach()
             if cfg.loss_on_fg_instances:
-                pred_scores = pred_scores[fg]
+                pred_scores = pred_scores[fg_rows]
             score_loss = torch.mean(torch.abs(pred_scores - gt_scores))
             losses_dict['optimization_loss'] += cfg.loss_weight_center_scores * score_loss
             losses_dict['center_score_loss'] = score_loss.detach()

@@ -179,6 +179,20 @@ class CoordinateManager:
         self._rb[('down', level)] = Rulebook(child, 8, nc, nf, self.keep_tables)
         self._rb[('up', level)] = Rulebook(up, 8, nf, nc, self.keep_tables)
 
+    def prefetch(self, n_levels: int, same=(), strided: bool = True):
+        """Build the coordinate maps of levels 0 .. n_levels-1 and the kernel maps a network will ask for -- `same`:
+        (level, kernel size) pairs, `strided`: every k2s2 map between consecutive levels -- NOW.  Every level's row count
+        comes back to the host (it sizes the next allocations); asked for lazily, in the middle of a forward pass, each of
+        those reads makes the host wait for all the convolutions queued so far and the device then idles while the host
+        catches up.  Done up front, the forward and backward passes are enqueued without a single host read."""
+        self.ensure_level(n_levels - 1)
+        for level, ksize in same:
+            if level < n_levels:
+                self.rulebook_same(level, ksize)
+        if strided:
+            for level in range(n_levels - 1):
+                self.rulebook_down(level)
+
     def rulebook_down(self, level: int) -> Rulebook:
         """k2s2 map level -> level+1, tiled over the coarse (output) rows."""
         if ('down', level) not in self._rb:
