@@ -184,6 +184,35 @@ def wgrad_raw(x, dy, rb: Rulebook | None, K: int, dw3, ci0: int, cin: int | None
           n_out, K, dw3.data_ptr() + 4 * ci0 * cout, cout, cin_total * cout, _ptr(ws))
 
 
+# ---- weight gradients on a second stream
+# The data gradient and the weight gradient of a layer both need only dy: issued on two HIP streams they share the
+# chip.  Neither kernel holds every SIMD's wave slots to the end of its launch (the last round of workgroups of a grid
+# leaves slots empty, and a conv_fwd_flow wave needs 12 KiB of LDS where a weight-gradient wave needs none), so the two
+# fill each other's gaps.  B2M_WGRAD_STREAM=0 keeps everything on one stream; the deterministic mode always does (its
+# partial-sum workspace is shared by all layers in stream order).
+_side = {'streams': {}, 'armed': False}
+
+
+def wgrad_on_side_stream() -> bool:
+    return os.environ.get('B2M_WGRAD_STREAM', '1') == '1' and not deterministic()
+
+
+def _side_stream(device):
+    st = _side['streams'].get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side['streams'][device] = st
+    return st
+
+
+def join_side_streams():
+    """The current stream waits for the weight gradients issued on the side stream(s).  Runs by itself at the end of
+    every backward pass; the data-parallel all-reduce calls it before it launches a bucket."""
+    _side['armed'] = False
+    for dev, st in _side['streams'].items():
+        torch.cuda.current_stream(dev).wait_stream(st)
+
+
 class _SparseConv(torch.autograd.Function):
     """Sparse convolution Y[o] = sum_k X[in_k(o)] W[k] (+bias).  [ME-mem] MinkowskiConvolution /
     MinkowskiConvolutionTranspose forward+backward (/root/reference/models/resnet.py:61-65,
@@ -232,9 +261,23 @@ class _SparseConv(torch.autograd.Function):
             if dw is None:
                 dw = torch.zeros_like(weight, dtype=torch.float32)
             dw3 = dw if weight.dim() == 3 else dw.unsqueeze(0)
-            wgrad_raw(x1, dy, ctx.rb_f, K, dw3, 0, c1)
-            if x2 is not None:
-                wgrad_raw(x2, dy, ctx.rb_f, K, dw3, c1, x2.shape[1])
+            if wgrad_on_side_stream():
+                main, side = torch.cuda.current_stream(dy.device), _side_stream(dy.device)
+                side.wait_stream(main)                      # dy, x and the zeroed gradient slot are ready
+                with torch.cuda.stream(side):
+                    wgrad_raw(x1, dy, ctx.rb_f, K, dw3, 0, c1)
+                    if x2 is not None:
+                        wgrad_raw(x2, dy, ctx.rb_f, K, dw3, c1, x2.shape[1])
+                for t in (dy, x1, x2, dw):                  # the allocator must not hand these out again before the side stream is done
+                    if t is not None:
+                        t.record_stream(side)
+                if not _side['armed']:
+                    _side['armed'] = True
+                    torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+            else:
+                wgrad_raw(x1, dy, ctx.rb_f, K, dw3, 0, c1)
+                if x2 is not None:
+                    wgrad_raw(x2, dy, ctx.rb_f, K, dw3, c1, x2.shape[1])
         if bias is not None and ctx.needs_input_grad[3]:
             db = grad_slot(bias)
             if db is not None and db.shape == (1, cout):

@@ -97,6 +97,8 @@ class GradAllReduce:
             self._launch(bi)
 
     def _launch(self, bi):
+        from . import functional as F_
+        F_.join_side_streams()                # weight gradients issued on the side stream (functional._SparseConv)
         b = self.buckets[bi]
         span = self.arena.span(b) if self.arena is not None else None
         if span is not None:                  # every gradient of the bucket lives in its arena slot: reduce in place
