@@ -30,6 +30,8 @@ struct ConvArgs {
     int wg_combine;  // nslice % 4 == 0: the 4 waves of a workgroup are 4 slices of one item and add up in LDS first
     int64_t nwg;     // workgroups of work; the grid is padded, see xcd_order()
     int64_t xcd_per; // > 0: XCD-aware order in chunks of this many workgroups, see wg_index()
+    double* stats;   // != NULL: per-tile column sums of the finished output, [tile][2][cout] (sum, sum of squares): the
+                     // BatchNorm statistics of the following layer without another pass over Y (conv_fwd_flow_kernel only)
 };
 
 // loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
@@ -545,11 +547,12 @@ extern "C" int b2m_weight_pack_run(const void* plan_dev, int32_t n, int64_t tota
     return B2M_OK;
 }
 
-extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
-                            int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
-                            const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
-                            int32_t cout, int32_t accumulate, void* stream) {
+static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
+                         int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
+                         const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
+                         int32_t cout, int32_t accumulate, double* tile_stats, int32_t* wrote_stats, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (wrote_stats) *wrote_stats = 0;
     B2M_CHECK_ARG(x1 && wp && y && c1 > 0 && c2 >= 0 && cout > 0 && K >= 1 && K <= 128, "bad pointers/sizes (K<=128)");
     B2M_CHECK_ARG((rb_in == nullptr) == (rb_out == nullptr) && (rb_in == nullptr) == (rb_cnt == nullptr),
                   "rulebook pointers must be all set or all NULL");
@@ -572,6 +575,7 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
     a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
+    a.stats = nullptr;
     const int TW = conv_tw(cout, K);
     a.nstrips = (cout + 16 * TW - 1) / (16 * TW);
     a.vec_store = (ldy % 4 == 0 && ((uintptr_t)y % 16) == 0) ? 1 : 0;
@@ -630,6 +634,12 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
         if (depth >= 2 && !ident && fast && KC == 16 && split_ok && a.fast32 && nc % ncs == 0 && (nc / ncs) % depth == 0 &&
             nc / ncs >= depth) {
             const int wpb = nslice == 1 ? 1 : 4;
+            // the workgroup that writes a (tile, strip) sees its final values: un-split maps, or exactly 4 slices
+            // combined in LDS and stored plainly
+            if (tile_stats && (nslice == 1 || (nslice == 4 && !accumulate))) {
+                a.stats = tile_stats;
+                if (wrote_stats) *wrote_stats = 1;
+            }
             a.nwg = cdiv64(items, wpb);
             const XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
             a.xcd_per = fo.chunk;
@@ -683,6 +693,22 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
 #undef B2M_CONV_LAUNCH
     B2M_LAUNCH_CHECK();
     return B2M_OK;
+}
+
+extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
+                            int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
+                            const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
+                            int32_t cout, int32_t accumulate, void* stream) {
+    return conv_fwd_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, accumulate,
+                         nullptr, nullptr, stream);
+}
+extern "C" int b2m_conv_fwd_stats(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
+                                  int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
+                                  const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
+                                  int32_t cout, int32_t accumulate, double* tile_stats, int32_t* wrote_stats, void* stream) {
+    B2M_CHECK_ARG(tile_stats && wrote_stats, "tile_stats / wrote_stats are NULL");
+    return conv_fwd_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, accumulate,
+                         tile_stats, wrote_stats, stream);
 }
 
 // ------------------------------------------------------------------ weight gradient

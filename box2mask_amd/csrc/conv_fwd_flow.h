@@ -28,6 +28,26 @@
 #pragma once
 #include <type_traits>
 
+// Column sums of a finished output strip (64 rows x SW columns in LDS, row pitch SW + 4): lane c adds up column c over
+// the tile's valid rows and stores sum / sum of squares to stats[tile][0 / 1][col0 + c] -- what bn_stats_kernel would
+// read the whole of Y again for.
+template <int SW>
+__device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float* strip, int64_t tile, int64_t row0, int col0, int lane) {
+    constexpr int PITCH = SW + 4;
+    const int64_t rem = a.n_out - row0;
+    const int rows = rem < B2M_TILE ? (int)rem : B2M_TILE;
+    if (lane < SW && col0 + lane < a.cout) {
+        double s = 0., s2 = 0.;                  // fp64: the variance is a difference of these sums (8-row deep levels!)
+        for (int r = 0; r < rows; ++r) {
+            const double v = (double)strip[r * PITCH + lane];
+            s += v; s2 = fma(v, v, s2);
+        }
+        double* o = a.stats + tile * 2 * a.cout + col0 + lane;
+        o[0] = s; o[a.cout] = s2;
+    }
+}
+#define tile_column_sums(a, strip, tile, row0, col0, lane) strip_column_sums<SW>(a, strip, tile, row0, col0, lane)
+
 // DBG (diagnostic builds of tools/pipe_breakdown.py only, results are WRONG): 1 = no strip flush, 2 = no gathers inside
 // the loop, 4 = no weight loads inside the loop -- each removes one component so that its cost shows in the launch time
 // WPB = 4: split maps (deep U-Net levels).  The four waves of a workgroup are four slices of ONE (tile, strip): the
@@ -291,6 +311,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             f32x4 v = *(const f32x4*)&smem[row * PITCH + c4];
 #pragma unroll
             for (int w = 1; w < WPB; ++w) v += *(const f32x4*)&smem[w * STRIP + row * PITCH + c4];
+            if (a.stats) *(f32x4*)&smem[row * PITCH + c4] = v;         // keep the combined strip for the column sums below
             const int col = col0 + c4;
             float* dst = a.y + grow * a.ldy + col;
             if (plain && a.vec_store && col + 3 < a.cout) {
@@ -305,8 +326,13 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                 }
             }
         }
+        if (a.stats) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            tile_column_sums(a, smem, tile, row0, col0, lane);
+        }
         return;
     }
+    if (a.stats) tile_column_sums(a, Cs, tile, row0, col0, lane);
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
@@ -322,3 +348,4 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         }
     }
 }
+#undef tile_column_sums

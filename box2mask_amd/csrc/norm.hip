@@ -174,6 +174,50 @@ extern "C" int b2m_bn_stats_finalize(const float* x, int64_t ldx, int64_t n, int
     return B2M_OK;
 }
 
+// Statistics from the per-tile column sums a convolution left behind (b2m_conv_fwd_stats): tile_stats [ntiles][2c]
+// fp64 -> partial [nblk][2c] fp64, the layout reduce_final_kernel / bn_final_finalize_kernel read.  Fixed order.
+__global__ __launch_bounds__(256) void bn_tilestats_kernel(const double* __restrict__ ts, int64_t ntiles, int c2,
+                                                           double* __restrict__ partial) {
+    const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * per;
+    int64_t t1 = t0 + per;
+    if (t1 > ntiles) t1 = ntiles;
+    for (int j = threadIdx.x; j < c2; j += 256) {
+        double s = 0;
+        for (int64_t t = t0; t < t1; ++t) s += ts[t * c2 + j];
+        partial[(size_t)blockIdx.x * c2 + j] = s;
+    }
+}
+static int tilestats_blocks(int64_t ntiles) {
+    int64_t b = (ntiles + 15) / 16;
+    if (b < 1) b = 1;
+    if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
+    return (int)b;
+}
+extern "C" int b2m_bn_tilestats(const double* tile_stats, int64_t ntiles, int32_t c, double* partial, double* stats,
+                                void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(tile_stats && partial && stats && ntiles >= 1 && c > 0 && c <= 1024, "bad arguments");
+    const int nblk = tilestats_blocks(ntiles);
+    bn_tilestats_kernel<<<nblk, 256, 0, st>>>(tile_stats, ntiles, 2 * c, partial);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, stats, nullptr, nullptr);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+extern "C" int b2m_bn_tilestats_finalize(const double* tile_stats, int64_t ntiles, int64_t n, int32_t c, double* partial,
+                                         double* stats, const float* gamma, const float* beta, float eps, float momentum,
+                                         float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                         float* shift, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(tile_stats && partial && scale && shift && ntiles >= 1 && n >= 1 && c > 0 && c <= 1024, "bad arguments");
+    const int nblk = tilestats_blocks(ntiles);
+    bn_tilestats_kernel<<<nblk, 256, 0, st>>>(tile_stats, ntiles, 2 * c, partial);
+    bn_final_finalize_kernel<<<c, 64, 0, st>>>(partial, nblk, (double)n, c, gamma, beta, eps, momentum, running_mean,
+                                               running_var, mean, invstd, scale, shift, stats);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 extern "C" int b2m_bn_finalize(const double* stats, double count, const double* count_dev, int32_t c, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var, float* mean,
                                float* invstd, float* scale, float* shift, void* stream) {

@@ -6,6 +6,7 @@ the MinkowskiEngine operator the reference calls (file:line cited per function; 
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import weakref
 
@@ -152,8 +153,12 @@ class _PackedWeights:
 packed_weights = _PackedWeights()
 
 
-def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: int, out=None, accumulate=False):
-    """Y = sum_k [x1|x2][in_k] @ B[k] with B given as a packed image for (K, c1+c2, cout)."""
+def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: int, out=None, accumulate=False,
+             tile_stats: list | None = None):
+    """Y = sum_k [x1|x2][in_k] @ B[k] with B given as a packed image for (K, c1+c2, cout).
+    tile_stats: a list; if the kernel of this shape can, it also leaves the per-tile column sums of Y (sum and sum of
+    squares over each tile of 64 rows: the statistics of the BatchNorm that follows) and the list receives
+    (tensor [ntiles, 2, cout], ntiles) -- b2m_conv_fwd_stats."""
     c1 = x1.shape[1]
     c2 = x2.shape[1] if x2 is not None else 0
     if out is None:
@@ -164,6 +169,16 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
     else:
         assert rb.K == K and rb.n_out == n_out
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
+    if tile_stats is not None and rb is not None and n_out > 0:
+        ntiles = (n_out + 63) // 64
+        ts = torch.empty((ntiles, 2, cout), dtype=torch.float64, device=x1.device)
+        wrote = ctypes.c_int32(0)
+        _call('b2m_conv_fwd_stats', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
+              x1.shape[0], wp.data_ptr(), K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
+              1 if accumulate else 0, ts.data_ptr(), ctypes.byref(wrote))
+        if wrote.value:
+            tile_stats.append((ts, ntiles))
+        return out
     _call('b2m_conv_fwd', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
           x1.shape[0], wp.data_ptr(), K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
           1 if accumulate else 0)
@@ -220,7 +235,7 @@ class _SparseConv(torch.autograd.Function):
     for the data gradient (same rulebook for stride-1 kernels, whose offsets mirror)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, rb_f, rb_b, mirror, n_out):
+    def forward(ctx, x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, tile_stats=None):
         x1 = _f32c(x1)
         x2 = _f32c(x2) if x2 is not None else None
         c1 = x1.shape[1]
@@ -234,7 +249,7 @@ class _SparseConv(torch.autograd.Function):
         w3 = _f32c(w3)
         K, cin, cout = w3.shape
         wp = packed_weights.get(weight)
-        y = conv_raw(x1, x2, wp, K, bias, rb_f, n_out, cout)
+        y = conv_raw(x1, x2, wp, K, bias, rb_f, n_out, cout, tile_stats=tile_stats)
         ctx.save_for_backward(x1, x2, weight, bias)
         ctx.rb_f, ctx.rb_b, ctx.mirror, ctx.c1 = rb_f, rb_b, mirror, c1
         return y
@@ -284,10 +299,24 @@ class _SparseConv(torch.autograd.Function):
                 torch.sum(dy, 0, keepdim=True, out=db)
             else:
                 db = dy.sum(0, keepdim=True).reshape(bias.shape)
-        return dx1, dx2, dw, db, None, None, None, None
+        return dx1, dx2, dw, db, None, None, None, None, None
 
 
-def sparse_conv(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out):
+def conv_tile_stats() -> bool:
+    """B2M_CONV_STATS=0: the BatchNorm statistics come from a pass over the convolution output (b2m_bn_stats) instead of
+    the per-tile column sums the convolution kernel leaves behind."""
+    return os.environ.get('B2M_CONV_STATS', '1') == '1'
+
+
+def sparse_conv(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, collect_stats=False):
+    """collect_stats: the caller will batch-normalise the result in training mode; the per-tile column sums then ride
+    along on the returned tensor (attribute `_b2m_tile_stats`, read by batch_norm) when the kernel can provide them."""
+    if collect_stats and conv_tile_stats():
+        holder = []
+        y = _SparseConv.apply(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, holder)
+        if holder:
+            y._b2m_tile_stats = holder[0]
+        return y
     return _SparseConv.apply(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out)
 
 
@@ -317,7 +346,7 @@ class _BatchNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync,
-                count_key=None):
+                count_key=None, tile_stats=None):
         x = _f32c(x)
         n, c = x.shape
         dev = x.device
@@ -330,15 +359,25 @@ class _BatchNorm(torch.autograd.Function):
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             invstd = torch.empty(c, dtype=torch.float32, device=dev)
             group = _sync_group() if sync else None
+            if tile_stats is not None and (tile_stats[0].shape[2] != c or tile_stats[1] != (n + 63) // 64):
+                tile_stats = None                  # not this tensor's sums
             if group is None:
-                _call('b2m_bn_stats_finalize', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), None, _ptr(gamma),
-                      _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
-                      invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+                if tile_stats is not None:         # the producing convolution left the per-tile column sums: no pass over x
+                    _call('b2m_bn_tilestats_finalize', tile_stats[0].data_ptr(), tile_stats[1], n, c, partial.data_ptr(),
+                          None, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var),
+                          mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+                else:
+                    _call('b2m_bn_stats_finalize', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), None, _ptr(gamma),
+                          _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(),
+                          invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
             else:
                 # SyncBN: local column sums and the local row count travel in one packed all-reduce; the global count
                 # is read by the kernels from device memory (no .item(), no per-level count exchange)
                 stats = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-                _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), stats.data_ptr())
+                if tile_stats is not None:
+                    _call('b2m_bn_tilestats', tile_stats[0].data_ptr(), tile_stats[1], c, partial.data_ptr(), stats.data_ptr())
+                else:
+                    _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), stats.data_ptr())
                 stats[2 * c:].fill_(float(n))
                 dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
                 count_dev = stats[2 * c:]
@@ -378,7 +417,7 @@ class _BatchNorm(torch.autograd.Function):
             # eval-mode BN is an affine map: dx = scale * g (mean holds `scale` here)
             g = dy if not relu else dy * (y > 0)
             dx = g * mean.reshape(1, -1)
-            return dx, None, None, None, None, None, None, None, (g if dres is not None else None), None, None, None
+            return dx, None, None, None, None, None, None, None, (g if dres is not None else None), None, None, None, None
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned
@@ -399,13 +438,15 @@ class _BatchNorm(torch.autograd.Function):
               count, _ptr(ctx.count_dev), relu, _ptr(mscale), _ptr(mshift), dx.data_ptr(), dx.stride(0), _ptr(dres),
               dres.stride(0) if dres is not None else 0)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, dres, None, None, None)
+                None, None, None, None, None, dres, None, None, None, None)
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None,
                relu=False, sync=False, count_key=None):
+    # per-tile column sums left by the convolution that produced x (sparse_conv(collect_stats=True))
+    tile_stats = getattr(x, '_b2m_tile_stats', None) if training else None
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync,
-                            count_key)
+                            count_key, tile_stats)
 
 
 class _ReLU(torch.autograd.Function):

@@ -84,13 +84,16 @@ class MinkowskiConvolution(_ConvBase):
             assert self.stride == 1
             y = F_.sparse_conv(x1, x2, self.kernel, self.bias, None, None, False, x1.shape[0])
             return x.new(y)
+        # every trunk convolution feeds a BatchNorm (resnet.py:61-66, detection_net.py:37-135): in training mode its
+        # kernel also leaves the column sums the normalisation needs
+        stats = self.training and self.bias is None
         if self.stride == 1:
             rb = m.rulebook_same(l, self.kernel_size)
-            y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb, rb, True, rb.n_out)
+            y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb, rb, True, rb.n_out, collect_stats=stats)
             return x.new(y)
         assert self.stride == 2 and self.kernel_size == 2, 'only k2s2 strided convolutions are on the path'
         rb_f, rb_b = m.rulebook_down(l), m.rulebook_up(l)
-        y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out)
+        y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out, collect_stats=stats)
         return x.new(y, level=l + 1)
 
 
@@ -104,7 +107,8 @@ class MinkowskiConvolutionTranspose(_ConvBase):
         m, l = x.manager, x.level - 1
         x1, x2 = _sources(x)
         rb_f, rb_b = m.rulebook_up(l), m.rulebook_down(l)
-        y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out)
+        y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out,
+                           collect_stats=self.training and self.bias is None)
         return x.new(y, level=l)
 
 

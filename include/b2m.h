@@ -145,6 +145,18 @@ int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int
                  const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                  int64_t n_out, float* y, int64_t ldy, int32_t cout, int32_t accumulate, void* stream);
 
+/* b2m_conv_fwd that also leaves the per-tile column sums of the finished output: tile_stats[t][0][c] = sum over the
+ * rows of tile t (64 output rows) of Y[row, c], tile_stats[t][1][c] the sum of squares ([ceil(n_out/64)][2][cout]
+ * doubles, accumulated in fp64) -- the statistics pass of the MinkowskiBatchNorm that follows every trunk convolution (resnet.py:61-66,
+ * detection_net.py:37-135) without reading Y again; consumed by b2m_bn_tilestats(_finalize).  *wrote_stats (host) = 1
+ * if the sums were written (real rulebook, whole 16-channel chunks, un-split map or exactly 4 in-LDS-combined
+ * slices), 0 if this shape takes a kernel that cannot (the caller then runs b2m_bn_stats as before). */
+int b2m_conv_fwd_stats(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
+                       int64_t n_in, const float* wp, int32_t K, const float* bias,
+                       const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                       int64_t n_out, float* y, int64_t ldy, int32_t cout, int32_t accumulate,
+                       double* tile_stats, int32_t* wrote_stats, void* stream);
+
 /* dW[k][ci][co] += sum over pairs (i,o) of offset k:  X[i, ci] * dY[o, co]     (fp32 atomics)
  * Replaces [ME] ConvolutionBackward (weight part).  x: n_in rows indexed by rb_in (ldx, cin columns used),
  * dy: rows indexed by tile*TILE+rb_out.  dw element (k,ci,co) lives at dw[k*dw_kstride + ci*lddw + co]
@@ -171,6 +183,15 @@ int b2m_bn_stats_finalize(const float* x, int64_t ldx, int64_t n, int32_t c, dou
                           const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* mean, float* invstd,
                           float* scale, float* shift, void* stream);
+
+/* BatchNorm statistics from the per-tile column sums of b2m_conv_fwd_stats instead of a pass over x:
+ * b2m_bn_tilestats = b2m_bn_stats, b2m_bn_tilestats_finalize = b2m_bn_stats_finalize with (tile_stats, ntiles) in
+ * place of (x, ldx); n = number of rows the sums cover.  partial: double[2*c*1280] scratch. */
+int b2m_bn_tilestats(const double* tile_stats, int64_t ntiles, int32_t c, double* partial, double* stats, void* stream);
+int b2m_bn_tilestats_finalize(const double* tile_stats, int64_t ntiles, int64_t n, int32_t c, double* partial,
+                              double* stats, const float* gamma, const float* beta, float eps, float momentum,
+                              float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                              float* shift, void* stream);
 
 /* From (possibly all-reduced) sums: scale/shift for the apply kernel, saved mean/invstd, and the
  * running-statistics update (momentum, unbiased variance), all on device.

@@ -217,3 +217,49 @@ def test_dense_equivalence_k2s2_and_transpose_random_occupancy(cin, cout):
     yg = F_.sparse_conv(xg, None, wg, None, m.rulebook_up(0), m.rulebook_down(0), False, nf)
     yg.backward(gy.float().cuda())
     _close(yg, yd, 'up forward'); _close(xg.grad, xd.grad, 'up dgrad'); _close(wg.grad, wd.grad, 'up wgrad')
+
+
+# ------------------------------------------------------------------ 4. BatchNorm statistics from the convolution's epilogue
+@pytest.mark.parametrize('regime', ['unsplit', 'split4', 'many_slices'])
+@pytest.mark.parametrize('cin,cout', [(96, 96), (32, 64), (64, 128)])
+def test_conv_tile_stats_feed_batchnorm(maps, monkeypatch, regime, cin, cout):
+    """b2m_conv_fwd_stats: the per-tile column sums the convolution kernel leaves behind equal the sums of its output,
+    and BatchNorm fed by them equals BatchNorm that reads the output (b2m_bn_stats) -- forward, running statistics and
+    the gradients.  `many_slices` (atomic combine across workgroups) cannot provide them and must fall back."""
+    from box2mask_amd import functional as F_
+    env = {'unsplit': {'B2M_CONV_TARGET': '0'}, 'split4': {'B2M_CONV_TARGET': '800', 'B2M_CONV_CHUNKSPLIT': '0'}, 'many_slices': {'B2M_CONV_TARGET': '100000'}}
+    for k, v in env[regime].items():
+        monkeypatch.setenv(k, v)
+    m, _ = maps
+    rb = m.rulebook_same(0, 3)
+    n = rb.n_out
+    torch.manual_seed(zlib.crc32(repr((regime, cin, cout)).encode()))
+    x = torch.randn(n, cin, device='cuda')
+    w = (torch.randn(27, cin, cout, device='cuda') * 0.05).requires_grad_(True)
+    gamma = (torch.rand(cout, device='cuda') + 0.5).requires_grad_(True)
+    beta = torch.randn(cout, device='cuda').requires_grad_(True)
+
+    def run(stats):
+        monkeypatch.setenv('B2M_CONV_STATS', '1' if stats else '0')
+        rm, rv = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+        y = F_.sparse_conv(x, None, w, None, rb, rb, True, n, collect_stats=True)
+        ts = getattr(y, '_b2m_tile_stats', None)
+        out = F_.batch_norm(y, gamma, beta, rm, rv, True, relu=True)
+        g = torch.autograd.grad(out.square().sum(), (w, gamma, beta))
+        return y.detach(), ts, out.detach(), rm, rv, g
+    y1, ts, o1, rm1, rv1, g1 = run(True)
+    y0, ts0, o0, rm0, rv0, g0 = run(False)
+    assert ts0 is None
+    if regime == 'many_slices':
+        assert ts is None                          # more than 4 slices: partial sums of different workgroups, no owner
+        return
+    assert ts is not None and ts[1] == (n + 63) // 64
+    pad = torch.zeros(ts[1] * 64 - n, cout, device='cuda')
+    yt = torch.cat([y1, pad]).reshape(ts[1], 64, cout).double()
+    _close(ts[0][:, 0].double(), yt.sum(1), 'tile sums', 1e-5)
+    _close(ts[0][:, 1].double(), (yt * yt).sum(1), 'tile sums of squares', 1e-5)
+    _close(o1, o0, 'BN output', 1e-5)
+    _close(rm1, rm0, 'running mean', 1e-5)
+    _close(rv1, rv0, 'running var', 1e-5)
+    for a, b, nm in zip(g1, g0, ('dW', 'dgamma', 'dbeta')):
+        _close(a, b, nm, 1e-4)
