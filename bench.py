@@ -49,7 +49,7 @@ class LaunchTimer:
         if name == 'b2m_bn_apply':
             # x, ldx, n, c, scale, shift, residual, ldr, relu, y, ldy: streams x (+ residual) in and y out
             meta = dict(bytes=4.0 * args[2] * args[3] * (3 if args[6] else 2))
-        elif name == 'b2m_conv_fwd':
+        elif name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats'):      # same leading arguments
             # x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
             meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12], n_in=args[6])
         else:   # b2m_conv_wgrad: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
@@ -144,7 +144,7 @@ def main():
     # (b2m_conv_fwd: `roofline_timed_region`, as it ran), and K more steps AFTER the H2D-inclusive repeat run with the side
     # stream off and all three kernels bracketed (`roofline`, `roofline_wgrad`, `roofline_bn_apply`: every kernel alone on
     # the chip, which is what a roofline fraction is about).
-    timer = LaunchTimer(['b2m_conv_fwd'])
+    timer = LaunchTimer(['b2m_conv_fwd', 'b2m_conv_fwd_stats'])
     _lib.set_hook(timer.hook)
 
     def step():
@@ -213,7 +213,7 @@ def main():
     # ---- K more steps, one stream, every conv / BN-apply launch bracketed: the kernels' own durations
     timed_records = timer.records
     timer.records = []
-    timer.names = {'b2m_conv_fwd', 'b2m_conv_wgrad', 'b2m_bn_apply'}
+    timer.names = {'b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_wgrad', 'b2m_bn_apply'}
     os.environ['B2M_WGRAD_STREAM'] = '0'
     step()
     torch.cuda.synchronize()
@@ -240,6 +240,8 @@ def main():
         if name == 'b2m_bn_apply':
             hbm['ms'] += ms; hbm['bytes'] += meta['bytes']; hbm['launches'] += 1
             continue
+        if name == 'b2m_conv_fwd_stats':
+            name = 'b2m_conv_fwd'
         P = pairs_of(meta, cache, rb_lookup)
         flops = 2.0 * P * meta['cin'] * meta['cout']
         # bytes any implementation moves: both feature matrices once, the weights once, the pair lists
@@ -254,7 +256,7 @@ def main():
         for name, s_, e_, meta in timer.records:
             if name == 'b2m_bn_apply':
                 continue
-            key = (name[4:], meta['K'], meta['cin'], meta['cout'], meta['n_out'])
+            key = ('conv_fwd' if name == 'b2m_conv_fwd_stats' else name[4:], meta['K'], meta['cin'], meta['cout'], meta['n_out'])
             d = shapes.setdefault(key, [0.0, 0.0, 0])
             d[0] += s_.elapsed_time(e_); d[1] += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']; d[2] += 1
         print('%-11s %4s %4s %4s %9s %6s %9s %8s' % ('kernel', 'K', 'cin', 'cout', 'n_out', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)

@@ -67,7 +67,7 @@ extern "C" int b2m_debug_stamps(unsigned long long* out8, int reset) {   // out8
 // Default: one chunk per XCD (contiguous eighths).  Work per tile varies over a scene, so the eighths differ in total
 // work (up to 8 % on 4 scenes, 5 % on the 8 scenes of the benchmark); finer chunks (B2M_XCD_TILES=32) even that out
 // but measured 0-2 % SLOWER in the training step -- L2 locality is worth more than the balance
-// (profiles/r02_pipe_analysis.md).
+// (profiles/r02_conv_analysis.md).
 struct XcdOrder { int64_t chunk; unsigned grid; };
 static inline XcdOrder xcd_order(int64_t nwg, int64_t chunk_pref) {
     XcdOrder o;
