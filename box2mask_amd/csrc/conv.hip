@@ -596,6 +596,8 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
             nslice = (nslice + 3) / 4 * 4;
             if (nslice > K) nslice = K / 4 * 4;
             if (nslice > 16) nslice = 16;
+            const int cap = env_flag("B2M_CONV_MAXSLICE", 16);
+            if (nslice > cap) nslice = cap;
         }
     }
     // tiny maps (a few tiles): also split the input-channel chunks, up to 4 ways, so that a wave's dependent chain of
