@@ -596,7 +596,10 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
             nslice = (nslice + 3) / 4 * 4;
             if (nslice > K) nslice = K / 4 * 4;
             if (nslice > 16) nslice = 16;
-            const int cap = env_flag("B2M_CONV_MAXSLICE", 16);
+            // At most 4 slices (one workgroup per item: plain stores, no zero-fill, no atomics, and the epilogue can
+            // take the BatchNorm column sums) unless the map is tiny: measured equal or faster than 8..16 slices from
+            // 8 tiles up (the atomic combine and the memset eat what the extra waves gain), slower below.
+            const int cap = env_flag("B2M_CONV_MAXSLICE", a.ntiles >= 8 ? 4 : 16);
             if (nslice > cap) nslice = cap;
         }
     }

@@ -38,7 +38,7 @@ REGIMES = {
     'unsplit': {'B2M_CONV_TARGET': '0'},
     'atomic_combine': {'B2M_CONV_WGCOMBINE': '0'},
     'no_chunk_slices': {'B2M_CONV_CHUNKSPLIT': '0'},
-    'many_slices': {'B2M_CONV_TARGET': '100000'},
+    'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'},
     'wgrad_plain': {'B2M_WGRAD_PIPE': '0'},
     'wgrad_64_tile_chunks': {'B2M_WGRAD_MIN_TILES': '64'},
     'no_xcd_order': {'B2M_XCD': '0'},
@@ -227,7 +227,7 @@ def test_conv_tile_stats_feed_batchnorm(maps, monkeypatch, regime, cin, cout):
     and BatchNorm fed by them equals BatchNorm that reads the output (b2m_bn_stats) -- forward, running statistics and
     the gradients.  `many_slices` (atomic combine across workgroups) cannot provide them and must fall back."""
     from box2mask_amd import functional as F_
-    env = {'unsplit': {'B2M_CONV_TARGET': '0'}, 'split4': {'B2M_CONV_TARGET': '800', 'B2M_CONV_CHUNKSPLIT': '0'}, 'many_slices': {'B2M_CONV_TARGET': '100000'}}
+    env = {'unsplit': {'B2M_CONV_TARGET': '0'}, 'split4': {'B2M_CONV_TARGET': '800', 'B2M_CONV_CHUNKSPLIT': '0'}, 'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'}}
     for k, v in env[regime].items():
         monkeypatch.setenv(k, v)
     m, _ = maps
