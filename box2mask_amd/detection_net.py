@@ -130,6 +130,7 @@ class SelectionNet(ResNetBase):
         (detection_net.py:234-364)."""
         cbr = self._cbr
         tr = getattr(self, '_trace', None)          # optional dict: named intermediates for parity debugging
+        F_.join_side_streams()                      # (a backward pass that died half-way leaves its side stream un-joined)
         F_.packed_weights.begin_pass()              # one launch repacks every layer's weight images for this pass
         arena = getattr(self, '_grad_arena', None)
         if arena is not None and torch.is_grad_enabled():
