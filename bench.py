@@ -109,6 +109,8 @@ def main():
     if world != args.gpus:
         sys.exit('bench.py: started as %d rank(s) but --gpus %d' % (world, args.gpus))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('B2M_BENCH_ONE_DEVICE') == '1':      # rehearsal of the N > 1 path on a one-GPU box (with B2M_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     torch.manual_seed(1234)
@@ -359,6 +361,8 @@ def spawn_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
+    if os.environ.get('B2M_BENCH_ONE_DEVICE') == '1':
+        have = n
     if have < n:
         print('bench.py: --gpus %d requested but only %d device(s) are visible' % (n, have), file=sys.stderr)
         return 2

@@ -32,7 +32,8 @@ def init_distributed(backend: str | None = None):
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # B2M_DIST_BACKEND=gloo: rehearse the N > 1 path where RCCL cannot run (several ranks on one GPU, or no GPU)
+        backend = os.environ.get('B2M_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(local)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
