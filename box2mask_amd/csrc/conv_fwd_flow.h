@@ -37,13 +37,23 @@ __device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float
     const int64_t rem = a.n_out - row0;
     const int rows = rem < B2M_TILE ? (int)rem : B2M_TILE;
     if (lane < SW && col0 + lane < a.cout) {
-        double s = 0., s2 = 0.;                  // fp64: the variance is a difference of these sums (8-row deep levels!)
-        for (int r = 0; r < rows; ++r) {
+        // fp64: the variance is a difference of these sums (8-row deep levels!).  Four independent chains (rows r, r+1,
+        // r+2, r+3 of every group of four): the dependent fp64 add latency would otherwise be the whole cost
+        double s[4] = {0., 0., 0., 0.}, s2[4] = {0., 0., 0., 0.};
+        int r = 0;
+        for (; r + 3 < rows; r += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double v = (double)strip[(r + u) * PITCH + lane];
+                s[u] += v; s2[u] = fma(v, v, s2[u]);
+            }
+        }
+        for (; r < rows; ++r) {
             const double v = (double)strip[r * PITCH + lane];
-            s += v; s2 = fma(v, v, s2);
+            s[0] += v; s2[0] = fma(v, v, s2[0]);
         }
         double* o = a.stats + tile * 2 * a.cout + col0 + lane;
-        o[0] = s; o[a.cout] = s2;
+        o[0] = (s[0] + s[1]) + (s[2] + s[3]); o[a.cout] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
     }
 }
 #define tile_column_sums(a, strip, tile, row0, col0, lane) strip_column_sums<SW>(a, strip, tile, row0, col0, lane)
