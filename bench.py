@@ -293,6 +293,17 @@ def main():
     wg = agg.get('b2m_conv_wgrad', dict(ms=0.0, flops=0.0, launches=0))
     roofline = roof(fwd, 'conv_fwd_kernel')
     roofline['kernel'] = 'b2m_conv_fwd: conv_fwd_flow_kernel (+ conv_fwd_kernel for 1x1 / 6-channel layers), forward + data gradient'
+    # the heaviest layer shapes of the dominant kernel, each with its own fraction (same isolated-kernel pass)
+    shp = {}
+    for name, s_, e_, meta in timer.records:
+        if name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats'):
+            d_ = shp.setdefault((meta['K'], meta['cin'], meta['cout'], meta['n_out']), [0.0, 0.0, 0])
+            d_[0] += s_.elapsed_time(e_); d_[1] += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']; d_[2] += 1
+    roofline['top_shapes'] = [
+        {'K': k_[0], 'cin': k_[1], 'cout': k_[2], 'rows': k_[3], 'launches_per_step': v_[2] // max(args.steps, 1),
+         'ms_per_step': round(v_[0] / max(args.steps, 1), 3), 'achieved': round(v_[1] / v_[0] / 1e9, 2),
+         'frac': round(v_[1] / v_[0] / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        for k_, v_ in sorted(shp.items(), key=lambda kv: -kv[1][0])[:4] if v_[0] > 0]
     # the dominant kernel as it ran inside the timed region (beside the weight-gradient stream)
     tr = dict(ms=0.0, flops=0.0, launches=0, bytes=0.0)
     for name, s_, e_, meta in timed_records:
