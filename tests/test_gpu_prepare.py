@@ -335,7 +335,13 @@ def test_other_dataset_branches_match_reference_golden(golden_dir):
             _close(a[0], g['s%d_s3dis_i%d_point0' % (i, ign)], 's3dis point inst')
             _close(a[1], g['s%d_s3dis_i%d_point1' % (i, ign)], 's3dis point sem')
         cfg = SimpleNamespace(ignore_wall_ceiling_floor=True)
-        check('s%d_s3dis_mask' % i, prepare.mask_supervision(prepare.voxelize_scene(sc, vs), lab, cfg, 's3dis'))
+        it = prepare.voxelize_scene(sc, vs)
+        check('s%d_s3dis_mask' % i, prepare.mask_supervision(it, lab, cfg, 's3dis'))
+        for k in ('vox2point', 'point2vox', 'vox_segments', 'seg2vox', 'seg2point'):        # S3DIS.__getitem__ (:671-730)
+            _close(it[k], g['s%d_s3dis_%s' % (i, k)], 's3dis ' + k)
+        assert np.array_equal(it['vox_coords'][:, 1:].cpu().numpy(), g['s%d_s3dis_vox_coords' % i].astype(np.int32))
+        assert np.array_equal(it['vox_features'].cpu().numpy(), g['s%d_s3dis_vox_features' % i].astype(np.float32))
+        _close(it['input_location'], g['s%d_s3dis_input_location' % i], 's3dis input_location')
 
 
 def test_segment_mode_and_oriented_boxes_on_a_large_scene():

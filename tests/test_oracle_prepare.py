@@ -99,6 +99,8 @@ def test_oracle_other_association_branches_match_reference():
             v = R.voxelize_scene(pos, sc['colors'], sc['normals'], seg, vs)
             useg = v['unique_vox_segments']
             if tag == 'scannet':
+                for k in ('vox_coords', 'vox2point', 'point2vox', 'vox_segments', 'seg2vox', 'seg2point'):   # S3DIS.__getitem__
+                    assert np.array_equal(v[k], g['s%d_s3dis_%s' % (i, k)]), k
                 for h in (1, 0):
                     pp, ps = R.approx_association_points(pos, seg, lab, useg, bool(h), True)
                     assert np.array_equal(pp, g['s%d_scannet_majority_h%d_pseudo0' % (i, h)])

@@ -484,6 +484,9 @@ def gen_prepare2():
             out['s%d_s3dis_i%d_point0' % (i, ign)], out['s%d_s3dis_i%d_point1' % (i, ign)] = (np.asarray(v) for v in a)
         r = run(D.S3DIS, D.s3dis, sc, 'val', do_segment_pooling=True, bb_supervision=False, ignore_wall_ceiling_floor=True)
         put('s%d_s3dis_mask' % i, r, TGT)
+        # the voxelisation block of S3DIS.__getitem__ itself (:671-730)
+        put('s%d_s3dis' % i, r, ('vox_coords', 'vox2point', 'point2vox', 'vox_segments', 'vox_features', 'seg2vox',
+                                 'seg2point', 'input_location'))
     np.savez_compressed(os.path.join(OUT, 'prepare2.npz'), **out)
     print('prepare2.npz: %d arrays, %.1f kB' % (len(out), os.path.getsize(os.path.join(OUT, 'prepare2.npz')) / 1e3))
 
