@@ -2,7 +2,7 @@
 // All HBM-bound: float4 accesses, one pass per tensor, deterministic two-stage column reductions.
 #include "b2m_common.h"
 
-#define RED_MAX_BLOCKS 1280   // 256 CUs x 5 resident blocks of bn_bwd_reduce: one full round, no tail
+#define RED_MAX_BLOCKS 1280   // 256 CUs x 5 resident blocks of bn_bwd_reduce: one full round, no tail (4096: 12 % slower)
 
 // Column reduction skeleton.  256 threads; thread -> (float4 column group cg, row slot rs).
 // F(row, cg) returns two float4 contributions (a, b); the block writes double partial sums
@@ -49,6 +49,57 @@ __device__ __forceinline__ void column_reduce(int64_t n, int c, double* __restri
         for (int u = 0; u < 4; ++u) { o[cg * 4 + u] = da[u]; o[c + cg * 4 + u] = db[u]; }
     }
 }
+// The same with the loads of four rows issued BEFORE any of them is used: `load(row, cg, in)` fills NIN float4 registers,
+// `f(in, a, b)` turns them into the two contributions.  In column_reduce the functor loads and computes, and with
+// wave-uniform branches inside it hipcc waited for every row's data before issuing the next row's loads: two or three
+// 16-byte loads in flight per thread, 3.5 TB/s; staged, eight to twelve.
+template <int NIN, class L, class F>
+__device__ __forceinline__ void column_reduce_staged(int64_t n, int c, double* __restrict__ partial, L load, F f) {
+    extern __shared__ float red[];             // [nslots][c4][8]
+    const int c4 = c >> 2;
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    const int64_t rows_per_blk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > n) r1 = n;
+    f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
+    if (rs < nslots) {
+        int64_t r = r0 + rs;
+        for (; r + 3 * nslots < r1; r += 4 * nslots) {
+            f32x4 in[4][NIN];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load(r + (int64_t)u * nslots, cg, in[u]);
+            __builtin_amdgcn_sched_barrier(0);         // (left alone, the scheduler sinks each load to its first use)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 a, b;
+                f(in[u], a, b);
+                sa += a; sb += b;
+            }
+        }
+        for (; r < r1; r += nslots) {
+            f32x4 in[NIN], a, b;
+            load(r, cg, in);
+            f(in, a, b);
+            sa += a; sb += b;
+        }
+        float* p = red + ((size_t)rs * c4 + cg) * 8;
+        *(f32x4*)p = sa; *(f32x4*)(p + 4) = sb;
+    }
+    __syncthreads();
+    if (rs == 0) {
+        double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+        for (int s = 0; s < nslots; ++s) {
+            const float* p = red + ((size_t)s * c4 + cg) * 8;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { da[u] += (double)p[u]; db[u] += (double)p[4 + u]; }
+        }
+        double* o = partial + (size_t)blockIdx.x * 2 * c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[cg * 4 + u] = da[u]; o[c + cg * 4 + u] = db[u]; }
+    }
+}
 // one wave per output column: lanes sum strided partials, then a fixed-order shuffle tree (deterministic)
 __global__ __launch_bounds__(64) void reduce_final_kernel(const double* __restrict__ partial, int nblk, int c2,
                                                           double* __restrict__ out, float* __restrict__ out_lo,
@@ -75,10 +126,9 @@ static int reduce_blocks(int64_t n) {
 // ------------------------------------------------------------------ BN forward
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int c,
                                                        double* __restrict__ partial) {
-    column_reduce(n, c, partial, [&](int64_t r, int cg, f32x4& a, f32x4& b) {
-        f32x4 v = *(const f32x4*)(x + r * ldx + cg * 4);
-        a = v; b = v * v;
-    });
+    column_reduce_staged<1>(n, c, partial,
+        [&](int64_t r, int cg, f32x4 (&in)[1]) { in[0] = *(const f32x4*)(x + r * ldx + cg * 4); },
+        [&](const f32x4 (&in)[1], f32x4& a, f32x4& b) { a = in[0]; b = in[0] * in[0]; });
 }
 extern "C" int b2m_bn_stats(const float* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats,
                             void* stream) {
@@ -280,31 +330,42 @@ extern "C" int b2m_bn_apply(const float* x, int64_t ldx, int64_t n, int32_t c, c
 }
 
 // ------------------------------------------------------------------ BN backward
+template <bool RELU, bool HASY>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ y, int64_t ldy,
                                                             const float* __restrict__ x, int64_t ldx, int64_t n, int c,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, int relu,
+                                                            const float* __restrict__ invstd,
                                                             const float* __restrict__ mscale,
                                                             const float* __restrict__ mshift,
                                                             double* __restrict__ partial) {
-    column_reduce(n, c, partial, [&](int64_t r, int cg, f32x4& a, f32x4& b) {
-        f32x4 g = *(const f32x4*)(dy + r * lddy + cg * 4);
-        const f32x4 xx = *(const f32x4*)(x + r * ldx + cg * 4);
-        if (relu) {
-            f32x4 yy;
-            if (y) yy = *(const f32x4*)(y + r * ldy + cg * 4);
-            else {      // no residual: the sign of the forward's fmaf(x, scale, shift), one tensor read less
-                const f32x4 ms = *(const f32x4*)(mscale + cg * 4), mb = *(const f32x4*)(mshift + cg * 4);
+    // the per-column constants of this thread's column group, loaded once
+    const int c4 = c >> 2, mycg = (threadIdx.x % c4) * 4;
+    const f32x4 m = *(const f32x4*)(mean + mycg), is = *(const f32x4*)(invstd + mycg);
+    f32x4 ms = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
+    if (RELU && !HASY) { ms = *(const f32x4*)(mscale + mycg); mb = *(const f32x4*)(mshift + mycg); }
+    constexpr int NIN = HASY ? 3 : 2;
+    column_reduce_staged<NIN>(n, c, partial,
+        [&](int64_t r, int cg, f32x4 (&in)[NIN]) {
+            in[0] = *(const f32x4*)(dy + r * lddy + cg * 4);
+            in[1] = *(const f32x4*)(x + r * ldx + cg * 4);
+            if constexpr (HASY) in[2] = *(const f32x4*)(y + r * ldy + cg * 4);
+        },
+        [&](const f32x4 (&in)[NIN], f32x4& a, f32x4& b) {
+            f32x4 g = in[0];
+            const f32x4 xx = in[1];
+            if constexpr (RELU) {
+                f32x4 yy;
+                if constexpr (HASY) yy = in[2];
+                else {      // no residual: the sign of the forward's fmaf(x, scale, shift), one tensor read less
 #pragma unroll
-                for (int u = 0; u < 4; ++u) yy[u] = __builtin_fmaf(xx[u], ms[u], mb[u]);
+                    for (int u = 0; u < 4; ++u) yy[u] = __builtin_fmaf(xx[u], ms[u], mb[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
-        }
-        const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
-        a = g; b = g * ((xx - m) * is);
-    });
+            a = g; b = g * ((xx - m) * is);
+        });
 }
 extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
                                  int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd,
@@ -317,8 +378,10 @@ extern "C" int b2m_bn_bwd_reduce(const float* dy, int64_t lddy, const float* y, 
                   "c and leading dimensions must be multiples of 4");
     const int nblk = reduce_blocks(n);
     const int c4 = c / 4, nslots = 256 / c4;
-    bn_bwd_reduce_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>(dy, lddy, y, ldy, x, ldx, n, c,
-                                                                                   mean, invstd, relu, y ? nullptr : mask_scale, y ? nullptr : mask_shift, partial);
+    const size_t lds = (size_t)nslots * c4 * 8 * sizeof(float);
+    if (!relu) bn_bwd_reduce_kernel<false, false><<<nblk, 256, lds, st>>>(dy, lddy, nullptr, 0, x, ldx, n, c, mean, invstd, nullptr, nullptr, partial);
+    else if (y) bn_bwd_reduce_kernel<true, true><<<nblk, 256, lds, st>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, nullptr, nullptr, partial);
+    else bn_bwd_reduce_kernel<true, false><<<nblk, 256, lds, st>>>(dy, lddy, nullptr, 0, x, ldx, n, c, mean, invstd, mask_scale, mask_shift, partial);
     reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, dbeta_f32, dgamma_f32);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
