@@ -1109,10 +1109,10 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     a.fast32 = (ldx >= (int64_t)a.nmb * 16 * MI && lddy >= (int64_t)a.nnb * 16 * NJ && n_out < (1 << 24) && n_in < (1 << 24) &&
                 ldx < (1 << 22) && lddy < (1 << 22) && n_out * lddy * 4 < (1ll << 32) && n_in * ldx * 4 < (1ll << 32) &&
                 env_flag("B2M_WGRAD_FAST32", 1)) ? 1 : 0;
-    // A/B on one box (tools/bench_conv.py): +8..26 % on the 32/96/128-channel layers; the 64x64 blocks of the
-    // 64-channel layers drop to 2 waves per SIMD and lose 10 %, they stay on the plain kernel
-    a.pipe = (a.fast32 && rb_in != nullptr && !(MI * NJ >= 16 && cin <= 64 && cout <= 64) && !workspace &&
-              env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
+    // The flat-pipeline kernel for real rulebooks and 32-bit addressable operands.  Its MFMAs are asm statements the
+    // compiler's hazard recogniser cannot see: a block with a single accumulator (MI = NJ = 1: consecutive MFMAs on the
+    // same registers) stays on the plain kernel, where the builtin lets hipcc place whatever the dependence needs.
+    a.pipe = (a.fast32 && rb_in != nullptr && MI * NJ >= 2 && !workspace && env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
     launch_wgrad(MI, NJ, grid, st, a);
     if (workspace) {
         const int nchunks = (int)cdiv64(a.ntiles, tpc);
