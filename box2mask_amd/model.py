@@ -65,10 +65,64 @@ class Model:
         self.BCEWithLogitsLoss = torch.nn.BCEWithLogitsLoss().to(device)
         self.semantics_loss = torch.nn.CrossEntropyLoss(ignore_index=-100).to(device)
         self._id2idx_dev = None
+        self._pf_stream = None
+        self._prefetched = None
 
     def compute_loss(self, batch, epoch):
         losses_dict, pred = self.compute_loss_detection(batch, epoch)
         return losses_dict
+
+    # ---- next batch's sparse tensor ahead of time (optional; the reference's loop does not need to call it)
+    @staticmethod
+    def _batch_key(batch):
+        c, f = batch['vox_coords'], batch['vox_features']
+        return (id(c), c.data_ptr(), tuple(c.shape), id(f), f.data_ptr())
+
+    def prefetch(self, batch, ready=None):
+        """Build the ME.SparseTensor of `batch` -- Morton order, coordinate hash, the 7 strided coordinate maps, the 16
+        kernel maps and their rulebooks -- NOW, on a second stream, and hand it to the next `compute_loss(batch, ...)`.
+        Called right after `optimizer.step()` for the batch the data loader already holds, the ~2 ms of map kernels and
+        the dozen host reads of their row counts run beside the current step's backward pass instead of in front of the
+        next step's first convolution (the host reads wait for the side stream only).  `vox_coords` / `vox_features`
+        may be (pinned) host tensors: the copy runs on the side stream as well.  Never required: a batch that was not
+        prefetched is built inside compute_loss as before; results are identical.
+
+        `ready` says when the tensors of `batch` are valid on the device: None = after everything enqueued on the current
+        stream so far (always safe, but the side stream then starts only when the current step has finished -- only the
+        host reads move); a torch.cuda.Event recorded after they were written; True = they are complete already (host
+        tensors, or device tensors made before the current step was enqueued) -- the maps are then built WHILE the
+        current step runs."""
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream(device=self.device)
+        side = self._pf_stream
+        if ready is None:
+            side.wait_stream(torch.cuda.current_stream())
+        elif ready is not True:
+            side.wait_event(ready)
+        with torch.cuda.stream(side):
+            sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=self.device)
+            if sin.manager is not None:
+                sin.manager.prefetch(8, same=[(0, 5)] + [(l, 3) for l in range(8)], strided=True)
+            fg_rows = None                                     # the loss terms' foreground row list (a host read too)
+            if 'fg_instances' in batch and (self.cfg.loss_on_fg_instances or self.cfg.bb_supervision):
+                fg_rows = torch.nonzero(batch['fg_instances'].to(self.device)).reshape(-1)
+        self._prefetched = (self._batch_key(batch), sin, fg_rows)
+
+    def _take_prefetched(self, batch):
+        pf = self._prefetched
+        self._prefetched = None
+        if pf is None or pf[0] != self._batch_key(batch):
+            return None, None
+        sin, fg_rows = pf[1], pf[2]
+        main = torch.cuda.current_stream()
+        main.wait_stream(self._pf_stream)
+        # built on the side stream, used (and later freed) while kernels of THIS stream read it
+        sin.F.record_stream(main)
+        for t in sin.manager.tensors():
+            t.record_stream(main)
+        if fg_rows is not None:
+            fg_rows.record_stream(main)
+        return sin, fg_rows
 
     def _sem_lut(self):
         if self._id2idx_dev is None:
@@ -84,12 +138,12 @@ class Model:
         # indexing is a host read of the row count.  Here the row list is made ONCE, BEFORE the forward pass is enqueued (the
         # host still has nothing to wait for), and every term gathers with it: same rows, same order, no host read while
         # the device works through the network -- the backward pass is enqueued behind the forward without a stall.
-        fg = fg_rows = None
-        if 'fg_instances' in batch:
-            fg = batch['fg_instances'].to(device)
-            if on_fg:
-                fg_rows = torch.nonzero(fg).reshape(-1)
-        sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=device)
+        sin, fg_rows = self._take_prefetched(batch)            # Model.prefetch(batch) ran: both were made ahead of time
+        fg = batch['fg_instances'].to(device) if 'fg_instances' in batch else None
+        if fg is not None and on_fg and fg_rows is None:
+            fg_rows = torch.nonzero(fg).reshape(-1)
+        if sin is None:
+            sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=device)
         n_seg = batch['input_location'].shape[0] if cfg.do_segment_pooling else None
         pred = self.detection_model(sin, batch['pooling_ids'].to(device), n_seg)
         for mlp_head, sparse_tensor in pred.items():

@@ -179,6 +179,22 @@ class CoordinateManager:
         self._rb[('down', level)] = Rulebook(child, 8, nc, nf, self.keep_tables)
         self._rb[('up', level)] = Rulebook(up, 8, nf, nc, self.keep_tables)
 
+    def tensors(self):
+        """Every device tensor this manager (and its kernel maps) owns -- for `record_stream` when the manager was built
+        on one stream and is used on another (Model.prefetch)."""
+        for t in self.coords + self.parent + self.koff + [self.perm, self.inv_perm, self.dup_count]:
+            if t is not None:
+                yield t
+        for keys, vals, _ in self.tables:
+            yield keys
+            yield vals
+        if self._occ:
+            yield self._occ[0]
+        for rb in self._rb.values():
+            for t in (rb.rb_in, rb.rb_out, rb.rb_cnt, rb.nbr):
+                if t is not None:
+                    yield t
+
     def prefetch(self, n_levels: int, same=(), strided: bool = True):
         """Build the coordinate maps of levels 0 .. n_levels-1 and the kernel maps a network will ask for -- `same`:
         (level, kernel size) pairs, `strided`: every k2s2 map between consecutive levels -- NOW.  Every level's row count

@@ -60,3 +60,47 @@ def test_ordered_forms_agree_with_the_fast_ones(monkeypatch):
         assert torch.equal(b_, c), what + ': two deterministic runs differ'
         err = float((a - b_).abs().max()) / float(b_.abs().max())
         assert err < 1e-5, (what, err)
+
+
+def test_prefetched_batch_gives_the_same_bits(monkeypatch):
+    """Model.prefetch builds the sparse tensor (coordinate maps, kernel maps, foreground row list) on a second stream
+    ahead of time: loss and gradients are the SAME BITS as when compute_loss builds them itself; a prefetch for other
+    tensors is dropped (the batch is built in place); host tensors are copied by the side stream."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    torch.manual_seed(5)
+    model = Model(scannet_config(), *synth.scannet_tables())
+    model.train()
+    batch = synth.make_batch(3, seed0=31, target_voxels=12000, pts_per_m2=8000.0)
+    other = synth.make_batch(2, seed0=77, target_voxels=5000, pts_per_m2=8000.0)
+
+    def run(prefetch_of=None, **kw):
+        model.detection_model.zero_grad()
+        if prefetch_of is not None:
+            model.prefetch(prefetch_of, **kw)
+        taken = model._prefetched is not None and model._prefetched[0] == model._batch_key(batch)
+        losses = model.compute_loss(batch, 150)
+        assert model._prefetched is None                    # consumed or dropped, never kept for a later batch
+        losses['optimization_loss'].backward()
+        torch.cuda.synchronize()
+        return taken, float(losses['optimization_loss']), {
+            n: p.grad.detach().clone() for n, p in model.detection_model.named_parameters() if p.grad is not None}
+
+    t0, l0, g0 = run()
+    assert not t0
+    host = dict(batch, vox_coords=batch['vox_coords'].cpu(), vox_features=batch['vox_features'].cpu())
+    ev = torch.cuda.Event(); ev.record()
+    for what, (taken, l, g) in (('default', run(batch)), ('ready=True', run(batch, ready=True)),
+                                ('event', run(batch, ready=ev)), ('other batch', run(other))):
+        assert taken == (what != 'other batch'), what
+        assert l == l0, what
+        bad = [n for n in g0 if not torch.equal(g0[n], g[n])]
+        assert not bad, (what, bad[:5])
+    # host tensors: the key is the host tensors' identity, so the step must be handed the same dict
+    model.detection_model.zero_grad()
+    model.prefetch(host, ready=True)
+    assert model._prefetched[0] == model._batch_key(host)
+    losses = model.compute_loss(host, 150)
+    assert float(losses['optimization_loss']) == l0
