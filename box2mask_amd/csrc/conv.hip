@@ -30,6 +30,9 @@ struct ConvArgs {
     int wg_combine;  // nslice % 4 == 0: the 4 waves of a workgroup are 4 slices of one item and add up in LDS first
     int64_t nwg;     // workgroups of work; the grid is padded, see xcd_order()
     int64_t xcd_per; // > 0: XCD-aware order in chunks of this many workgroups, see wg_index()
+    const int32_t* xcd_start;  // != NULL: work-balanced XCD runs, first tile of XCD 0..7 and ntiles (wg_index_balanced)
+    int64_t wg_per_tile;       //          workgroups per tile in that order
+    const int32_t* tile_order; //          tile worked on at position j of that order (heavy tiles of a run's end first)
     double* stats;   // != NULL: per-tile column sums of the finished output, [tile][2][cout] (sum, sum of squares): the
                      // BatchNorm statistics of the following layer without another pass over Y (conv_fwd_flow_kernel only)
 };
@@ -85,6 +88,17 @@ __device__ __forceinline__ int64_t wg_index(int64_t nwg, int64_t chunk) {
     const int64_t x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int64_t v = ((j / chunk) * 8 + x) * chunk + (j % chunk);
     return v < nwg ? v : -1;
+}
+
+// Work-balanced form: XCD x owns the tiles [start[x], start[x+1]) that b2m_rulebook_balance chose (equal WORK, not
+// equal tile counts), `per_tile` workgroups each; hardware workgroup 8*j + x is the j-th of XCD x.  The grid covers the
+// longest run the balance kernel allows (B2M_XCD_CAP tiles); workgroups past the end of their XCD's run leave.
+#define B2M_XCD_CAP(ntiles) (((ntiles) * 5 + 31) / 32)
+__device__ __forceinline__ int64_t wg_index_balanced(const int32_t* __restrict__ start, int64_t per_tile) {
+    const int x = blockIdx.x & 7;
+    const int64_t j = blockIdx.x >> 3;
+    const int64_t v = (int64_t)start[x] * per_tile + j;
+    return v < (int64_t)start[x + 1] * per_tile ? v : -1;
 }
 
 static_assert(B2M_TILE == 64, "conv kernels assume 64-row tiles (4 row groups of 16)");
@@ -576,6 +590,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
     a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
     a.stats = nullptr;
+    a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr;
     const int TW = conv_tw(cout, K);
     a.nstrips = (cout + 16 * TW - 1) / (16 * TW);
     a.vec_store = (ldy % 4 == 0 && ((uintptr_t)y % 16) == 0) ? 1 : 0;
@@ -646,8 +661,15 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 if (wrote_stats) *wrote_stats = 1;
             }
             a.nwg = cdiv64(items, wpb);
-            const XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
+            XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
             a.xcd_per = fo.chunk;
+            // XCD runs of equal work (the tail of rb_cnt, b2m_rulebook_balance) instead of equal tile counts
+            if (a.ntiles >= 64 && xcd_tiles > 0 && (a.nstrips * nslice) % wpb == 0 && env_flag("B2M_XCD_BALANCE", 1)) {
+                a.xcd_start = rb_cnt + (int64_t)K * a.ntiles;
+                a.tile_order = env_flag("B2M_XCD_ORDER", 1) ? a.xcd_start + 16 + a.ntiles : nullptr;
+                a.wg_per_tile = a.nstrips * nslice / wpb;
+                fo.grid = (unsigned)(8 * B2M_XCD_CAP(a.ntiles) * a.wg_per_tile);
+            }
             const int dbg = env_flag("B2M_PIPE_DBG", 0);      // diagnostic builds, wrong results: tools/pipe_breakdown.py
             if (wpb == 4) {
                 if (depth == 2) {
@@ -733,18 +755,44 @@ struct WgradArgs {
     int nz;                  // block groups of 4 (ci,co) blocks
     int pipe;                // software-pipelined kernel (real rulebook, fast32)
     float* partial;          // deterministic mode: per tile-chunk partial dW (dense [chunk][K][cin][cout]), plain stores
+    const int32_t* xcd_start; // != NULL: work-balanced XCD runs of tiles (b2m_rulebook_balance); a run is cut into tile
+                              // chunks of tiles_per_chunk from ITS first tile
 };
+// work item -> (offset k, block group, tile range [t0, t1)); false: nothing to do.  `chunk` numbers the tile chunks of the
+// plain order (it addresses the deterministic mode's partial buffer, which never uses the balanced order).
+__device__ __forceinline__ bool wgrad_item(const WgradArgs& a, int& k, int& zg, int64_t& chunk, int64_t& t0, int64_t& t1) {
+    if (a.xcd_start) {
+        const int x = blockIdx.x & 7;
+        const int64_t j = blockIdx.x >> 3;
+        k = (int)(j % a.K);
+        const int64_t rest = j / a.K;
+        zg = (int)(rest % a.nz);
+        chunk = rest / a.nz;
+        const int64_t s1 = a.xcd_start[x + 1];
+        t0 = a.xcd_start[x] + chunk * a.tiles_per_chunk;
+        if (t0 >= s1) return false;
+        t1 = t0 + a.tiles_per_chunk < s1 ? t0 + a.tiles_per_chunk : s1;
+        return true;
+    }
+    const int64_t wg = wg_index(a.nwg, a.xcd_per);
+    if (wg < 0) return false;
+    k = (int)(wg % a.K);
+    const int64_t rest = wg / a.K;
+    zg = (int)(rest % a.nz);
+    chunk = rest / a.nz;
+    t0 = chunk * a.tiles_per_chunk;
+    t1 = t0 + a.tiles_per_chunk < a.ntiles ? t0 + a.tiles_per_chunk : a.ntiles;
+    return true;
+}
 
 template <int MI, int NJ>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t wg = wg_index(a.nwg, a.xcd_per);
-    if (wg < 0) return;
-    const int k = (int)(wg % a.K);
-    const int64_t rest = wg / a.K;
-    const int blk = (int)(rest % a.nz) * 4 + wave;
-    const int64_t chunk = rest / a.nz;
+    int k, zg;
+    int64_t chunk, t0, t1;
+    if (!wgrad_item(a, k, zg, chunk, t0, t1)) return;
+    const int blk = zg * 4 + wave;
     if (blk >= a.nmb * a.nnb) return;
     const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
     const bool identity = a.rb_in == nullptr;
@@ -755,9 +803,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int n = 0; n < NJ; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int64_t t0 = chunk * a.tiles_per_chunk;
-    int64_t t1 = t0 + a.tiles_per_chunk;
-    if (t1 > a.ntiles) t1 = a.ntiles;
     // a group SLOT = 16 pairs of one (tile, offset): slot = tile*4 + g
     const int64_t kbase = (int64_t)k * ldr;
     auto load_slot = [&](int64_t slot, int (&rin)[4], uint32_t& o4) {
@@ -883,18 +928,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
-    const int64_t wg = wg_index(a.nwg, a.xcd_per);
-    if (wg < 0) return;
-    const int k = (int)(wg % a.K);
-    const int64_t rest = wg / a.K;
-    const int blk = (int)(rest % a.nz) * 4 + wave;
-    const int64_t chunk = rest / a.nz;
+    int k, zg;
+    int64_t chunk, t0, t1;
+    if (!wgrad_item(a, k, zg, chunk, t0, t1)) return;
+    const int blk = zg * 4 + wave;
     if (blk >= a.nmb * a.nnb) return;
     const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
     const int64_t ldr = a.ntiles * B2M_TILE;
-    const int64_t t0 = chunk * a.tiles_per_chunk;
-    int64_t t1 = t0 + a.tiles_per_chunk;
-    if (t1 > a.ntiles) t1 = a.ntiles;
     const int nt = (int)(t1 - t0);                       // <= 64 tiles: lane t holds the pair count of tile t0 + t
     const int cnt = lane < nt ? a.rb_cnt[(int64_t)k * a.ntiles + t0 + lane] : 0;
     const uint64_t live = __ballot(cnt > 0);
@@ -1103,6 +1143,12 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     const XcdOrder xo = xcd_order(a.nwg, env_flag("B2M_XCD", 1) ? (int64_t)env_flag("B2M_XCD_WG_CHUNKS", 1 << 20) * K * a.nz : 0);
     a.xcd_per = xo.chunk;
     dim3 grid(xo.grid);
+    // XCD runs of equal work (the tail of rb_cnt, b2m_rulebook_balance), each cut into tile chunks from its own start
+    a.xcd_start = nullptr;
+    if (rb_cnt && !workspace && a.ntiles >= 64 && env_flag("B2M_XCD", 1) && env_flag("B2M_XCD_BALANCE", 1)) {
+        a.xcd_start = rb_cnt + (int64_t)K * a.ntiles;
+        grid = dim3((unsigned)(8 * K * a.nz * cdiv64(B2M_XCD_CAP(a.ntiles), tpc)));
+    }
     // 24-bit multiply operands and 32-bit byte offsets: rows < 2^24, row pitch < 2^22 floats, tensors < 4 GiB
     // (blocks may overhang cin/cout as long as the row PITCH covers them: the extra columns only feed dW rows /
     // columns that are never written)

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     const int lane = threadIdx.x & 63;
     const int wave = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
-    const int64_t wg = wg_index(a.nwg, a.xcd_per);
+    const int64_t wg = a.xcd_start ? wg_index_balanced(a.xcd_start, a.wg_per_tile) : wg_index(a.nwg, a.xcd_per);
     if (wg < 0) return;
     const int nch1 = a.c1 >> 4, NC = (a.c1 + a.c2) >> 4;      // chunks of the first source / in all
     int64_t item = wg;
@@ -89,9 +89,10 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         cb = NC / a.ncs * cslice; ce = cb + NC / a.ncs;
         lead = sl == 0;
     }
-    const int64_t tile = item / a.nstrips;
+    int64_t tile = item / a.nstrips;
     const int strip = (int)(item % a.nstrips);
     if (tile >= a.ntiles) return;             // the whole workgroup leaves (its waves share the item)
+    if (a.tile_order) tile = a.tile_order[tile];
     const int col0 = strip * SW;
     float* Cs = smem + wave * STRIP;
     const int64_t ldr = a.ntiles * B2M_TILE;

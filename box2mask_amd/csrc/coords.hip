@@ -1,6 +1,7 @@
 // Coordinate hashing, strided coordinate generation, kernel maps and the tile rulebook.
 // All integer work, HBM/L2-latency bound; results are bit-exact against oracle/sparse_ref.py.
 #include "b2m_common.h"
+#include <cstdlib>
 #include <stdarg.h>
 #include <string.h>
 
@@ -298,6 +299,164 @@ extern "C" int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int
     return B2M_OK;
 }
 
+// ------------------------------------------------------------------ XCD work boundaries of a rulebook
+// The convolution kernels give every XCD one CONTIGUOUS run of tiles (its L2 then holds the rows neighbouring tiles
+// gather in common).  Work per tile varies over a scene (surface tiles have 9..15 active offsets, interior ones 27): with
+// equal tile counts the eight runs differ by 5..10 % in work and the launch ends when the heaviest XCD does.  The
+// boundaries are therefore set by WORK: tile cost = sum over the active offsets of (3 x row groups of 16 pairs + 1), the
+// MFMA steps plus the per-offset overhead of conv_fwd_flow_kernel; the weight-gradient kernel's k-steps follow the same
+// pair counts.  Tail of rb_cnt (b2m.h): [K*ntiles + 0..8] = first tile of XCD 0..7 and ntiles; [K*ntiles + 16 + t] =
+// cost of tile t (scratch).  No run is longer than ceil(1.25 * ntiles / 8) tiles (B2M_XCD_CAP): the launch grids are
+// sized for that without a host read of the boundaries.
+__global__ __launch_bounds__(256) void rulebook_cost_kernel(int32_t* __restrict__ rb_cnt, int32_t K, int64_t ntiles) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    int cost = 0;
+    for (int k = 0; k < K; ++k) {
+        const int c = rb_cnt[(int64_t)k * ntiles + t];
+        if (c > 0) cost += 3 * ((c + 15) >> 4) + 1;
+    }
+    rb_cnt[(int64_t)K * ntiles + 16 + t] = cost;
+}
+__global__ __launch_bounds__(1024) void rulebook_balance_kernel(int32_t* __restrict__ rb_cnt, int32_t K, int64_t ntiles) {
+    __shared__ long long part[1024];
+    __shared__ int start[9];
+    const int32_t* cost = rb_cnt + (int64_t)K * ntiles + 16;
+    int32_t* out = rb_cnt + (int64_t)K * ntiles;
+    const int tid = threadIdx.x;
+    const int64_t per = (ntiles + 1023) / 1024;
+    const int64_t lo = tid * per < ntiles ? tid * per : ntiles;
+    const int64_t hi = lo + per < ntiles ? lo + per : ntiles;
+    long long s = 0;
+    for (int64_t t = lo; t < hi; ++t) s += cost[t];
+    part[tid] = s;
+    if (tid < 9) start[tid] = tid == 8 ? (int)ntiles : (int)(ntiles * tid / 8);     // (no work at all: equal runs)
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                   // inclusive scan of the 1024 chunk sums
+        const long long v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const long long total = part[1023];
+    long long run = part[tid] - s;                         // work in front of this thread's tiles
+    if (total > 0) {
+        for (int64_t t = lo; t < hi; ++t) {
+            const long long before = run;
+            run += cost[t];
+            // XCD x begins behind the tile that carries the prefix over x/8 of the total
+#pragma unroll
+            for (int x = 1; x < 8; ++x) {
+                const long long target = (total * x + 7) / 8;
+                if (before < target && run >= target) start[x] = (int)(t + 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int cap = (int)((ntiles * 5 + 31) / 32);     // B2M_XCD_CAP: 1.25 x an eighth, rounded up
+        for (int x = 1; x < 8; ++x) {
+            if (start[x] < start[x - 1]) start[x] = start[x - 1];
+            if (start[x] > start[x - 1] + cap) start[x] = start[x - 1] + cap;
+        }
+        for (int x = 7; x >= 1; --x)
+            if (start[x] < start[x + 1] - cap) start[x] = start[x + 1] - cap;
+        for (int x = 0; x < 9; ++x) out[x] = start[x];
+        for (int x = 9; x < 16; ++x) out[x] = 0;
+    }
+}
+// Dispatch order of the tiles inside each XCD run: [K*ntiles + 16 + ntiles + j] = tile worked on at position j.  A
+// conv_fwd_flow wave owns a tile for all of its offsets, and tiles differ 10x in cost (interior tiles: 27 offsets x 4 row
+// groups; surface tiles a third of that): in plain row order the launch ends with a few waves still inside heavy tiles
+// they took last -- up to 0.3 ms of a 2.3 ms launch with most SIMDs idle.  The last `window` positions of every run are
+// therefore ordered by cost class, heaviest first (B2M_XCD_CLASSES classes of equal width below the run's largest cost,
+// stable: row order inside a class, so neighbouring tiles of a class still run together); the positions before the
+// window keep the row order and with it all of the L2 locality.
+#define ORDER_MAX_CLASSES 8
+__global__ __launch_bounds__(1024) void rulebook_order_kernel(int32_t* __restrict__ rb_cnt, int32_t K, int64_t ntiles,
+                                                              int window, int ncls) {
+    __shared__ int cnts[ORDER_MAX_CLASSES][1024];
+    __shared__ int red[1024];
+    __shared__ int base[ORDER_MAX_CLASSES + 1];
+    const int32_t* start = rb_cnt + (int64_t)K * ntiles;
+    const int32_t* cost = start + 16;
+    int32_t* order = rb_cnt + (int64_t)K * ntiles + 16 + ntiles;
+    const int tid = threadIdx.x;
+    const int s0 = start[blockIdx.x], s1 = start[blockIdx.x + 1];
+    const int w0 = (window <= 0 || s1 - window < s0) ? s0 : s1 - window;
+    for (int t = s0 + tid; t < w0; t += 1024) order[t] = t;
+    const int n = s1 - w0;
+    if (n <= 0) return;
+    const int per = (n + 1023) / 1024;
+    const int lo = w0 + (tid * per < n ? tid * per : n);
+    const int hi = lo + per < s1 ? lo + per : s1;
+    int mx = 0;
+    for (int t = lo; t < hi; ++t) mx = cost[t] > mx ? cost[t] : mx;
+    red[tid] = mx;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if (tid < d && red[tid + d] > red[tid]) red[tid] = red[tid + d];
+        __syncthreads();
+    }
+    const int cmax = red[0];
+    auto cls_of = [&](int c) { const int q = (int)((long long)c * ncls / (cmax + 1)); return ncls - 1 - q; };   // 0 = heaviest
+    int mine[ORDER_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < ORDER_MAX_CLASSES; ++c) mine[c] = 0;
+    for (int t = lo; t < hi; ++t) {
+        const int q = cls_of(cost[t]);
+#pragma unroll
+        for (int c = 0; c < ORDER_MAX_CLASSES; ++c) mine[c] += (c == q);
+    }
+#pragma unroll
+    for (int c = 0; c < ORDER_MAX_CLASSES; ++c) cnts[c][tid] = mine[c];
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                   // inclusive scans over the threads, all classes at once
+        int v[ORDER_MAX_CLASSES];
+#pragma unroll
+        for (int c = 0; c < ORDER_MAX_CLASSES; ++c) v[c] = tid >= d ? cnts[c][tid - d] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < ORDER_MAX_CLASSES; ++c) cnts[c][tid] += v[c];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        base[0] = 0;
+        for (int c = 0; c < ORDER_MAX_CLASSES; ++c) base[c + 1] = base[c] + cnts[c][1023];
+    }
+    __syncthreads();
+    int pos[ORDER_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < ORDER_MAX_CLASSES; ++c) pos[c] = w0 + base[c] + cnts[c][tid] - mine[c];
+    for (int t = lo; t < hi; ++t) {
+        const int q = cls_of(cost[t]);
+        int p = 0;
+#pragma unroll
+        for (int c = 0; c < ORDER_MAX_CLASSES; ++c)
+            if (c == q) { p = pos[c]; pos[c] += 1; }
+        order[p] = t;
+    }
+}
+static int coords_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+extern "C" int64_t b2m_rulebook_cnt_size(int32_t K, int64_t n_out) {
+    const int64_t ntiles = cdiv64(n_out, B2M_TILE);
+    return (int64_t)K * ntiles + 16 + 2 * ntiles;
+}
+extern "C" int b2m_rulebook_balance(int32_t* rb_cnt, int32_t K, int64_t n_out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(rb_cnt && K >= 1, "bad arguments");
+    const int64_t ntiles = cdiv64(n_out, B2M_TILE);
+    if (ntiles == 0) return B2M_OK;
+    rulebook_cost_kernel<<<(unsigned)cdiv64(ntiles, 256), 256, 0, st>>>(rb_cnt, K, ntiles);
+    rulebook_balance_kernel<<<1, 1024, 0, st>>>(rb_cnt, K, ntiles);
+    int ncls = coords_env("B2M_XCD_CLASSES", 8);
+    if (ncls < 1) ncls = 1;
+    if (ncls > ORDER_MAX_CLASSES) ncls = ORDER_MAX_CLASSES;
+    rulebook_order_kernel<<<8, 1024, 0, st>>>(rb_cnt, K, ntiles, coords_env("B2M_XCD_WINDOW", 768), ncls);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 // ------------------------------------------------------------------ tile rulebook
 // one wave per tile of B2M_TILE (= 64) output rows: lane = row; per offset one ballot compacts the valid
 // pairs in row order
@@ -335,7 +494,7 @@ extern "C" int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n
     rulebook_kernel<<<dim3((unsigned)ntiles, (unsigned)((K + 3) / 4)), 256, 0, st>>>(nbr, ld, K, n_out, ntiles, rb_in,
                                                                                    rb_out, rb_cnt, pair_total);
     B2M_LAUNCH_CHECK();
-    return B2M_OK;
+    return b2m_rulebook_balance(rb_cnt, K, n_out, stream);
 }
 
 // ------------------------------------------------------------------ stride-1 kernel map straight into the rulebook
@@ -410,7 +569,7 @@ extern "C" int b2m_kernel_map_rulebook(const int32_t* coords, int64_t n, int32_t
     if (occ) map_rulebook_kernel<true><<<grid, 256, 0, st>>>(coords, n, ksize, ts, keys, vals, cap - 1, occ, d, ntiles, rb_in, rb_out, rb_cnt);
     else map_rulebook_kernel<false><<<grid, 256, 0, st>>>(coords, n, ksize, ts, keys, vals, cap - 1, occ, d, ntiles, rb_in, rb_out, rb_cnt);
     B2M_LAUNCH_CHECK();
-    return B2M_OK;
+    return b2m_rulebook_balance(rb_cnt, ksize * ksize * ksize, n, stream);
 }
 
 // ------------------------------------------------------------------ Morton keys (spatial row order)

@@ -44,7 +44,8 @@ class Rulebook:
         ldr = self.ntiles * TILE
         self.rb_in = torch.empty(max(K * ldr, 1), dtype=torch.int32, device=dev)
         self.rb_out = torch.empty(max(K * ldr, 1), dtype=torch.uint8, device=dev)
-        self.rb_cnt = torch.empty(max(K * self.ntiles, 1), dtype=torch.int32, device=dev)
+        # K*ntiles pair counts + the tail b2m_rulebook_balance fills (XCD work boundaries, per-tile cost): b2m.h
+        self.rb_cnt = torch.empty(_lib.load().b2m_rulebook_cnt_size(K, n_out), dtype=torch.int32, device=dev)
         if nbr is not None:
             ld = nbr.shape[1] if nbr.dim() == 2 else n_out
             _lib.call('b2m_rulebook', nbr.data_ptr(), ld, K, n_out, self.rb_in.data_ptr(), self.rb_out.data_ptr(),

@@ -74,7 +74,7 @@ int b2m_kernel_map(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts,
                    int32_t* nbr, int64_t ld, void* stream);
 
 /* b2m_kernel_map followed by b2m_rulebook in one pass, without the K x n neighbour table: the tile rulebook
- * (rb_in int32[K*ntiles*64], rb_out uint8[same], rb_cnt int32[K*ntiles], ntiles = ceil(n/64)) of the stride-1
+ * (rb_in int32[K*ntiles*64], rb_out uint8[same], rb_cnt int32[b2m_rulebook_cnt_size], ntiles = ceil(n/64)) of the stride-1
  * kernel map of an odd cubic kernel.  Bit-identical to the two-step path. */
 int b2m_kernel_map_rulebook(const int32_t* coords, int64_t n, int32_t ksize, int32_t ts,
                             const uint64_t* keys, const int32_t* vals, int64_t cap,
@@ -98,7 +98,22 @@ int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int64_t n_fine
  *   rb_out[k*ldr + t*TILE + j]  output row - t*TILE      (0 beyond the count)
  *   rb_cnt[k*ntiles + t]       number of pairs
  *   pair_total[K]              pairs per offset (may be NULL)
- * ldr = ntiles*TILE, ntiles = ceil(n_out/TILE). */
+ * ldr = ntiles*TILE, ntiles = ceil(n_out/TILE).
+ * rb_cnt has b2m_rulebook_cnt_size(K, n_out) = K*ntiles + 16 + 2*ntiles entries: behind the counts comes the tail
+ * b2m_rulebook_balance writes (both builders call it themselves):
+ *   rb_cnt[K*ntiles + x], x = 0..8   first tile of the run of tiles XCD x works on (x = 8: ntiles).  The runs carry equal
+ *                                    WORK (3 per row group of 16 pairs + 1 per active offset, summed over a tile), not
+ *                                    equal tile counts, and none is longer than ceil(1.25 * ntiles / 8) tiles;
+ *   rb_cnt[K*ntiles + 16 + t]        that cost of tile t;
+ *   rb_cnt[K*ntiles + 16 + ntiles + j]  the tile worked on at position j: inside every run the last B2M_XCD_WINDOW
+ *                                    (768) positions are ordered by cost class, heaviest first (B2M_XCD_CLASSES = 8
+ *                                    classes of equal width below the largest cost of the window, row order inside
+ *                                    a class), the positions before keep the row order.  b2m_conv_fwd walks the tiles in
+ *                                    this order (B2M_XCD_ORDER=0: row order): a launch then ends on light tiles.
+ * b2m_conv_fwd / b2m_conv_wgrad read the nine boundaries of rulebooks with >= 64 tiles (B2M_XCD_BALANCE=0: equal tile
+ * counts, the tail is not read).  A caller that fills rb_in/rb_out/rb_cnt itself calls b2m_rulebook_balance once. */
+int64_t b2m_rulebook_cnt_size(int32_t K, int64_t n_out);
+int b2m_rulebook_balance(int32_t* rb_cnt, int32_t K, int64_t n_out, void* stream);
 int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out,
                  int32_t* rb_in, uint8_t* rb_out, int32_t* rb_cnt, int32_t* pair_total, void* stream);
 

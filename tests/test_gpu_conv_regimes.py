@@ -3,8 +3,8 @@ against an independent dense reference.
 
   1. forced regimes on the 12 k-row maps of test_gpu_ops: the un-split vector-store path that carries levels 0/1 in
      the benchmark (B2M_CONV_TARGET=0), the atomic split-K combine, no chunk slices, the plain weight-gradient
-     kernel, 64-tile chunks in the pipelined weight-gradient kernel (the 64-lane `live` walk incl. lane 63), and
-     the non-XCD workgroup order;
+     kernel, 64-tile chunks in the pipelined weight-gradient kernel (the 64-lane `live` walk incl. lane 63), the
+     non-XCD workgroup order and XCD runs of equal tile counts (the default: runs of equal work);
   2. whole layers at benchmark size -- one 150 k-voxel scene (k3 96->96, 128(96|32)->96, k5 6->32, 1x1 128->96)
      and the 1.2 M-row batch of BASELINE configs[1] (k3 96->96) -- forward, data gradient, weight gradient
      against oracle/sparse_ref.conv_nbr_explicit;
@@ -42,6 +42,7 @@ REGIMES = {
     'wgrad_plain': {'B2M_WGRAD_PIPE': '0'},
     'wgrad_64_tile_chunks': {'B2M_WGRAD_MIN_TILES': '64'},
     'no_xcd_order': {'B2M_XCD': '0'},
+    'xcd_equal_tile_counts': {'B2M_XCD_BALANCE': '0'},
     'unsplit_64bit': {'B2M_CONV_TARGET': '0', 'B2M_CONV_FAST32': '0', 'B2M_WGRAD_FAST32': '0'},
 }
 

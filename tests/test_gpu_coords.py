@@ -118,3 +118,103 @@ def test_full_size_scene_properties():
     for l in range(7):
         tot = m.rulebook_down(l).pairs
         assert tot == m.n(l)                                          # every fine voxel is exactly one pair
+
+
+def _expected_runs(cnt):
+    """XCD work boundaries as include/b2m.h states them (rb_cnt tail), restated with numpy."""
+    K, nt = cnt.shape
+    cost = np.where(cnt > 0, 3 * ((cnt + 15) // 16) + 1, 0).sum(0).astype(np.int64)
+    prefix = np.cumsum(cost)
+    total = int(prefix[-1]) if nt else 0
+    start = [nt * x // 8 for x in range(8)] + [nt]
+    if total > 0:
+        for x in range(1, 8):
+            target = (total * x + 7) // 8
+            start[x] = int(np.searchsorted(prefix, target, side='left')) + 1
+    cap = (nt * 5 + 31) // 32
+    for x in range(1, 8):
+        start[x] = min(max(start[x], start[x - 1]), start[x - 1] + cap)
+    for x in range(7, 0, -1):
+        start[x] = max(start[x], start[x + 1] - cap)
+    return cost, np.array(start), cap
+
+
+@pytest.mark.parametrize('case', ['scene', 'skewed', 'tiny', 'empty_half'])
+def test_xcd_runs_carry_equal_work(case):
+    """The tail of rb_cnt: per-tile cost and the nine run boundaries, exactly as stated; runs cover all tiles, none is
+    longer than the cap the launch grids are sized for; on a real scene the runs' work is level to one tile's cost."""
+    from box2mask_amd import synth
+    from box2mask_amd.sparse import CoordinateManager
+    rng = np.random.default_rng(3)
+    if case == 'scene':
+        coords = synth.make_batch(2, seed0=4, target_voxels=30000, pts_per_m2=8000.0)['vox_coords']
+    elif case == 'skewed':      # a dense block (27 neighbours everywhere) next to isolated voxels (1 active offset each)
+        g = np.stack(np.meshgrid(*[np.arange(36)] * 3, indexing='ij'), -1).reshape(-1, 3)
+        iso = np.stack(np.meshgrid(*[np.arange(40) * 3 + 200] * 3, indexing='ij'), -1).reshape(-1, 3)
+        xyz = np.concatenate([g, iso])
+        coords = torch.from_numpy(np.concatenate([np.zeros((len(xyz), 1), np.int64), xyz], 1)).int()
+    elif case == 'tiny':
+        xyz = rng.integers(0, 12, (300, 3))
+        xyz = np.unique(xyz, axis=0)
+        coords = torch.from_numpy(np.concatenate([np.zeros((len(xyz), 1), np.int64), xyz], 1)).int()
+    else:                       # isolated voxels only in the first half of the rows: costs 1,1,1,... then the block
+        iso = np.stack(np.meshgrid(*[np.arange(30) * 3] * 3, indexing='ij'), -1).reshape(-1, 3)
+        g = np.stack(np.meshgrid(*[np.arange(20)] * 3, indexing='ij'), -1).reshape(-1, 3) + 400
+        xyz = np.concatenate([iso, g])
+        coords = torch.from_numpy(np.concatenate([np.zeros((len(xyz), 1), np.int64), xyz], 1)).int()
+    m = CoordinateManager(coords, reorder=True)
+    for rb in (m.rulebook_same(0, 3), m.rulebook_down(0), m.rulebook_up(0), m.rulebook_same(1, 3)):
+        K, nt = rb.K, rb.ntiles
+        raw = rb.rb_cnt.cpu().numpy()
+        assert raw.shape[0] == K * nt + 16 + 2 * nt
+        cnt = raw[:K * nt].reshape(K, nt).astype(np.int64)
+        cost, start, cap = _expected_runs(cnt)
+        assert (raw[K * nt + 16:K * nt + 16 + nt] == cost).all()
+        order = raw[K * nt + 16 + nt:]
+        assert (np.sort(order) == np.arange(nt)).all()          # a permutation of the tiles
+        got = raw[K * nt:K * nt + 9]
+        assert (got == start).all(), (case, got, start)
+        assert got[0] == 0 and got[8] == nt and (np.diff(got) >= 0).all() and (np.diff(got) <= cap).all()
+        for x in range(8):                                      # every run: row order, then the window heavy -> light
+            s0, s1 = int(got[x]), int(got[x + 1])
+            w0 = max(s0, s1 - 768)
+            assert (order[s0:w0] == np.arange(s0, w0)).all()
+            win = order[w0:s1]
+            assert (np.sort(win) == np.arange(w0, s1)).all()
+            if len(win):
+                cmax = int(cost[w0:s1].max())
+                cls = 7 - cost[win] * 8 // (cmax + 1)
+                assert (np.diff(cls) >= 0).all()                                    # heaviest class first
+                assert all((np.diff(win[cls == c]) > 0).all() for c in range(8))      # row order inside a class
+        if case == 'scene' and nt >= 64:
+            work = np.array([cost[got[x]:got[x + 1]].sum() for x in range(8)])
+            assert work.max() - work.min() <= 2 * cost.max(), work
+        if case == 'skewed' and rb.K == 27 and rb is m.rulebook_same(0, 3):
+            assert (np.diff(got) == cap).any()          # the clamp is reached (and the convolution still covers every tile)
+
+
+def test_conv_on_skewed_runs_matches_equal_counts(monkeypatch):
+    """Runs at the clamp (dense block + isolated voxels): forward and weight gradient agree with the equal-count order."""
+    from box2mask_amd import functional as F_
+    from box2mask_amd.sparse import CoordinateManager
+    g = np.stack(np.meshgrid(*[np.arange(36)] * 3, indexing='ij'), -1).reshape(-1, 3)
+    iso = np.stack(np.meshgrid(*[np.arange(40) * 3 + 200] * 3, indexing='ij'), -1).reshape(-1, 3)
+    xyz = np.concatenate([g, iso])
+    coords = torch.from_numpy(np.concatenate([np.zeros((len(xyz), 1), np.int64), xyz], 1)).int()
+    m = CoordinateManager(coords, reorder=True)
+    rb = m.rulebook_same(0, 3)
+    n = rb.n_out
+    torch.manual_seed(1)
+    x = torch.randn(n, 96, device='cuda'); w = torch.randn(27, 96, 96, device='cuda') * 0.05; dy = torch.randn(n, 96, device='cuda')
+
+    def run():
+        y = F_.conv_raw(x, None, F_.weight_pack(w), 27, None, rb, n, 96)
+        dw = torch.zeros_like(w)
+        F_.wgrad_raw(x, dy, rb, 27, dw, 0)
+        torch.cuda.synchronize()
+        return y, dw
+    y1, dw1 = run()
+    monkeypatch.setenv('B2M_XCD_BALANCE', '0')
+    y0, dw0 = run()
+    assert torch.equal(y1, y0)                           # the same wave code per tile: the same bits
+    assert float((dw1 - dw0).abs().max()) / float(dw0.abs().max()) < 1e-5
