@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 }
 
 #include "conv_fwd_flow.h"
+#include "conv_1x1.h"
 
 static int env_flag(const char* name, int dflt);
 static inline int conv_kc(int cin) { return cin >= 16 ? 16 : 8; }
@@ -642,6 +643,17 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     a.xcd_per = xo.chunk;
     const unsigned grid = xo.grid;
     const bool ident = rb_in == nullptr;
+    // 1x1 layers with whole 16-channel chunks: the streaming-GEMM kernel (conv_1x1.h), accumulators in registers
+    if (ident && fast && KC == 16 && a.fast32 && n_in >= n_out && env_flag("B2M_CONV_1X1", 1)) {
+        const int spw = a.nstrips % 3 == 0 ? 3 : a.nstrips % 2 == 0 ? 2 : 1;
+        const int64_t g1 = a.ntiles * (a.nstrips / spw);
+        B2M_CHECK_ARG(g1 < (1ll << 31), "too many workgroups");
+        if (spw == 3) conv_1x1_kernel<3><<<(unsigned)g1, 64, 0, st>>>(a);
+        else if (spw == 2) conv_1x1_kernel<2><<<(unsigned)g1, 64, 0, st>>>(a);
+        else conv_1x1_kernel<1><<<(unsigned)g1, 64, 0, st>>>(a);
+        B2M_LAUNCH_CHECK();
+        return B2M_OK;
+    }
     // Real rulebook, whole 16-channel chunks, 32-bit addressable: the flat-pipeline kernel (conv_fwd_flow.h), D steps
     // deep (B2M_CONV_PIPE = depth, 0 = off) -- un-split maps with one wave per workgroup, split maps with the four
     // waves of a workgroup as four slices that combine in LDS.

@@ -75,6 +75,21 @@ def test_conv_forced_regime(maps, monkeypatch, regime, kind, level, cins, cout, 
     _conv_case(maps, kind, level, cins, cout, bias)
 
 
+def _one_by_one_cases():
+    from test_gpu_ops import CONV_CASES
+    return [c for c in CONV_CASES if c[0] == '1x1']
+
+
+@pytest.mark.parametrize('kind,level,cins,cout,bias', _one_by_one_cases())
+def test_conv_1x1_through_the_general_kernel(maps, monkeypatch, kind, level, cins, cout, bias):
+    """1x1 layers with whole 16-channel chunks take the streaming-GEMM kernel (conv_1x1.h) by default (test_gpu_ops);
+    B2M_CONV_1X1=0 sends them through the identity-rulebook variant of the general kernel, which still carries the
+    layers with fewer than 16 input channels per chunk."""
+    from test_gpu_ops import _conv_case
+    monkeypatch.setenv('B2M_CONV_1X1', '0')
+    _conv_case(maps, kind, level, cins, cout, bias)
+
+
 # ------------------------------------------------------------------ 2. benchmark-size layers
 @pytest.fixture(scope='module')
 def scene150k():
