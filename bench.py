@@ -307,7 +307,7 @@ def main():
     fwd = agg.get('b2m_conv_fwd', dict(ms=0.0, flops=0.0, launches=0))
     wg = agg.get('b2m_conv_wgrad', dict(ms=0.0, flops=0.0, launches=0))
     roofline = roof(fwd, 'conv_fwd_kernel')
-    roofline['kernel'] = 'b2m_conv_fwd: conv_fwd_flow_kernel (+ conv_fwd_kernel for 1x1 / 6-channel layers), forward + data gradient'
+    roofline['kernel'] = 'b2m_conv_fwd: conv_fwd_flow_kernel (+ conv_1x1_kernel for 1x1 layers, conv_fwd_kernel for the 6-channel stem and the heads), forward + data gradient'
     # the heaviest layer shapes of the dominant kernel, each with its own fraction (same isolated-kernel pass)
     shp = {}
     for name, s_, e_, meta in timer.records:

@@ -40,6 +40,9 @@ void b2m_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// rulebooks with at least this many tiles carry XCD work boundaries and a dispatch order (b2m_rulebook_balance), and the
+// convolutions use them
+#define B2M_BALANCE_MIN_TILES 64
 
 __device__ __forceinline__ uint64_t b2m_pack(int b, int x, int y, int z) {
     return ((uint64_t)(uint32_t)b << 48) | ((uint64_t)(uint32_t)x << 32) | ((uint64_t)(uint32_t)y << 16) |

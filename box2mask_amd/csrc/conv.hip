@@ -676,7 +676,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
             XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
             a.xcd_per = fo.chunk;
             // XCD runs of equal work (the tail of rb_cnt, b2m_rulebook_balance) instead of equal tile counts
-            if (a.ntiles >= 64 && xcd_tiles > 0 && (a.nstrips * nslice) % wpb == 0 && env_flag("B2M_XCD_BALANCE", 1)) {
+            if (a.ntiles >= B2M_BALANCE_MIN_TILES && xcd_tiles > 0 && (a.nstrips * nslice) % wpb == 0 && env_flag("B2M_XCD_BALANCE", 1)) {
                 a.xcd_start = rb_cnt + (int64_t)K * a.ntiles;
                 a.tile_order = env_flag("B2M_XCD_ORDER", 1) ? a.xcd_start + 16 + a.ntiles : nullptr;
                 a.wg_per_tile = a.nstrips * nslice / wpb;
@@ -1157,7 +1157,7 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     dim3 grid(xo.grid);
     // XCD runs of equal work (the tail of rb_cnt, b2m_rulebook_balance), each cut into tile chunks from its own start
     a.xcd_start = nullptr;
-    if (rb_cnt && !workspace && a.ntiles >= 64 && env_flag("B2M_XCD", 1) && env_flag("B2M_XCD_BALANCE", 1)) {
+    if (rb_cnt && !workspace && a.ntiles >= B2M_BALANCE_MIN_TILES && env_flag("B2M_XCD", 1) && env_flag("B2M_XCD_BALANCE", 1)) {
         a.xcd_start = rb_cnt + (int64_t)K * a.ntiles;
         grid = dim3((unsigned)(8 * K * a.nz * cdiv64(B2M_XCD_CAP(a.ntiles), tpc)));
     }

@@ -318,11 +318,8 @@ __global__ __launch_bounds__(256) void rulebook_cost_kernel(int32_t* __restrict_
     }
     rb_cnt[(int64_t)K * ntiles + 16 + t] = cost;
 }
-__global__ __launch_bounds__(1024) void rulebook_balance_kernel(int32_t* __restrict__ rb_cnt, int32_t K, int64_t ntiles) {
-    __shared__ long long part[1024];
-    __shared__ int start[9];
-    const int32_t* cost = rb_cnt + (int64_t)K * ntiles + 16;
-    int32_t* out = rb_cnt + (int64_t)K * ntiles;
+// (every block of rulebook_order_kernel runs this redundantly: no second launch, no grid-wide barrier)
+__device__ __forceinline__ void rulebook_runs(const int32_t* __restrict__ cost, int64_t ntiles, long long* part, int* start) {
     const int tid = threadIdx.x;
     const int64_t per = (ntiles + 1023) / 1024;
     const int64_t lo = tid * per < ntiles ? tid * per : ntiles;
@@ -361,9 +358,8 @@ __global__ __launch_bounds__(1024) void rulebook_balance_kernel(int32_t* __restr
         }
         for (int x = 7; x >= 1; --x)
             if (start[x] < start[x + 1] - cap) start[x] = start[x + 1] - cap;
-        for (int x = 0; x < 9; ++x) out[x] = start[x];
-        for (int x = 9; x < 16; ++x) out[x] = 0;
     }
+    __syncthreads();
 }
 // Dispatch order of the tiles inside each XCD run: [K*ntiles + 16 + ntiles + j] = tile worked on at position j.  A
 // conv_fwd_flow wave owns a tile for all of its offsets, and tiles differ 10x in cost (interior tiles: 27 offsets x 4 row
@@ -376,12 +372,16 @@ __global__ __launch_bounds__(1024) void rulebook_balance_kernel(int32_t* __restr
 __global__ __launch_bounds__(1024) void rulebook_order_kernel(int32_t* __restrict__ rb_cnt, int32_t K, int64_t ntiles,
                                                               int window, int ncls) {
     __shared__ int cnts[ORDER_MAX_CLASSES][1024];
+    __shared__ long long part[1024];
     __shared__ int red[1024];
     __shared__ int base[ORDER_MAX_CLASSES + 1];
-    const int32_t* start = rb_cnt + (int64_t)K * ntiles;
-    const int32_t* cost = start + 16;
+    __shared__ int start[9];
+    int32_t* out = rb_cnt + (int64_t)K * ntiles;
+    const int32_t* cost = out + 16;
     int32_t* order = rb_cnt + (int64_t)K * ntiles + 16 + ntiles;
     const int tid = threadIdx.x;
+    rulebook_runs(cost, ntiles, part, start);
+    if (blockIdx.x == 0 && tid < 16) out[tid] = tid < 9 ? start[tid] : 0;
     const int s0 = start[blockIdx.x], s1 = start[blockIdx.x + 1];
     const int w0 = (window <= 0 || s1 - window < s0) ? s0 : s1 - window;
     for (int t = s0 + tid; t < w0; t += 1024) order[t] = t;
@@ -446,9 +446,8 @@ extern "C" int b2m_rulebook_balance(int32_t* rb_cnt, int32_t K, int64_t n_out, v
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(rb_cnt && K >= 1, "bad arguments");
     const int64_t ntiles = cdiv64(n_out, B2M_TILE);
-    if (ntiles == 0) return B2M_OK;
+    if (ntiles < B2M_BALANCE_MIN_TILES) return B2M_OK;     // (the convolutions use the tail from that many tiles on)
     rulebook_cost_kernel<<<(unsigned)cdiv64(ntiles, 256), 256, 0, st>>>(rb_cnt, K, ntiles);
-    rulebook_balance_kernel<<<1, 1024, 0, st>>>(rb_cnt, K, ntiles);
     int ncls = coords_env("B2M_XCD_CLASSES", 8);
     if (ncls < 1) ncls = 1;
     if (ncls > ORDER_MAX_CLASSES) ncls = ORDER_MAX_CLASSES;

@@ -110,8 +110,9 @@ int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int64_t n_fine
  *                                    classes of equal width below the largest cost of the window, row order inside
  *                                    a class), the positions before keep the row order.  b2m_conv_fwd walks the tiles in
  *                                    this order (B2M_XCD_ORDER=0: row order): a launch then ends on light tiles.
- * b2m_conv_fwd / b2m_conv_wgrad read the nine boundaries of rulebooks with >= 64 tiles (B2M_XCD_BALANCE=0: equal tile
- * counts, the tail is not read).  A caller that fills rb_in/rb_out/rb_cnt itself calls b2m_rulebook_balance once. */
+ * The tail is written for rulebooks with >= 64 tiles, and b2m_conv_fwd / b2m_conv_wgrad read it from that size on
+ * (B2M_XCD_BALANCE=0: equal tile counts, the tail is not read).  A caller that fills rb_in/rb_out/rb_cnt itself calls
+ * b2m_rulebook_balance once (two launches: the costs, then boundaries + order by eight workgroups). */
 int64_t b2m_rulebook_cnt_size(int32_t K, int64_t n_out);
 int b2m_rulebook_balance(int32_t* rb_cnt, int32_t K, int64_t n_out, void* stream);
 int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out,

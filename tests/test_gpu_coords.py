@@ -53,7 +53,10 @@ def _check(coords, levels=4, k0=5):
         a, b = m.rulebook_same(l, ks), m2.rulebook_same(l, ks)
         assert b.nbr is None
         for f in ('rb_in', 'rb_out', 'rb_cnt'):
-            assert torch.equal(getattr(a, f), getattr(b, f)), (l, ks, f)
+            x, y = getattr(a, f), getattr(b, f)
+            if f == 'rb_cnt' and a.ntiles < 64:          # (the tail behind the counts is written from 64 tiles on)
+                x, y = x[:a.K * a.ntiles], y[:a.K * a.ntiles]
+            assert torch.equal(x, y), (l, ks, f)
     return m, h
 
 
@@ -167,6 +170,8 @@ def test_xcd_runs_carry_equal_work(case):
         K, nt = rb.K, rb.ntiles
         raw = rb.rb_cnt.cpu().numpy()
         assert raw.shape[0] == K * nt + 16 + 2 * nt
+        if nt < 64:                 # small rulebooks: the convolutions take equal tile counts, the tail stays unwritten
+            continue
         cnt = raw[:K * nt].reshape(K, nt).astype(np.int64)
         cost, start, cap = _expected_runs(cnt)
         assert (raw[K * nt + 16:K * nt + 16 + nt] == cost).all()

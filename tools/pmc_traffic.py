@@ -17,7 +17,7 @@ def load(path):
         base = r['Kernel_Name'].replace('void ', '').split('<')[0].split('(')[0]
         if base.startswith('conv_wgrad'):
             base = 'conv_wgrad_kernel'          # plain + flat-pipeline variants: one b2m_conv_wgrad entry
-        if base.startswith('conv_fwd'):
+        if base.startswith('conv_fwd') or base.startswith('conv_1x1'):
             base = 'conv_fwd_kernel'            # likewise for b2m_conv_fwd
         by[base][0] += float(r['Counter_Value']); by[base][1] += 1
     return by

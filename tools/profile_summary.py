@@ -25,7 +25,7 @@ def main():
         base = re.split(r'[<(]', name)[0]
         if base.startswith('conv_wgrad'):
             base = 'conv_wgrad_kernel'          # plain + flat-pipeline variants: one b2m_conv_wgrad entry
-        if base.startswith('conv_fwd'):
+        if base.startswith('conv_fwd') or base.startswith('conv_1x1'):
             base = 'conv_fwd_kernel'            # likewise for b2m_conv_fwd
         if base.startswith('at::') or base.startswith('__amd') or 'Cijk' in base:
             base = 'torch / runtime kernels'
