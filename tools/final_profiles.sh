@@ -2,7 +2,7 @@
 # All profile artefacts of a round in one go (run on the GPU box from the repository root):
 #   tools/final_profiles.sh <outdir>
 # 1. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` (the driver's command) -> kernel_stats.csv, summary.md
-# 2. the same with B2M_WGRAD_STREAM=0 (one stream: a kernel's duration is its own)            -> *_one_stream.*
+# 2. the same with B2M_WGRAD_STREAM=0 B2M_BENCH_PREFETCH=0 (one stream: a kernel's duration is its own) -> *_one_stream.*
 # 3. two PMC passes (FETCH_SIZE / WRITE_SIZE, kernel-trace only) of one bench step, one stream  -> traffic.json
 # 4. PMC passes of the conv micro-benchmark (tools/pmc_passes.sh)                               -> pmc/summary.txt
 out=${1:-gpurun_out/final}
@@ -20,9 +20,9 @@ stats() {   # $1 = tag, rest = env assignments
   echo "== $tag"; head -12 $out/summary_$tag.md
 }
 stats default
-stats one_stream B2M_WGRAD_STREAM=0
+stats one_stream B2M_WGRAD_STREAM=0 B2M_BENCH_PREFETCH=0
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && export B2M_WGRAD_STREAM=0 && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/$out/pmc_$c -- \
+  (cd /tmp && export B2M_WGRAD_STREAM=0 B2M_BENCH_PREFETCH=0 && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/$out/pmc_$c -- \
      python3 $root/bench.py --steps 1 --warmup 1 --cpu-baseline 0 --votes 0 --prepare 0 > $root/$out/pmc_$c.log 2>&1)
 done
 python3 tools/pmc_traffic.py $(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
