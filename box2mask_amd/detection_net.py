@@ -121,9 +121,15 @@ class SelectionNet(ResNetBase):
 
     # conv -> BN -> ReLU with the BN+ReLU epilogue fused into one launch
     @staticmethod
-    def _cbr(conv, bn, x):
-        out = conv(x)
-        return out.new(bn.apply_bn(out.F, relu=True, count_key=ME.count_key_of(out), defer_counter=True))
+    def _cbr(conv, bn, x, skip=False):
+        """conv -> BN -> ReLU.  skip: x has a second consumer later in the network (the decoder's ME.cat); returns
+        (result, x') with x' the alias that consumer must take (ME.MinkowskiConvolution.forward(passthrough=True))."""
+        if skip:
+            out, x = conv(x, passthrough=True)
+        else:
+            out = conv(x)
+        out = out.new(bn.apply_bn(out.F, relu=True, count_key=ME.count_key_of(out), defer_counter=True))
+        return (out, x) if skip else out
 
     def forward(self, x, pooling_ids=None, n_segments=None):
         """x: SparseTensor at tensor stride 1 -> dict head-name -> tensor holder with `.F`
@@ -147,13 +153,23 @@ class SelectionNet(ResNetBase):
         if mgr is not None:
             mgr.prefetch(8, same=[(0, 5)] + [(l, 3) for l in range(8)], strided=True)
         out_p1 = T('out_p1', cbr(self.conv0p1s1, self.bn0, x))
-        out_b1p2 = T('block1', self.block1(T('down1', cbr(self.conv1p1s2, self.bn1, out_p1))))
-        out_b2p4 = T('block2', self.block2(T('down2', cbr(self.conv2p2s2, self.bn2, out_b1p2))))
-        out_b3p8 = T('block3', self.block3(T('down3', cbr(self.conv3p4s2, self.bn3, out_b2p4))))
-        out_b4p16 = T('block4', self.block4(T('down4', cbr(self.conv4p8s2, self.bn4, out_b3p8))))
-        out_added_b1p32 = T('added_block1', self.added_block1(T('down5', cbr(self.added_conv1p16s2, self.added_bn1, out_b4p16))))
-        out_added_b2p64 = T('added_block2', self.added_block2(T('down6', cbr(self.added_conv2p32s2, self.added_bn2, out_added_b1p32))))
-        out = T('added_block3', self.added_block3(T('down7', cbr(self.added_conv3p64s2, self.added_bn3, out_added_b2p64))))
+        # every encoder output feeds the next strided convolution AND the decoder's ME.cat: the decoder takes the alias the
+        # strided convolution hands back (skip=True), so the two gradients are summed inside that convolution's
+        # data-gradient kernel
+        down, out_p1 = cbr(self.conv1p1s2, self.bn1, out_p1, skip=True)
+        out_b1p2 = T('block1', self.block1(T('down1', down)))
+        down, out_b1p2 = cbr(self.conv2p2s2, self.bn2, out_b1p2, skip=True)
+        out_b2p4 = T('block2', self.block2(T('down2', down)))
+        down, out_b2p4 = cbr(self.conv3p4s2, self.bn3, out_b2p4, skip=True)
+        out_b3p8 = T('block3', self.block3(T('down3', down)))
+        down, out_b3p8 = cbr(self.conv4p8s2, self.bn4, out_b3p8, skip=True)
+        out_b4p16 = T('block4', self.block4(T('down4', down)))
+        down, out_b4p16 = cbr(self.added_conv1p16s2, self.added_bn1, out_b4p16, skip=True)
+        out_added_b1p32 = T('added_block1', self.added_block1(T('down5', down)))
+        down, out_added_b1p32 = cbr(self.added_conv2p32s2, self.added_bn2, out_added_b1p32, skip=True)
+        out_added_b2p64 = T('added_block2', self.added_block2(T('down6', down)))
+        down, out_added_b2p64 = cbr(self.added_conv3p64s2, self.added_bn3, out_added_b2p64, skip=True)
+        out = T('added_block3', self.added_block3(T('down7', down)))
 
         out = T('added_block4', self.added_block4(ME.cat(T('up6', cbr(self.added_convtr4p128s2, self.added_bntr4, out)), out_added_b2p64)))
         out = T('added_block5', self.added_block5(ME.cat(T('up5', cbr(self.added_convtr5p64s2, self.added_bntr5, out)), out_added_b1p32)))

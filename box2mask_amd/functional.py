@@ -235,7 +235,8 @@ class _SparseConv(torch.autograd.Function):
     for the data gradient (same rulebook for stride-1 kernels, whose offsets mirror)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, tile_stats=None):
+    def forward(ctx, x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, tile_stats=None, passthrough=False):
+        in1, in2 = x1, x2
         x1 = _f32c(x1)
         x2 = _f32c(x2) if x2 is not None else None
         c1 = x1.shape[1]
@@ -252,11 +253,20 @@ class _SparseConv(torch.autograd.Function):
         y = conv_raw(x1, x2, wp, K, bias, rb_f, n_out, cout, tile_stats=tile_stats)
         ctx.save_for_backward(x1, x2, weight, bias)
         ctx.rb_f, ctx.rb_b, ctx.mirror, ctx.c1 = rb_f, rb_b, mirror, c1
+        if passthrough:
+            # The inputs come back as second / third outputs: whoever else consumes them (the residual branch of a
+            # BasicBlock, its 1x1 shortcut) takes THESE, so their gradients arrive here, in one call with dy, and the data
+            # gradient is accumulated onto them by the kernel (accumulate = 1) instead of by an add kernel of autograd's
+            # (59 adds per step, the level-0 ones 0.25 ms each).  Absent gradients stay None (no zero tensors).
+            ctx.set_materialize_grads(False)
+            return (y, in1) if in2 is None else (y, in1, in2)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, p1=None, p2=None):
         x1, x2, weight, bias = ctx.saved_tensors
+        if dy is None:                         # only the passed-through inputs were used downstream
+            return p1, p2, None, None, None, None, None, None, None, None
         dy = _f32c(dy)
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         w3 = _f32c(w3)
@@ -265,10 +275,16 @@ class _SparseConv(torch.autograd.Function):
         dx1 = dx2 = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = packed_weights.get(weight, True, ctx.mirror, 0, c1)
-            dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1)
+            acc = _accumulation_target(p1, x1.shape[0], c1)
+            dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1, out=acc, accumulate=acc is not None)
+            if p1 is not None and acc is None:
+                dx1 = dx1 + p1
         if x2 is not None and ctx.needs_input_grad[1]:
             wt = packed_weights.get(weight, True, ctx.mirror, c1, x2.shape[1])
-            dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1])
+            acc = _accumulation_target(p2, x2.shape[0], x2.shape[1])
+            dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1], out=acc, accumulate=acc is not None)
+            if p2 is not None and acc is None:
+                dx2 = dx2 + p2
         if ctx.needs_input_grad[2]:
             # the weight's slot in the model's gradient arena (zeroed once per pass, adopted by autograd as .grad), else a
             # zero-filled tensor of the weight's own shape
@@ -299,7 +315,16 @@ class _SparseConv(torch.autograd.Function):
                 torch.sum(dy, 0, keepdim=True, out=db)
             else:
                 db = dy.sum(0, keepdim=True).reshape(bias.shape)
-        return dx1, dx2, dw, db, None, None, None, None, None
+        return dx1, dx2, dw, db, None, None, None, None, None, None
+
+
+def _accumulation_target(g, n: int, c: int):
+    """The gradient of a passed-through input, if the data gradient may be added onto it in place: a dense fp32 (n, c)
+    tensor that owns its memory (what BatchNorm's residual gradient, a convolution's data gradient or autograd's own sum
+    of several gradients are)."""
+    if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n, c) or not g.is_contiguous() or g._base is not None:
+        return None
+    return g
 
 
 def conv_tile_stats() -> bool:
@@ -308,16 +333,30 @@ def conv_tile_stats() -> bool:
     return os.environ.get('B2M_CONV_STATS', '1') == '1'
 
 
-def sparse_conv(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, collect_stats=False):
+def conv_passthrough() -> bool:
+    """B2M_CONV_PASSTHROUGH=0: residual / shortcut branches take the block input itself and autograd adds the two
+    gradients of that input with a kernel of its own."""
+    return os.environ.get('B2M_CONV_PASSTHROUGH', '1') == '1'
+
+
+def sparse_conv(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, collect_stats=False, passthrough=False):
     """collect_stats: the caller will batch-normalise the result in training mode; the per-tile column sums then ride
-    along on the returned tensor (attribute `_b2m_tile_stats`, read by batch_norm) when the kernel can provide them."""
-    if collect_stats and conv_tile_stats():
-        holder = []
-        y = _SparseConv.apply(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, holder)
-        if holder:
-            y._b2m_tile_stats = holder[0]
+    along on the returned tensor (attribute `_b2m_tile_stats`, read by batch_norm) when the kernel can provide them.
+    passthrough: returns (y, x1, x2) -- x1 / x2 as aliases of the inputs for every OTHER consumer of them, whose gradients
+    the data gradient of this convolution is then accumulated onto (see _SparseConv.forward); the inputs themselves when
+    no gradient is being recorded."""
+    holder = [] if (collect_stats and conv_tile_stats()) else None
+    alias = bool(passthrough) and torch.is_grad_enabled() and conv_passthrough() and \
+        (x1.requires_grad or (x2 is not None and x2.requires_grad))
+    out = _SparseConv.apply(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, holder, alias)
+    y = out[0] if alias else out
+    if holder:
+        y._b2m_tile_stats = holder[0]
+    if not passthrough:
         return y
-    return _SparseConv.apply(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out)
+    if not alias:
+        return y, x1, x2
+    return (y, out[1], out[2] if x2 is not None else None)
 
 
 # ----------------------------------------------------------------------------- batch norm
@@ -417,7 +456,8 @@ class _BatchNorm(torch.autograd.Function):
             # eval-mode BN is an affine map: dx = scale * g (mean holds `scale` here)
             g = dy if not relu else dy * (y > 0)
             dx = g * mean.reshape(1, -1)
-            return dx, None, None, None, None, None, None, None, (g if dres is not None else None), None, None, None, None
+            gres = None if dres is None else (g.clone() if g is dy else g)       # (never the incoming tensor itself)
+            return dx, None, None, None, None, None, None, None, gres, None, None, None, None
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned

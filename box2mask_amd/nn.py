@@ -44,6 +44,15 @@ def _sources(x: SparseTensor):
     return x.F, None
 
 
+def _like(x: SparseTensor, f1, f2=None) -> SparseTensor:
+    """x with its feature matrix (or its two lazily concatenated parts) replaced."""
+    if isinstance(x, CatTensor):
+        y = CatTensor.__new__(CatTensor)
+        y.manager, y.level, y.parts, y._F = x.manager, x.level, (f1, f2), None
+        return y
+    return x.new(f1)
+
+
 class _ConvBase(nn.Module):
     transposed = False
 
@@ -77,24 +86,33 @@ class _ConvBase(nn.Module):
 class MinkowskiConvolution(_ConvBase):
     """[ME-mem] stride 1 (odd kernel, centred) or kernel 2 / stride 2."""
 
-    def forward(self, x: SparseTensor) -> SparseTensor:
+    def forward(self, x: SparseTensor, passthrough: bool = False):
+        """passthrough: returns (y, x') with x' an alias of x for every other consumer of x (a block's residual /
+        shortcut branch): this layer's data gradient is then accumulated onto their gradient by the kernel instead of
+        by an add of autograd's (functional._SparseConv)."""
         m, l = x.manager, x.level
         x1, x2 = _sources(x)
+
+        def result(out, level=None):
+            if not passthrough:
+                return x.new(out, level=level)
+            y, a1, a2 = out
+            return x.new(y, level=level), _like(x, a1, a2)
         if self.kernel_volume == 1:
             assert self.stride == 1
-            y = F_.sparse_conv(x1, x2, self.kernel, self.bias, None, None, False, x1.shape[0])
-            return x.new(y)
+            return result(F_.sparse_conv(x1, x2, self.kernel, self.bias, None, None, False, x1.shape[0],
+                                         passthrough=passthrough))
         # every trunk convolution feeds a BatchNorm (resnet.py:61-66, detection_net.py:37-135): in training mode its
         # kernel also leaves the column sums the normalisation needs
         stats = self.training and self.bias is None
         if self.stride == 1:
             rb = m.rulebook_same(l, self.kernel_size)
-            y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb, rb, True, rb.n_out, collect_stats=stats)
-            return x.new(y)
+            return result(F_.sparse_conv(x1, x2, self.kernel, self.bias, rb, rb, True, rb.n_out, collect_stats=stats,
+                                         passthrough=passthrough))
         assert self.stride == 2 and self.kernel_size == 2, 'only k2s2 strided convolutions are on the path'
         rb_f, rb_b = m.rulebook_down(l), m.rulebook_up(l)
-        y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out, collect_stats=stats)
-        return x.new(y, level=l + 1)
+        return result(F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out, collect_stats=stats,
+                                     passthrough=passthrough), level=l + 1)
 
 
 class MinkowskiConvolutionTranspose(_ConvBase):

@@ -28,7 +28,9 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.conv1(x)
+        # (x from here on: the alias conv1 hands back -- the residual / shortcut gradient is then summed with conv1's data
+        # gradient inside the convolution kernel, not by an add kernel per block)
+        out, x = self.conv1(x, passthrough=True)
         ck = ME.count_key_of(out)
         out = out.new(self.norm1.apply_bn(out.F, relu=True, count_key=ck, defer_counter=True))
         out = self.conv2(out)

@@ -104,3 +104,32 @@ def test_prefetched_batch_gives_the_same_bits(monkeypatch):
     assert model._prefetched[0] == model._batch_key(host)
     losses = model.compute_loss(host, 150)
     assert float(losses['optimization_loss']) == l0
+
+
+def test_passthrough_inputs_give_the_same_gradients(monkeypatch):
+    """Block inputs and encoder outputs have two consumers.  By default the second consumer takes the alias the first
+    one (a convolution) hands back and that convolution's data-gradient kernel adds onto the other gradient in place;
+    B2M_CONV_PASSTHROUGH=0 leaves the sum to an add kernel of autograd's.  Same loss bits, gradients equal to rounding
+    (the order of one addition per element differs)."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    batch = synth.make_batch(3, seed0=41, target_voxels=12000, pts_per_m2=8000.0)
+
+    def run():
+        torch.manual_seed(7)
+        model = Model(scannet_config(), *synth.scannet_tables())
+        model.train()
+        losses = model.compute_loss(batch, 150)
+        losses['optimization_loss'].backward()
+        torch.cuda.synchronize()
+        return float(losses['optimization_loss']), {
+            n: p.grad.detach().clone() for n, p in model.detection_model.named_parameters() if p.grad is not None}
+    l1, g1 = run()
+    monkeypatch.setenv('B2M_CONV_PASSTHROUGH', '0')
+    l0, g0 = run()
+    assert l1 == l0
+    assert g1.keys() == g0.keys() and len(g1) > 250
+    worst = max(float((g1[n] - g0[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-12) for n in g0)
+    assert worst < 2e-4, worst
