@@ -1133,15 +1133,19 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     const int MI = pick_blk(cin), NJ = pick_blk(cout);
     a.nmb = (cin + 16 * MI - 1) / (16 * MI);
     a.nnb = (cout + 16 * NJ - 1) / (16 * NJ);
-    // chunking: enough waves to fill the chip (~16k), but a wave should own at least 4 tiles: every wave ends with
-    // 16*MI x 16*NJ atomics into dW, and on the small deep-level maps those outweighed the MFMA work (A/B per layer:
-    // +30..50 % there with the floor; the large maps are above it anyway)
+    // chunking: enough waves to fill the chip several times over, but a wave should own at least 4 tiles: every wave
+    // ends with 16*MI x 16*NJ atomics into dW, and on the small deep-level maps those outweighed the MFMA work (A/B per
+    // layer: +30..50 % there with the floor).  Large maps (>= 2048 tiles: levels 0 and 1 of the benchmark) are cut twice
+    // as fine, into chunks of at most 32 tiles: a wave's life is its chunk's pairs of one offset, and with 64-tile chunks
+    // the launch ended on a long tail of them (level-0 96->96: 96 -> 100 TFLOP/s, level-1: 85 -> 91, 64->64: 69 -> 76;
+    // the same cut on the 1 k-tile level-2 maps LOSES 20 %: there the atomics of twice as many waves weigh more).
     const int64_t blocks_per_chunk = (int64_t)K * a.nmb * a.nnb;
-    int64_t want_chunks = cdiv64(16384, blocks_per_chunk);
+    const bool large = a.ntiles >= 2048;
+    int64_t want_chunks = cdiv64(env_flag("B2M_WGRAD_TARGET", large ? 32768 : 16384), blocks_per_chunk);
     if (want_chunks < 1) want_chunks = 1;
     int64_t tpc = cdiv64(a.ntiles, want_chunks);
     if (tpc < env_flag("B2M_WGRAD_MIN_TILES", 4)) tpc = env_flag("B2M_WGRAD_MIN_TILES", 4);
-    if (tpc > 64) tpc = 64;
+    { int mx = env_flag("B2M_WGRAD_MAX_TILES", large ? 32 : 64); if (mx < 1) mx = 1; if (mx > 64) mx = 64; if (tpc > mx) tpc = mx; }
     // Deterministic mode (workspace given): at most B2M_WGRAD_DET_CHUNKS tile chunks, every chunk stores its partial
     // blocks plainly and a second kernel adds them up in chunk order -- no atomics, the same bits on every run.
     a.partial = workspace;
