@@ -645,7 +645,8 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     const bool ident = rb_in == nullptr;
     // 1x1 layers with whole 16-channel chunks: the streaming-GEMM kernel (conv_1x1.h), accumulators in registers
     if (ident && fast && KC == 16 && a.fast32 && n_in >= n_out && env_flag("B2M_CONV_1X1", 1)) {
-        const int spw = a.nstrips % 3 == 0 ? 3 : a.nstrips % 2 == 0 ? 2 : 1;
+        int spw = a.nstrips % 3 == 0 ? 3 : a.nstrips % 2 == 0 ? 2 : 1;
+        if (a.ntiles * (a.nstrips / spw) < 2048) spw = 1;       // few rows (the heads on segments): one wave per strip
         const int64_t g1 = a.ntiles * (a.nstrips / spw);
         B2M_CHECK_ARG(g1 < (1ll << 31), "too many workgroups");
         if (spw == 3) conv_1x1_kernel<3><<<(unsigned)g1, 64, 0, st>>>(a);
