@@ -128,15 +128,36 @@ def _full_case(m, coords, ksize, c1, c2, cout, seed):
 
 
 @pytest.mark.parametrize('ksize,c1,c2,cout', [(3, 96, 0, 96), (3, 96, 32, 96), (5, 6, 0, 32), (1, 128, 0, 96),
-                                              (3, 32, 0, 32)])
+                                              (3, 32, 0, 32),
+                                              # 1x1 streaming-GEMM kernel: 3 / 2 / 1 strips per wave, two sources
+                                              (1, 96, 32, 128), (1, 64, 0, 64), (1, 96, 0, 32)])
 def test_full_size_layer_150k(scene150k, ksize, c1, c2, cout):
     m, coords = scene150k
     _full_case(m, coords, ksize, c1, c2, cout, zlib.crc32(repr((ksize, c1, c2, cout)).encode()) % 1000)
 
 
+def test_conv_1x1_bias_and_accumulate_150k(scene150k):
+    """conv_1x1_kernel epilogue at benchmark size: Y = Y0 + X W + b (accumulate = 1, bias) with a row pitch wider than
+    the channel count, against torch."""
+    from box2mask_amd import functional as F_
+    m, coords = scene150k
+    n = len(coords)
+    torch.manual_seed(5)
+    for cin, cout in ((128, 96), (96, 64), (64, 20)):
+        x = torch.randn(n, cin, device='cuda'); w = torch.randn(cin, cout, device='cuda') / cin ** 0.5
+        b = torch.randn(1, cout, device='cuda')
+        wide = torch.randn(n, cout + 12, device='cuda')
+        y0 = wide[:, 4:4 + cout]                                   # 16-byte aligned rows, pitch cout + 12
+        ref = y0.double() + x.double() @ w.double() + b.double()
+        out = F_.conv_raw(x, None, F_.weight_pack(w.unsqueeze(0)), 1, b, None, n, cout, out=y0, accumulate=True)
+        torch.cuda.synchronize()
+        assert out.data_ptr() == y0.data_ptr()
+        _close(out, ref, '1x1 %d->%d accumulate + bias' % (cin, cout), 1e-5)
+
+
 def test_full_size_layer_1p2m_rows():
-    """The level-0 map of the benchmark batch (8 scenes, ~1.2 M rows): un-split path over ~37 k items, XCD order
-    over the whole grid, weight-gradient chunks of 64 tiles."""
+    """The level-0 map of the benchmark batch (8 scenes, ~1.2 M rows): un-split path over ~37 k items, XCD runs over
+    the whole grid, weight-gradient chunks of 32 tiles."""
     from box2mask_amd import synth
     from box2mask_amd.sparse import CoordinateManager
     b = synth.make_batch(8, seed0=0, target_voxels=150_000)
