@@ -770,31 +770,41 @@ struct WgradArgs {
     float* partial;          // deterministic mode: per tile-chunk partial dW (dense [chunk][K][cin][cout]), plain stores
     const int32_t* xcd_start; // != NULL: work-balanced XCD runs of tiles (b2m_rulebook_balance); a run is cut into tile
                               // chunks of tiles_per_chunk from ITS first tile
+    int kpack;                // offsets per workgroup: 1, or -- layers with only 1 or 2 (ci, co) blocks -- 4 or 2: the waves
+                              // a single block would leave idle take the neighbouring offsets of the same tile chunk
+    int kgroups;              // ceil(K / kpack)
 };
-// work item -> (offset k, block group, tile range [t0, t1)); false: nothing to do.  `chunk` numbers the tile chunks of the
-// plain order (it addresses the deterministic mode's partial buffer, which never uses the balanced order).
-__device__ __forceinline__ bool wgrad_item(const WgradArgs& a, int& k, int& zg, int64_t& chunk, int64_t& t0, int64_t& t1) {
+// work item of a wave -> (offset k, block blk, tile range [t0, t1)); false: nothing to do.  A workgroup is (offset group,
+// block group, tile chunk); its 4 waves are 4 blocks of one offset (kpack = 1) or 4 / kpack blocks of kpack consecutive
+// offsets.  `chunk` numbers the tile chunks of the plain order (it addresses the deterministic mode's partial buffer,
+// which never uses the balanced order).
+__device__ __forceinline__ bool wgrad_item(const WgradArgs& a, int wave, int& k, int& blk, int64_t& chunk, int64_t& t0,
+                                           int64_t& t1) {
+    int64_t j;
+    const int32_t* run = nullptr;
     if (a.xcd_start) {
-        const int x = blockIdx.x & 7;
-        const int64_t j = blockIdx.x >> 3;
-        k = (int)(j % a.K);
-        const int64_t rest = j / a.K;
-        zg = (int)(rest % a.nz);
-        chunk = rest / a.nz;
-        const int64_t s1 = a.xcd_start[x + 1];
-        t0 = a.xcd_start[x] + chunk * a.tiles_per_chunk;
+        run = a.xcd_start + (blockIdx.x & 7);
+        j = blockIdx.x >> 3;
+    } else {
+        j = wg_index(a.nwg, a.xcd_per);
+        if (j < 0) return false;
+    }
+    const int kg = (int)(j % a.kgroups);
+    const int64_t rest = j / a.kgroups;
+    const int zg = (int)(rest % a.nz);
+    chunk = rest / a.nz;
+    if (a.kpack == 1) { k = kg; blk = zg * 4 + wave; }
+    else { const int nb = 4 / a.kpack; k = kg * a.kpack + wave / nb; blk = wave % nb; }
+    if (k >= a.K || blk >= a.nmb * a.nnb) return false;
+    if (run) {
+        const int64_t s1 = run[1];
+        t0 = run[0] + chunk * a.tiles_per_chunk;
         if (t0 >= s1) return false;
         t1 = t0 + a.tiles_per_chunk < s1 ? t0 + a.tiles_per_chunk : s1;
-        return true;
+    } else {
+        t0 = chunk * a.tiles_per_chunk;
+        t1 = t0 + a.tiles_per_chunk < a.ntiles ? t0 + a.tiles_per_chunk : a.ntiles;
     }
-    const int64_t wg = wg_index(a.nwg, a.xcd_per);
-    if (wg < 0) return false;
-    k = (int)(wg % a.K);
-    const int64_t rest = wg / a.K;
-    zg = (int)(rest % a.nz);
-    chunk = rest / a.nz;
-    t0 = chunk * a.tiles_per_chunk;
-    t1 = t0 + a.tiles_per_chunk < a.ntiles ? t0 + a.tiles_per_chunk : a.ntiles;
     return true;
 }
 
@@ -802,11 +812,9 @@ template <int MI, int NJ>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    int k, zg;
+    int k, blk;
     int64_t chunk, t0, t1;
-    if (!wgrad_item(a, k, zg, chunk, t0, t1)) return;
-    const int blk = zg * 4 + wave;
-    if (blk >= a.nmb * a.nnb) return;
+    if (!wgrad_item(a, wave, k, blk, chunk, t0, t1)) return;
     const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
     const bool identity = a.rb_in == nullptr;
     const int64_t ldr = a.ntiles * B2M_TILE;
@@ -941,11 +949,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
-    int k, zg;
+    int k, blk;
     int64_t chunk, t0, t1;
-    if (!wgrad_item(a, k, zg, chunk, t0, t1)) return;
-    const int blk = zg * 4 + wave;
-    if (blk >= a.nmb * a.nnb) return;
+    if (!wgrad_item(a, wave, k, blk, chunk, t0, t1)) return;
     const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int nt = (int)(t1 - t0);                       // <= 64 tiles: lane t holds the pair count of tile t0 + t
@@ -1153,18 +1159,22 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     if (workspace) tpc = cdiv64(a.ntiles, B2M_WGRAD_DET_CHUNKS);
     a.tiles_per_chunk = (int)tpc;
     a.nz = (a.nmb * a.nnb + 3) / 4;
-    a.nwg = (int64_t)K * cdiv64(a.ntiles, tpc) * a.nz;
+    // layers with one or two blocks (32->32, the 6->32 stem, 32->96): 4 or 2 offsets per workgroup instead of idle waves
+    const int nblocks = a.nmb * a.nnb;
+    a.kpack = (nblocks <= 2 && K >= 4 && env_flag("B2M_WGRAD_KPACK", 1)) ? 4 / nblocks : 1;
+    a.kgroups = (K + a.kpack - 1) / a.kpack;
+    a.nwg = (int64_t)a.kgroups * cdiv64(a.ntiles, tpc) * a.nz;
     B2M_CHECK_ARG(a.nwg < (1ll << 31) - 8, "too many workgroups");
     // work item = (k fastest, block group, tile chunk): a chunk of the XCD order = all offsets and blocks of
     // B2M_XCD_WG_CHUNKS tile chunks (default: contiguous eighths)
-    const XcdOrder xo = xcd_order(a.nwg, env_flag("B2M_XCD", 1) ? (int64_t)env_flag("B2M_XCD_WG_CHUNKS", 1 << 20) * K * a.nz : 0);
+    const XcdOrder xo = xcd_order(a.nwg, env_flag("B2M_XCD", 1) ? (int64_t)env_flag("B2M_XCD_WG_CHUNKS", 1 << 20) * a.kgroups * a.nz : 0);
     a.xcd_per = xo.chunk;
     dim3 grid(xo.grid);
     // XCD runs of equal work (the tail of rb_cnt, b2m_rulebook_balance), each cut into tile chunks from its own start
     a.xcd_start = nullptr;
     if (rb_cnt && !workspace && a.ntiles >= B2M_BALANCE_MIN_TILES && env_flag("B2M_XCD", 1) && env_flag("B2M_XCD_BALANCE", 1)) {
         a.xcd_start = rb_cnt + (int64_t)K * a.ntiles;
-        grid = dim3((unsigned)(8 * K * a.nz * cdiv64(B2M_XCD_CAP(a.ntiles), tpc)));
+        grid = dim3((unsigned)(8 * a.kgroups * a.nz * cdiv64(B2M_XCD_CAP(a.ntiles), tpc)));
     }
     // 24-bit multiply operands and 32-bit byte offsets: rows < 2^24, row pitch < 2^22 floats, tensors < 4 GiB
     // (blocks may overhang cin/cout as long as the row PITCH covers them: the extra columns only feed dW rows /

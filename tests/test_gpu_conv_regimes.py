@@ -41,6 +41,7 @@ REGIMES = {
     'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'},
     'wgrad_plain': {'B2M_WGRAD_PIPE': '0'},
     'wgrad_64_tile_chunks': {'B2M_WGRAD_MIN_TILES': '64'},
+    'wgrad_one_offset_per_workgroup': {'B2M_WGRAD_KPACK': '0'},
     'no_xcd_order': {'B2M_XCD': '0'},
     'xcd_equal_tile_counts': {'B2M_XCD_BALANCE': '0'},
     'unsplit_64bit': {'B2M_CONV_TARGET': '0', 'B2M_CONV_FAST32': '0', 'B2M_WGRAD_FAST32': '0'},
