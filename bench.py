@@ -51,7 +51,8 @@ class LaunchTimer:
             meta = dict(bytes=4.0 * args[2] * args[3] * (3 if args[6] else 2))
         elif name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats'):      # same leading arguments
             # x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
-            meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12], n_in=args[6])
+            meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12], n_in=args[6],
+                        acc=int(args[17]))
         else:   # b2m_conv_wgrad: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
             meta = dict(cin=args[2], cout=args[6], K=args[11], n_out=args[10], rb_cnt=args[9], n_in=args[3])
 
@@ -267,7 +268,9 @@ def main():
         # bytes any implementation moves: both feature matrices once, the weights once, the pair lists
         # once (5 B per rulebook slot; identity maps have none)
         slots = 0 if meta['rb_cnt'] is None else meta['K'] * ((meta['n_out'] + 63) // 64) * 64
-        nbytes = 4.0 * (meta['n_in'] * meta['cin'] + meta['n_out'] * meta['cout'] + meta['K'] * meta['cin'] * meta['cout']) + 5.0 * slots
+        # (a data gradient that accumulates onto the other consumer's gradient also reads its output once: acc)
+        nbytes = 4.0 * (meta['n_in'] * meta['cin'] + (1 + meta.get('acc', 0)) * meta['n_out'] * meta['cout'] +
+                        meta['K'] * meta['cin'] * meta['cout']) + 5.0 * slots
         a = agg.setdefault(name, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
         a['ms'] += ms; a['flops'] += flops; a['launches'] += 1; a['bytes'] += nbytes
 
