@@ -513,6 +513,37 @@ extern "C" int64_t b2m_weight_pack_plan(int32_t n, const int64_t* w, const int64
 // read in whole row segments (64..192 B contiguous) into LDS and written out in fragment order.  Reading it in
 // fragment order straight from memory touched a different 64-byte segment with every 4-byte load (1.4 TB/s).
 #define PACK_PER_WG 8
+// one packed block; KC / TW as compile-time constants (0: read them from the descriptor) -- every index below is a
+// division by them, and with runtime divisors the divisions were most of the kernel (1.5 TB/s)
+template <int KCc, int TWc>
+__device__ __forceinline__ void pack_one_block(const PackDesc& d, int64_t pb, float* tile) {
+    const int KC = KCc ? KCc : d.KC, TW = TWc ? TWc : d.TW;
+    const int KS = KC / 4, SW = 16 * TW, LW = 64 * TW * KS;
+    const int nchunk = (d.CI + KC - 1) / KC, nstrip = (d.CO + SW - 1) / SW;
+    const int chunk = (int)(pb % nchunk); const int64_t b2 = pb / nchunk;
+    const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
+    const int ci0 = chunk * KC, co0 = strip * SW;
+    __syncthreads();                                                 // the previous tile has been consumed
+    for (int j = threadIdx.x; j < KC * SW; j += 256) {
+        int ci_l, co_l;
+        if (!d.transpose) { ci_l = j / SW; co_l = j % SW; }          // rows of B are rows of w: SW contiguous floats
+        else { co_l = j / KC; ci_l = j % KC; }                       // rows of B are columns of w: KC contiguous floats
+        float v = 0.f;
+        if (ci0 + ci_l < d.CI && co0 + co_l < d.CO) {
+            if (!d.transpose) v = d.w[((int64_t)k * d.rows + ci0 + ci_l) * d.ldw + co0 + co_l];
+            else v = d.w[((int64_t)(d.mirror ? d.K - 1 - k : k) * d.rows + d.sb + co0 + co_l) * d.ldw + ci0 + ci_l];
+        }
+        tile[ci_l * SW + co_l] = v;
+    }
+    __syncthreads();
+    float* out = d.wp + pb * LW;
+    for (int e = threadIdx.x; e < LW; e += 256) {
+        int lane, f;
+        pack_unpos(e, TW * KS, lane, f);
+        const int s_ = f / TW, t = f % TW, q = lane >> 4, i = lane & 15;
+        out[e] = tile[(KS * q + s_) * SW + 16 * t + i];
+    }
+}
 __global__ __launch_bounds__(256) void weight_pack_batch_kernel(const PackDesc* __restrict__ plan, int n) {
     __shared__ float tile[16 * 48];
     const int64_t blk0 = (int64_t)blockIdx.x * PACK_PER_WG;
@@ -525,33 +556,11 @@ __global__ __launch_bounds__(256) void weight_pack_batch_kernel(const PackDesc* 
         const int64_t blk = blk0 + it;
         while (lo + 1 < n && plan[lo + 1].first_block <= blk) ++lo;      // crossing into the next layer is rare
         const PackDesc d = plan[lo];
-        const int KS = d.KC / 4, SW = 16 * d.TW, LW = 64 * d.TW * KS;
         const int64_t pb = blk - d.first_block;
-        if (pb * LW >= d.total) return;                                  // past the last layer
-        const int nchunk = (d.CI + d.KC - 1) / d.KC, nstrip = (d.CO + SW - 1) / SW;
-        const int chunk = (int)(pb % nchunk); const int64_t b2 = pb / nchunk;
-        const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
-        const int ci0 = chunk * d.KC, co0 = strip * SW;
-        __syncthreads();                                                 // the previous tile has been consumed
-        for (int j = threadIdx.x; j < d.KC * SW; j += 256) {
-            int ci_l, co_l;
-            if (!d.transpose) { ci_l = j / SW; co_l = j % SW; }          // rows of B are rows of w: SW contiguous floats
-            else { co_l = j / d.KC; ci_l = j % d.KC; }                   // rows of B are columns of w: KC contiguous floats
-            float v = 0.f;
-            if (ci0 + ci_l < d.CI && co0 + co_l < d.CO) {
-                if (!d.transpose) v = d.w[((int64_t)k * d.rows + ci0 + ci_l) * d.ldw + co0 + co_l];
-                else v = d.w[((int64_t)(d.mirror ? d.K - 1 - k : k) * d.rows + d.sb + co0 + co_l) * d.ldw + ci0 + ci_l];
-            }
-            tile[ci_l * SW + co_l] = v;
-        }
-        __syncthreads();
-        float* out = d.wp + pb * LW;
-        for (int e = threadIdx.x; e < LW; e += 256) {
-            int lane, f;
-            pack_unpos(e, d.TW * KS, lane, f);
-            const int s_ = f / d.TW, t = f % d.TW, q = lane >> 4, i = lane & 15;
-            out[e] = tile[(KS * q + s_) * SW + 16 * t + i];
-        }
+        if (pb * (64 * d.TW * (d.KC / 4)) >= d.total) return;            // past the last layer
+        if (d.KC == 16 && d.TW == 3) pack_one_block<16, 3>(d, pb, tile);  // (workgroup-uniform)
+        else if (d.KC == 16 && d.TW == 2) pack_one_block<16, 2>(d, pb, tile);
+        else pack_one_block<0, 0>(d, pb, tile);
     }
 }
 extern "C" int b2m_weight_pack_run(const void* plan_dev, int32_t n, int64_t total_blocks, void* stream) {
