@@ -524,28 +524,70 @@ __device__ __forceinline__ void pack_one_block(const PackDesc& d, int64_t pb, fl
     const int strip = (int)(b2 % nstrip); const int k = (int)(b2 / nstrip);
     const int ci0 = chunk * KC, co0 = strip * SW;
     __syncthreads();                                                 // the previous tile has been consumed
-    for (int j = threadIdx.x; j < KC * SW; j += 256) {
-        int ci_l, co_l;
-        if (!d.transpose) { ci_l = j / SW; co_l = j % SW; }          // rows of B are rows of w: SW contiguous floats
-        else { co_l = j / KC; ci_l = j % KC; }                       // rows of B are columns of w: KC contiguous floats
-        float v = 0.f;
-        if (ci0 + ci_l < d.CI && co0 + co_l < d.CO) {
-            if (!d.transpose) v = d.w[((int64_t)k * d.rows + ci0 + ci_l) * d.ldw + co0 + co_l];
-            else v = d.w[((int64_t)(d.mirror ? d.K - 1 - k : k) * d.rows + d.sb + co0 + co_l) * d.ldw + ci0 + ci_l];
+    // whole 16-channel chunks of 16-byte aligned rows: 16-byte loads and stores (one each per thread and block)
+    const bool vec = KCc == 16 && (d.ldw & 3) == 0 && ((uintptr_t)d.w & 15) == 0 && (d.sb & 3) == 0;
+    if (vec) {
+        const int j = threadIdx.x;
+        if (j < KC * SW / 4) {
+            if (!d.transpose) {                                      // rows of B are rows of w: SW contiguous floats
+                const int ci_l = j / (SW / 4), co_l = (j % (SW / 4)) * 4;
+                const float* src = d.w + ((int64_t)k * d.rows + ci0 + ci_l) * d.ldw + co0 + co_l;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ci0 + ci_l < d.CI) {
+                    if (co0 + co_l + 3 < d.CO) v = *(const f32x4*)src;
+                    else for (int u = 0; u < 4; ++u) if (co0 + co_l + u < d.CO) v[u] = src[u];
+                }
+                *(f32x4*)&tile[ci_l * SW + co_l] = v;
+            } else {                                                 // rows of B are columns of w: KC contiguous floats
+                const int co_l = j / (KC / 4), ci_l = (j % (KC / 4)) * 4;
+                const float* src = d.w + ((int64_t)(d.mirror ? d.K - 1 - k : k) * d.rows + d.sb + co0 + co_l) * d.ldw + ci0 + ci_l;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (co0 + co_l < d.CO) {
+                    if (ci0 + ci_l + 3 < d.CI) v = *(const f32x4*)src;
+                    else for (int u = 0; u < 4; ++u) if (ci0 + ci_l + u < d.CI) v[u] = src[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tile[(ci_l + u) * SW + co_l] = v[u];
+            }
         }
-        tile[ci_l * SW + co_l] = v;
+    } else {
+        for (int j = threadIdx.x; j < KC * SW; j += 256) {
+            int ci_l, co_l;
+            if (!d.transpose) { ci_l = j / SW; co_l = j % SW; }
+            else { co_l = j / KC; ci_l = j % KC; }
+            float v = 0.f;
+            if (ci0 + ci_l < d.CI && co0 + co_l < d.CO) {
+                if (!d.transpose) v = d.w[((int64_t)k * d.rows + ci0 + ci_l) * d.ldw + co0 + co_l];
+                else v = d.w[((int64_t)(d.mirror ? d.K - 1 - k : k) * d.rows + d.sb + co0 + co_l) * d.ldw + ci0 + ci_l];
+            }
+            tile[ci_l * SW + co_l] = v;
+        }
     }
     __syncthreads();
     float* out = d.wp + pb * LW;
-    for (int e = threadIdx.x; e < LW; e += 256) {
-        int lane, f;
-        pack_unpos(e, TW * KS, lane, f);
-        const int s_ = f / TW, t = f % TW, q = lane >> 4, i = lane & 15;
-        out[e] = tile[(KS * q + s_) * SW + 16 * t + i];
+    if (KCc == 16) {                                                 // layout [piece u][lane][4]: 4 consecutive floats = one (u, lane)
+        const int e4 = threadIdx.x;
+        if (e4 < LW / 4) {
+            const int lane = e4 & 63, u = e4 >> 6, q = lane >> 4, i = lane & 15;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * u + r, s_ = f / TW, t = f % TW;
+                v[r] = tile[(KS * q + s_) * SW + 16 * t + i];
+            }
+            *(f32x4*)&out[4 * e4] = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < LW; e += 256) {
+            int lane, f;
+            pack_unpos(e, TW * KS, lane, f);
+            const int s_ = f / TW, t = f % TW, q = lane >> 4, i = lane & 15;
+            out[e] = tile[(KS * q + s_) * SW + 16 * t + i];
+        }
     }
 }
 __global__ __launch_bounds__(256) void weight_pack_batch_kernel(const PackDesc* __restrict__ plan, int n) {
-    __shared__ float tile[16 * 48];
+    __shared__ __attribute__((aligned(16))) float tile[16 * 48];
     const int64_t blk0 = (int64_t)blockIdx.x * PACK_PER_WG;
     int lo = 0, hi = n - 1;                              // last descriptor with first_block <= blk0
     while (lo < hi) {
