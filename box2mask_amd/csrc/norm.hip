@@ -509,7 +509,23 @@ __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__
         int64_t cur = ids[r0];
         float acc = 0.f;
         int len = 0;                                                 // rows of the current segment (channel 0 counts)
-        for (int64_t r = r0; r < r1; ++r) {
+        int64_t r = r0;
+        for (; r + 3 < r1; r += 4) {                                 // four rows' loads in flight, then in row order
+            int64_t id4[4]; float v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { id4[u] = ids[r + u]; v4[u] = x[(r + u) * ldx + col]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (id4[u] != cur) {
+                    atomicAdd(&out[cur * c + col], acc);
+                    if (col == 0) atomicAdd(&counts[cur], len);
+                    acc = 0.f; len = 0; cur = id4[u];
+                }
+                acc += v4[u];
+                ++len;
+            }
+        }
+        for (; r < r1; ++r) {
             const int64_t id = ids[r];
             if (id != cur) {
                 atomicAdd(&out[cur * c + col], acc);
@@ -628,6 +644,32 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
         dx[r * lddx + col] = g;
     }
 }
+// the same with 16-byte accesses: thread -> (row slot, float4 column group), rows walked with a constant stride (no
+// per-element division); c % 4 == 0, dx rows and dout 16-byte aligned
+__global__ __launch_bounds__(256) void pool_bwd_vec_kernel(const float* __restrict__ dout, int64_t n, int c4,
+                                                           const int64_t* __restrict__ ids, int mode,
+                                                           const int32_t* __restrict__ counts,
+                                                           const int32_t* __restrict__ argmax, float* __restrict__ dx,
+                                                           int64_t lddx) {
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    if (rs >= nslots) return;
+    const int c = c4 * 4;
+    for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
+        const int64_t s = ids[r];
+        f32x4 g = *(const f32x4*)(dout + s * c + cg * 4);
+        if (mode == 0) {
+            const float cnt = (float)counts[s];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = g[u] / cnt;              // (a division, as the scalar kernel: the same bits)
+        } else {
+            const i32x4 a = *(const i32x4*)(argmax + s * c + cg * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = a[u] == (int32_t)r ? g[u] : 0.f;
+        }
+        *(f32x4*)(dx + r * lddx + cg * 4) = g;
+    }
+}
 extern "C" int b2m_segment_pool_bwd(const float* dout, int64_t n, int32_t c, const int64_t* ids, int64_t n_seg,
                                     int32_t mode, const int32_t* counts, const int32_t* argmax, float* dx,
                                     int64_t lddx, void* stream) {
@@ -635,7 +677,11 @@ extern "C" int b2m_segment_pool_bwd(const float* dout, int64_t n, int32_t c, con
     B2M_CHECK_ARG(dout && ids && dx && c > 0 && lddx >= c, "bad arguments");
     B2M_CHECK_ARG((mode == 0 && counts) || (mode == 1 && argmax), "mode 0 needs counts, mode 1 needs argmax");
     if (n == 0) return B2M_OK;
-    pool_bwd_kernel<<<ew_grid(n * c), 256, 0, st>>>(dout, n, c, ids, mode, counts, argmax, dx, lddx);
+    if (c % 4 == 0 && c <= 1024 && lddx % 4 == 0 && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
+        (mode == 0 || ((uintptr_t)argmax % 16) == 0))
+        pool_bwd_vec_kernel<<<row_grid(n, c / 4), 256, 0, st>>>(dout, n, c / 4, ids, mode, counts, argmax, dx, lddx);
+    else
+        pool_bwd_kernel<<<ew_grid(n * c), 256, 0, st>>>(dout, n, c, ids, mode, counts, argmax, dx, lddx);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
