@@ -339,7 +339,7 @@ def main():
     roofline['measured'] = ('%d steps after the timed region on ONE stream, no prefetch beside them (B2M_WGRAD_STREAM=0: %.2f ms per step incl. the '
                             'events), every launch alone on the chip' % (args.steps, elapsed_serial / args.steps * 1e3))
     roofline_wgrad = roof(wg, 'conv_wgrad_kernel')
-    roofline_wgrad['kernel'] = 'b2m_conv_wgrad: conv_wgrad_flow_kernel (+ conv_wgrad_kernel for 1x1 layers)'
+    roofline_wgrad['kernel'] = 'b2m_conv_wgrad: conv_wgrad_flow_kernel (+ conv_wgrad_kernel for single-block narrow heads)'
 
     value = scenes / elapsed
     result = {

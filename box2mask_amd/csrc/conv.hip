@@ -1006,7 +1006,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int nt = (int)(t1 - t0);                       // <= 64 tiles: lane t holds the pair count of tile t0 + t
-    const int cnt = lane < nt ? a.rb_cnt[(int64_t)k * a.ntiles + t0 + lane] : 0;
+    const bool ident = a.rb_in == nullptr;               // identity map (1x1 layers): pair j of a tile is (row j, row j)
+    int cnt = 0;
+    if (lane < nt) {
+        if (ident) { const int64_t rem = a.n_out - (t0 + lane) * B2M_TILE; cnt = rem < B2M_TILE ? (int)rem : B2M_TILE; }
+        else cnt = a.rb_cnt[(int64_t)k * a.ntiles + t0 + lane];
+    }
     const uint64_t live = __ballot(cnt > 0);
     if (live == 0) return;
 
@@ -1022,6 +1027,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     const int64_t kbase = (int64_t)k * ldr + t0 * B2M_TILE;
     // list of a slot: lane (i, .) loads entry i; word = input row | row inside the tile << 24, bit 31 = no pair
     auto load_list = [&](int ti, int g, int& r_in, int& r_out) {
+        if (ident) {                                     // (wave-uniform)
+            const int64_t row = (t0 + ti) * B2M_TILE + 16 * g + i;
+            r_in = row < a.n_out ? (int)row : -1;
+            r_out = 16 * g + i;
+            return;
+        }
         const int64_t base = kbase + (int64_t)ti * B2M_TILE + 16 * g + i;
         r_in = a.rb_in[base];
         r_out = a.rb_out[base];
@@ -1236,7 +1247,8 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     // The flat-pipeline kernel for real rulebooks and 32-bit addressable operands.  Its MFMAs are asm statements the
     // compiler's hazard recogniser cannot see: a block with a single accumulator (MI = NJ = 1: consecutive MFMAs on the
     // same registers) stays on the plain kernel, where the builtin lets hipcc place whatever the dependence needs.
-    a.pipe = (a.fast32 && rb_in != nullptr && MI * NJ >= 2 && !workspace && env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
+    a.pipe = (a.fast32 && (rb_in != nullptr || (n_in >= n_out && env_flag("B2M_WGRAD_PIPE_IDENT", 1))) && MI * NJ >= 2 &&
+              !workspace && env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
     launch_wgrad(MI, NJ, grid, st, a);
     if (workspace) {
         const int nchunks = (int)cdiv64(a.ntiles, tpc);

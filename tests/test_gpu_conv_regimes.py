@@ -88,6 +88,7 @@ def test_conv_1x1_through_the_general_kernel(maps, monkeypatch, kind, level, cin
     layers with fewer than 16 input channels per chunk."""
     from test_gpu_ops import _conv_case
     monkeypatch.setenv('B2M_CONV_1X1', '0')
+    monkeypatch.setenv('B2M_WGRAD_PIPE_IDENT', '0')       # and their weight gradient through the plain kernel
     _conv_case(maps, kind, level, cins, cout, bias)
 
 
