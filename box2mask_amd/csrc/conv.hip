@@ -1202,7 +1202,7 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     const int MI = pick_blk(cin), NJ = pick_blk(cout);
     a.nmb = (cin + 16 * MI - 1) / (16 * MI);
     a.nnb = (cout + 16 * NJ - 1) / (16 * NJ);
-    // chunking: enough waves to fill the chip several times over, but a wave should own at least 4 tiles: every wave
+    // chunking: enough waves to fill the chip several times over, but a wave should own at least 4-8 tiles: every wave
     // ends with 16*MI x 16*NJ atomics into dW, and on the small deep-level maps those outweighed the MFMA work (A/B per
     // layer: +30..50 % there with the floor).  Large maps (>= 2048 tiles: levels 0 and 1 of the benchmark) are cut twice
     // as fine, into chunks of at most 32 tiles: a wave's life is its chunk's pairs of one offset, and with 64-tile chunks
@@ -1213,7 +1213,10 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     int64_t want_chunks = cdiv64(env_flag("B2M_WGRAD_TARGET", large ? 32768 : 16384), blocks_per_chunk);
     if (want_chunks < 1) want_chunks = 1;
     int64_t tpc = cdiv64(a.ntiles, want_chunks);
-    if (tpc < env_flag("B2M_WGRAD_MIN_TILES", 4)) tpc = env_flag("B2M_WGRAD_MIN_TILES", 4);
+    // (floor 8 from 32 tiles up: level-3 128->128 58 -> 66, level-4 256->256 58 -> 67 TFLOP/s; the 11-tile level-5 maps lose
+    // a quarter with it and keep 4)
+    const int min_tiles = env_flag("B2M_WGRAD_MIN_TILES", a.ntiles >= 32 ? 8 : 4);
+    if (tpc < min_tiles) tpc = min_tiles;
     { int mx = env_flag("B2M_WGRAD_MAX_TILES", large ? 32 : 64); if (mx < 1) mx = 1; if (mx > 64) mx = 64; if (tpc > mx) tpc = mx; }
     // Deterministic mode (workspace given): at most B2M_WGRAD_DET_CHUNKS tile chunks, every chunk stores its partial
     // blocks plainly and a second kernel adds them up in chunk order -- no atomics, the same bits on every run.
