@@ -40,7 +40,7 @@ class LaunchTimer:
         self.records = []          # (name, start_event, end_event, meta)
         self.enabled = False
 
-    def hook(self, name, args):
+    def hook(self, name, args, meta_in=None):
         if not self.enabled or name not in self.names:
             return None
         s = torch.cuda.Event(enable_timing=True)
@@ -51,7 +51,9 @@ class LaunchTimer:
             meta = dict(bytes=4.0 * args[2] * args[3] * (3 if args[6] else 2))
         elif name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats'):      # same leading arguments
             # x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
-            meta = dict(cin=args[2] + args[5], cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12], n_in=args[6],
+            # (the 6-channel network input is read through a zero-padded 8-channel view: its FLOPs count the logical 6)
+            cin = (meta_in or {}).get('cin', args[2] + args[5])
+            meta = dict(cin=cin, cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12], n_in=args[6],
                         acc=int(args[17]))
         else:   # b2m_conv_wgrad: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
             meta = dict(cin=args[2], cout=args[6], K=args[11], n_out=args[10], rb_cnt=args[9], n_in=args[3])
@@ -86,7 +88,12 @@ def main():
     ap.add_argument('--cpu-timeout', type=int, default=240, help='seconds after which the CPU baseline is abandoned')
     ap.add_argument('--votes', type=int, default=1, help='0 skips the votes -> instance masks leg (outside the timed steps)')
     ap.add_argument('--prepare', type=int, default=1, help='0 skips the raw points -> device batch leg (outside the timed steps)')
+    ap.add_argument('--workload', default='scannet', choices=['scannet', 's3dis', 'arkit'],
+                    help='scannet = BASELINE configs[1] (the headline); s3dis / arkit = configs[4] / [5], own lines under profiles/, '
+                         'never the headline')
     args = ap.parse_args()
+    if args.workload != 'scannet':       # the side legs and the CPU baseline belong to the headline workload
+        args.votes = args.prepare = args.cpu_baseline = 0
 
     # `python bench.py --gpus N` without a launcher: start the N rank processes here, BEFORE this process makes any
     # GPU call (children via subprocess; a process that has initialised the GPU must never exec another program).
@@ -96,9 +103,9 @@ def main():
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%s' % (args.gpus, os.environ['WORLD_SIZE']))
 
     # The CPU baseline runs FIRST, before this process touches the GPU (pure torch-CPU oracle, rank 0, N=1 only).
-    cpu_result = None
+    cpu_result = cpu_keep = None
     if args.cpu_baseline and int(os.environ.get('WORLD_SIZE', '1')) == 1:
-        cpu_result = cpu_baseline(args.cpu_scenes, args.cpu_voxels, args.cpu_timeout, args.target_voxels)
+        cpu_result, cpu_keep = cpu_baseline(args.cpu_scenes, args.cpu_voxels, args.cpu_timeout, args.target_voxels)
 
     from box2mask_amd import _lib, synth
     from box2mask_amd import sparse as sparse_mod
@@ -114,23 +121,29 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+
+    # ---- the CPU oracle's forward of its full-size scene against the device path on the same weights and inputs
+    # (whole network at the metric's scene size, train-mode BatchNorm; the parity figure travels with the bench line)
+    if cpu_result is not None and cpu_keep is not None:
+        cpu_result.update(gpu_vs_oracle(cpu_keep, dev))
+        cpu_keep = None
     torch.manual_seed(1234)
 
-    cfg = scannet_config(multigpu=(world > 1), batch_size=args.batch_size)
-    model = Model(cfg, *synth.scannet_tables(), device=dev)
+    backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+    workload, cfg, tables, batch = make_workload(args, rank, world)
+    model = Model(cfg, *tables, device=dev)
     opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, fused=True)      # same update as training.py:35, one kernel
     model.train()
 
     # ---- synthetic batch of this rank (weak scaling: every rank gets batch_size scenes), resident in HBM
     t0 = time.time()
-    seeds0 = rank * args.batch_size
-    batch = synth.make_batch(args.batch_size, seed0=seeds0, target_voxels=args.target_voxels)
     n_vox = int(batch['vox_coords'].shape[0])
     for k in ('vox_coords', 'vox_features', 'pooling_ids', 'input_location', 'gt_bb_offsets', 'gt_bb_bounds',
-              'gt_semantics', 'fg_instances', 'batch_ids'):
-        batch[k] = batch[k].to(dev)
+              'gt_semantics', 'fg_instances', 'batch_ids', 'gt_per_vox_semantics'):
+        if k in batch:
+            batch[k] = batch[k].to(dev)
     torch.cuda.synchronize()
-    gen_s = time.time() - t0
+    gen_s = workload['gen_s'] + time.time() - t0
 
     # keep every rulebook built during the timed steps reachable for the FLOP accounting
     rb_lookup = {}
@@ -199,6 +212,7 @@ def main():
     # H2D copy; `value` stays the HBM-resident rate, this one is reported beside it)
     host_keys = ('vox_coords', 'vox_features', 'pooling_ids', 'input_location', 'gt_bb_offsets', 'gt_bb_bounds',
                  'gt_semantics', 'fg_instances', 'batch_ids')
+    host_keys = tuple(k for k in host_keys + ('gt_per_vox_semantics',) if k in batch)
     dev_batch = dict(batch)
     pinned = {k: batch[k].cpu().pin_memory() for k in host_keys}
     h2d_bytes = sum(v.numel() * v.element_size() for v in pinned.values())
@@ -229,11 +243,35 @@ def main():
     batch.update(dev_batch)
     next_batch[0] = None
 
+    # ---- the same K steps with every loss read on the host in every iteration, as the reference's loop does
+    # (/root/reference/models/training.py:170-174: `.item()` of each entry of the loss dict): the host cannot run ahead
+    # across steps.  `value` stays the rate of the free-running loop; this one is reported beside it.
+    def step_sync():
+        ld = step()
+        return {k_: (v_.item() if hasattr(v_, 'item') else float(v_)) for k_, v_ in ld.items()}
+    step_sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_y = time.perf_counter()
+    for _ in range(args.steps):
+        step_sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed_sync = time.perf_counter() - t_y
+    if world > 1:
+        t = torch.tensor([elapsed_sync], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_sync = float(t.item())
+
     # ---- K more steps, one stream, every conv / BN-apply launch bracketed: the kernels' own durations
     timed_records = timer.records
     timer.records = []
     timer.names = {'b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_wgrad', 'b2m_bn_apply'}
+    prev_wgrad_stream = os.environ.get('B2M_WGRAD_STREAM')        # (a user-set value is restored afterwards)
     os.environ['B2M_WGRAD_STREAM'] = '0'
+    _lib.reload_env()
     prefetch_on[0] = False              # (nothing beside the bracketed kernels: the maps are built in front of the forward pass)
     step()
     torch.cuda.synchronize()
@@ -244,7 +282,11 @@ def main():
     torch.cuda.synchronize()
     elapsed_serial = time.perf_counter() - t_s
     timer.enabled = False
-    os.environ.pop('B2M_WGRAD_STREAM', None)
+    if prev_wgrad_stream is None:
+        os.environ.pop('B2M_WGRAD_STREAM', None)
+    else:
+        os.environ['B2M_WGRAD_STREAM'] = prev_wgrad_stream
+    _lib.reload_env()
     prefetch_on[0] = True
 
     if rank != 0:
@@ -309,7 +351,7 @@ def main():
                 'gflop_per_step': round(a['flops'] / max(args.steps, 1) / 1e9, 2),
                 'ms_per_step': round(a['ms'] / max(args.steps, 1), 3)}
 
-    scenes = world * args.batch_size * args.steps
+    scenes = world * workload['batch_size'] * args.steps
     fwd = agg.get('b2m_conv_fwd', dict(ms=0.0, flops=0.0, launches=0))
     wg = agg.get('b2m_conv_wgrad', dict(ms=0.0, flops=0.0, launches=0))
     roofline = roof(fwd, 'conv_fwd_kernel')
@@ -343,22 +385,25 @@ def main():
 
     value = scenes / elapsed
     result = {
-        'metric': 'ScanNet scenes/sec (fwd+bwd, ~150k voxels @2cm)', 'value': round(value, 3), 'unit': 'scenes/s',
+        'metric': workload['metric'], 'value': round(value, 3), 'unit': 'scenes/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         # the same steps with the batch arriving in pinned host memory (PCIe copy inside the timed region)
         'value_incl_h2d': round(scenes / elapsed_h2d, 3), 'h2d_mb_per_step': round(h2d_bytes / 1e6, 1),
+        # every loss `.item()`-ed in every iteration, as training.py:170-174 does (the host cannot run ahead)
+        'value_sync_per_step': round(scenes / elapsed_sync, 3),
         # /root/reference/README.md:102 quotes "~48GB GPURAM" for this batch size on MinkowskiEngine
         'peak_mem_gb': round(peak_mem_gb, 2),
-        'config': {'workload': 'ScanNet 2cm voxels, batch_size=%d per GPU, sparse-conv fwd/bwd + losses + Adam '
-                               '(BASELINE configs[1])' % args.batch_size,
-                   'global_batch': world * args.batch_size, 'voxels_per_scene': n_vox // args.batch_size,
+        'config': {'workload': workload['name'],
+                   'global_batch': world * workload['batch_size'], 'voxels_per_scene': n_vox // workload['batch_size'],
+                   # what the process group saw (RCCL is backend "nccl" on ROCm); None / 1 for a single process
+                   'backend': backend, 'ranks_seen': (dist.get_world_size() if backend else 1),
                    'voxels_per_gpu_batch': n_vox, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 4),
                    'scene_gen_s': round(gen_s, 1), 'setup_steps': SETUP_STEPS,
                    'prefetch': ('next batch: coordinate + kernel maps on a second stream during the step'
                                 if PREFETCH else 'off'),
-                   'steps_executed': SETUP_STEPS + args.warmup + 3 * args.steps + 2},
+                   'steps_executed': SETUP_STEPS + args.warmup + 4 * args.steps + 3},
         'roofline': roofline, 'roofline_timed_region': roofline_timed, 'roofline_wgrad': roofline_wgrad,
         # an HBM-bound kernel of the path, same live HIP-event method: BatchNorm apply (+residual, +ReLU) streams
         # 2-3 tensors per launch; small deep-level layers (launch-latency bound) are part of the average
@@ -387,6 +432,87 @@ def main():
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+
+
+def make_workload(args, rank, world):
+    """(description, cfg, class tables, host batch) of this rank.  scannet = BASELINE configs[1], the headline.  The other
+    two are BASELINE configs[4] / [5] as bench lines of their own (profiles/r03_workload_*.json), never the headline:
+    s3dis -- configs/s3dis_fold5.txt: batch 4, 13 classes, per-voxel semantics head beside the segment heads, rooms of
+    0.25-0.6 M voxels (S3DIS rooms after the reference's 0.25 point sampling); arkit -- configs/arkitscenes.txt: batch 4,
+    4 cm voxels, 28 classes, mixed scene sizes, features handed over as fp16 (upcast at the boundary)."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    t0 = time.time()
+    if args.workload == 'scannet':
+        cfg = scannet_config(multigpu=(world > 1), batch_size=args.batch_size)
+        batch = synth.make_batch(args.batch_size, seed0=rank * args.batch_size, target_voxels=args.target_voxels)
+        w = dict(name='ScanNet 2cm voxels, batch_size=%d per GPU, sparse-conv fwd/bwd + losses + Adam '
+                      '(BASELINE configs[1])' % args.batch_size,
+                 metric='ScanNet scenes/sec (fwd+bwd, ~150k voxels @2cm)', batch_size=args.batch_size)
+        tables = synth.scannet_tables()
+    elif args.workload == 's3dis':
+        cfg = scannet_config(multigpu=(world > 1), batch_size=4, eval_ths=[0.5, 0.03, 0.3, 0.6], loss_weight_bb_scores=3.0,
+                             network_heads=['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_per_vox_semantics'])
+        sizes = [250_000, 400_000, 600_000, 350_000]
+        items = [synth.make_scene(rank * 4 + i, target_voxels=tv) for i, tv in enumerate(sizes)]
+        batch = synth.collate(items)
+        n = batch['vox_coords'].shape[0]
+        batch['gt_semantics'] = batch['gt_semantics'] % 13
+        batch['gt_per_vox_semantics'] = torch.from_numpy(np.random.default_rng(rank).integers(0, 13, n))
+        valid = torch.Tensor(np.arange(13)); id2idx = torch.arange(41).long() % 13
+        tables = (valid, id2idx, id2idx.clone(), (lambda s_: s_ > 2))
+        w = dict(name='S3DIS-shaped rooms (%s voxels @2cm), batch_size=4 per GPU, 13 classes, per-voxel semantics head '
+                      '(BASELINE configs[4], configs/s3dis_fold5.txt)' % '/'.join('%dk' % (v // 1000) for v in sizes),
+                 metric='S3DIS-shaped scenes/sec (fwd+bwd, 0.25-0.6 M voxels @2cm)', batch_size=4)
+    else:
+        ids = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 18, 19, 20, 21, 22, 23, 24, 25, 28, 33, 34, 36, 39])
+        cfg = scannet_config(multigpu=(world > 1), batch_size=4, eval_ths=[0.5, 0.05, 0.4, 0.6], loss_weight_bb_scores=3.0,
+                             loss_weight_semantics=0.3, voxel_size=0.04)
+        sizes = [30_000, 200_000, 80_000, 120_000]
+        items = [synth.make_scene(rank * 4 + 10 + i, target_voxels=tv, voxel_size=0.04, pts_per_m2=5000.0)
+                 for i, tv in enumerate(sizes)]
+        batch = synth.collate(items)
+        batch['gt_semantics'] = torch.from_numpy(ids[batch['gt_semantics'].numpy() % len(ids)])
+        batch['vox_features'] = batch['vox_features'].half()
+        valid = torch.Tensor(ids)
+        id2idx = torch.zeros(41).fill_(-100).long(); id2idx[ids] = torch.arange(len(ids)).long()
+        tables = (valid, id2idx, id2idx.clone(), (lambda s_: s_ > 2))
+        w = dict(name='ARKitScenes-shaped scenes (%s voxels @4cm), batch_size=4 per GPU, 28 classes, fp16 features in '
+                      '(BASELINE configs[5], configs/arkitscenes.txt)' % '/'.join('%dk' % (v // 1000) for v in sizes),
+                 metric='ARKit-shaped scenes/sec (fwd+bwd, 30-200 k voxels @4cm)', batch_size=4)
+    w['gen_s'] = time.time() - t0
+    return w, cfg, tables, batch
+
+
+def gpu_vs_oracle(keep, dev):
+    """Forward of the device path on the CPU baseline's own weights and scene; max over the heads and the per-voxel
+    trunk features of |gpu - oracle|_max / |oracle|_max (north_star tolerance: 1e-3)."""
+    from box2mask_amd import nn as ME, synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.detection_net import SelectionNet
+    cfg = scannet_config()
+    valid, _, _, is_fg = synth.scannet_tables()
+    net = SelectionNet(cfg, dev, valid, is_fg, out_channels=[96, 96, 6]).to(dev)
+    net.load_state_dict(keep['state'])
+    net.train()
+    b = keep['batch']
+    net._trace = {}
+    with torch.no_grad():
+        sin = ME.SparseTensor(b['vox_features'], b['vox_coords'], device=dev)
+        out = net(sin, b['pooling_ids'].to(dev), b['input_location'].shape[0])
+        trunk = net._trace['block8']
+        if sin.manager.inv_perm is not None:
+            trunk = trunk[sin.manager.inv_perm]
+    errs = {}
+    for h, ref in keep['out'].items():
+        got = trunk if h == '_trunk' else out[h].F
+        errs[h] = float((got.detach().cpu().double() - ref.double()).abs().max()) / max(float(ref.abs().max()), 1e-30)
+    del net, out, trunk, sin
+    torch.cuda.empty_cache()
+    return {'max_rel_err_vs_gpu': float('%.3e' % max(errs.values())),
+            'rel_err_vs_gpu_by_output': {('vox_feats' if k == '_trunk' else k): float('%.3e' % v) for k, v in errs.items()},
+            'parity_note': 'device forward (default mode, train-mode BatchNorm) on the same weights and the same full-size '
+                           'scene as this CPU sample; error = max |gpu - cpu| / max |cpu| per output'}
 
 
 def spawn_ranks(n):
@@ -444,7 +570,7 @@ def votes_leg(model, batch, cfg, cpu):
     from box2mask_amd import _lib
     rec = []
 
-    def hook(name, a):
+    def hook(name, a, meta_in=None):
         # algorithmic bytes per launch (every operand once)
         if name == 'b2m_nmc_batch':        # boxes, desc, n_scenes, max_n, th, ...: boxes once + the heat-map rows written
             nb = None                      # filled below from the results (needs the cluster counts)
@@ -567,7 +693,7 @@ def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
     from box2mask_amd import _lib
     rec = []
 
-    def hook(name, a):
+    def hook(name, a, meta_in=None):
         s_ = torch.cuda.Event(enable_timing=True); e_ = torch.cuda.Event(enable_timing=True)
         s_.record()
 
@@ -649,26 +775,29 @@ def cpu_baseline(n_scenes, voxels, timeout_s, ref_voxels):
     def _alarm(signum, frame):
         raise _Timeout()
 
+    keep = None
     old = signal.signal(signal.SIGALRM, _alarm)
     signal.alarm(int(timeout_s))
     t0 = time.perf_counter()
     try:
         out = unet_ref.forward(p, b['vox_coords'].numpy(), b['vox_features'], b['pooling_ids'], cfg, training=True,
-                               n_segments=b['input_location'].shape[0])
-        loss = sum(v.abs().mean() for k, v in out.items())
+                               n_segments=b['input_location'].shape[0], return_trunk=True)
+        keep = {'state': {k: v.detach().clone() for k, v in net.state_dict().items()}, 'batch': b,
+                'out': {k: v.detach().clone() for k, v in out.items()}}
+        loss = sum(v.abs().mean() for k, v in out.items() if k != '_trunk')
         loss.backward()
         dt = time.perf_counter() - t0
         value = round(n_scenes / dt, 5)
         note = '%.1f s' % dt
     except _Timeout:
-        value, note = None, 'abandoned after %d s' % timeout_s
+        value, note, keep = None, 'abandoned after %d s' % timeout_s, None
     finally:
         signal.alarm(0)
         signal.signal(signal.SIGALRM, old)
     return {'value': value, 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
             'sample': '%d synthetic scene(s) of the metric\'s size (%d voxels in all, seed 0..%d; no scaling): coordinate/'
                       'kernel-map build + forward + backward on the CPU oracle (oracle/unet_ref.py, torch %s, %d threads): '
-                      '%s; value = scenes / seconds' % (n_scenes, nvox, n_scenes - 1, torch.__version__, cores, note)}
+                      '%s; value = scenes / seconds' % (n_scenes, nvox, n_scenes - 1, torch.__version__, cores, note)}, keep
 
 
 if __name__ == '__main__':

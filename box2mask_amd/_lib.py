@@ -76,6 +76,7 @@ PROTOTYPES = {
     'b2m_seg_mode': [P, P, I64, I64, I32, P, P, P],
 }
 PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_device_ok': (C.c_int, []),
+         'b2m_reload_env': (C.c_int, []),
          'b2m_weight_pack_size': (C.c_int64, [I32, I32, I32]),
          'b2m_conv_wgrad_workspace': (C.c_int64, [I32, I32, I32]),
          'b2m_unique_insert': (C.c_int64, [P, I64, P, I64, P, P, P, P]),
@@ -123,7 +124,7 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# optional observer used by bench.py to bracket launches with HIP events: hook(name, args) -> finish()
+# optional observer used by bench.py to bracket launches with HIP events: hook(name, args, meta) -> finish()
 _hook = None
 
 
@@ -132,15 +133,33 @@ def set_hook(fn):
     _hook = fn
 
 
-def call(name, *args):
-    """Invoke a b2m_* entry on the current stream; raise B2MError on a negative return."""
+def call(name, *args, meta=None):
+    """Invoke a b2m_* entry on the current stream; raise B2MError on a negative return.  `meta`: facts about the call the
+    raw arguments do not carry (the logical channel count of a padded input), for the observer only."""
     lib = load()
-    done = _hook(name, args) if _hook is not None else None
+    done = _hook(name, args, meta) if _hook is not None else None
     rc = getattr(lib, name)(*args, stream())
     if done is not None:
         done()
     if rc != 0:
         raise B2MError('%s failed (%d): %s' % (name, rc, lib.b2m_last_error().decode()))
+
+
+def call_ret(name, *args):
+    """An entry of PLAIN that takes the stream and returns a count (>= 0) or a negative error code."""
+    lib = load()
+    done = _hook(name, args, None) if _hook is not None else None
+    rc = getattr(lib, name)(*args, stream())
+    if done is not None:
+        done()
+    if rc < 0:
+        raise B2MError('%s failed (%d): %s' % (name, rc, lib.b2m_last_error().decode()))
+    return rc
+
+
+def reload_env():
+    """The library caches the B2M_* switches per process: call this after changing one in os.environ."""
+    load().b2m_reload_env()
 
 
 def require_gpu():

@@ -12,6 +12,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define B2M_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
 void b2m_set_error(const char* fmt, ...);
+// integer value of an environment switch, cached per process (coords.hip); `name` must be a string literal
+int b2m_env_int(const char* name, int dflt);
 
 #define B2M_CHECK_ARG(cond, msg)                                   \
     do {                                                           \

@@ -1160,8 +1160,8 @@ static void launch_wgrad(int MI, int NJ, dim3 grid, hipStream_t st, const WgradA
         default: launch_wgrad_nj<4>(NJ, grid, st, a); break;
     }
 }
-// tuning switches (A/B inside one process: tools/bench_conv.py); read at every call
-static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// tuning switches (A/B inside one process: tools/bench_conv.py); read once per process (b2m_reload_env re-reads them)
+static int env_flag(const char* name, int dflt) { return b2m_env_int(name, dflt); }
 static int pick_blk(int c) {      // 16-column sub-tiles per wave block
     // 64 channels: four 32x32 blocks keep all 4 waves of a workgroup busy and fit the pipelined kernel at full
     // occupancy (+27..35 % over one 64x64 block)

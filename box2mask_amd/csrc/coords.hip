@@ -10,6 +10,31 @@ void b2m_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char* b2m_last_error(void) { return g_err; }
+
+// Tuning switches (B2M_* environment variables): read ONCE per process and kept in a small table -- a training step makes
+// ~300 convolution calls that each consult ~25 switches, and getenv() walks the whole environment every time (round 2:
+// ~4 ms of host time per step).  b2m_reload_env() drops the table (tests and A/B tools that flip a switch in-process).
+#include <mutex>
+namespace {
+struct EnvEntry { const char* name; int value; };
+EnvEntry g_env[96];
+int g_env_n = 0;
+std::mutex g_env_mu;
+}
+int b2m_env_int(const char* name, int dflt) {
+    std::lock_guard<std::mutex> lock(g_env_mu);
+    for (int i = 0; i < g_env_n; ++i)
+        if (g_env[i].name == name || strcmp(g_env[i].name, name) == 0) return g_env[i].value == INT32_MIN ? dflt : g_env[i].value;
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : INT32_MIN;          // INT32_MIN = unset (the caller's default applies, it may differ per call)
+    if (g_env_n < (int)(sizeof(g_env) / sizeof(g_env[0]))) { g_env[g_env_n].name = name; g_env[g_env_n].value = v; ++g_env_n; }
+    return v == INT32_MIN ? dflt : v;
+}
+extern "C" int b2m_reload_env(void) {
+    std::lock_guard<std::mutex> lock(g_env_mu);
+    g_env_n = 0;
+    return 0;
+}
 extern "C" int b2m_version(void) { return 1; }
 extern "C" int b2m_device_ok(void) {
     int n = 0;
@@ -437,7 +462,7 @@ __global__ __launch_bounds__(1024) void rulebook_order_kernel(int32_t* __restric
         order[p] = t;
     }
 }
-static int coords_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int coords_env(const char* name, int dflt) { return b2m_env_int(name, dflt); }
 extern "C" int64_t b2m_rulebook_cnt_size(int32_t K, int64_t n_out) {
     const int64_t ntiles = cdiv64(n_out, B2M_TILE);
     return (int64_t)K * ntiles + 16 + 2 * ntiles;

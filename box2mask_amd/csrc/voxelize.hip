@@ -90,24 +90,52 @@ extern "C" int b2m_vox_keys(const double* pos, int64_t n_pts, const double* shif
 }
 
 // ------------------------------------------------------------------ unique with inverse on 64-bit keys
+// slot of `key` in the table, inserting it if absent; the first inserter publishes the key in the (unordered) unique list.
+// A plain read in front of every compare-and-swap: once a key is in the table, later arrivals never touch the atomic unit.
+__device__ __forceinline__ int64_t unique_insert_one(uint64_t key, uint64_t* __restrict__ tkeys, int64_t mask,
+                                                     uint64_t* __restrict__ ukeys, int32_t* __restrict__ n_unique) {
+    int64_t s = (int64_t)(b2m_hash(key) & (uint64_t)mask);
+    for (;;) {
+        uint64_t cur = __hip_atomic_load(&tkeys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == B2M_EMPTY_KEY) {
+            cur = atomicCAS((unsigned long long*)&tkeys[s], (unsigned long long)B2M_EMPTY_KEY, (unsigned long long)key);
+            if (cur == B2M_EMPTY_KEY) {
+                ukeys[atomicAdd(n_unique, 1)] = key;
+                return s;
+            }
+        }
+        if (cur == key) return s;
+        s = (s + 1) & mask;
+    }
+}
+// Inputs with few distinct keys (1.2 M ground-truth instance ids holding a few dozen values: utils/eval_metric.py:316-330)
+// made every thread of the grid fight for the same handful of slots (round 2: 7.7 ms per scene).  Now a wave first
+// elects, per distinct key it holds, ONE lane that probes / inserts, and hands the slot to the others by a cross-lane
+// read: one atomic per (wave, key) at most.  A wave whose keys are mostly distinct (voxel keys) sees that in the first
+// election and takes the per-lane path at once.
 __global__ void unique_insert_kernel(const uint64_t* __restrict__ in, int64_t n, uint64_t* __restrict__ tkeys,
                                      int64_t mask, int32_t* __restrict__ slot_of, uint64_t* __restrict__ ukeys,
                                      int32_t* __restrict__ n_unique) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t key = in[i];
-    int64_t s = (int64_t)(b2m_hash(key) & (uint64_t)mask);
-    for (;;) {
-        const unsigned long long prev = atomicCAS((unsigned long long*)&tkeys[s], (unsigned long long)B2M_EMPTY_KEY,
-                                                  (unsigned long long)key);
-        if (prev == B2M_EMPTY_KEY) {          // first inserter of this key: publish it in the (unordered) unique list
-            ukeys[atomicAdd(n_unique, 1)] = key;
-            break;
-        }
-        if (prev == key) break;
-        s = (s + 1) & mask;
+    const int lane = lane_id();
+    bool pending = i < n;
+    const uint64_t key = pending ? in[i] : 0;
+    int64_t myslot = -1;
+    for (int iter = 0; iter < 16; ++iter) {
+        const uint64_t act = __ballot(pending);
+        if (act == 0) break;
+        const int leader = __builtin_ctzll(act);
+        const uint64_t lk = (uint64_t)__shfl((long long)key, leader, 64);
+        const bool same = pending && key == lk;
+        const uint64_t grp = __ballot(same);
+        if (iter == 0 && __builtin_popcountll(grp) * 8 < __builtin_popcountll(act)) break;     // mostly distinct keys
+        long long s = 0;
+        if (lane == leader) s = unique_insert_one(key, tkeys, mask, ukeys, n_unique);
+        s = __shfl(s, leader, 64);
+        if (same) { myslot = s; pending = false; }
     }
-    slot_of[i] = (int32_t)s;
+    if (pending) myslot = unique_insert_one(key, tkeys, mask, ukeys, n_unique);
+    if (i < n) slot_of[i] = (int32_t)myslot;
 }
 
 static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }

@@ -154,7 +154,7 @@ packed_weights = _PackedWeights()
 
 
 def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: int, out=None, accumulate=False,
-             tile_stats: list | None = None):
+             tile_stats: list | None = None, logical_cin: int | None = None):
     """Y = sum_k [x1|x2][in_k] @ B[k] with B given as a packed image for (K, c1+c2, cout).
     tile_stats: a list; if the kernel of this shape can, it also leaves the per-tile column sums of Y (sum and sum of
     squares over each tile of 64 rows: the statistics of the BatchNorm that follows) and the list receives
@@ -163,6 +163,7 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
     c2 = x2.shape[1] if x2 is not None else 0
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=x1.device)
+    meta = None if logical_cin is None else {'cin': logical_cin}
     if rb is None:
         assert K == 1
         rbi = rbo = rbc = None
@@ -175,13 +176,13 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
         wrote = ctypes.c_int32(0)
         _call('b2m_conv_fwd_stats', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
               x1.shape[0], wp.data_ptr(), K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
-              1 if accumulate else 0, ts.data_ptr(), ctypes.byref(wrote))
+              1 if accumulate else 0, ts.data_ptr(), ctypes.byref(wrote), meta=meta)
         if wrote.value:
             tile_stats.append((ts, ntiles))
         return out
     _call('b2m_conv_fwd', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
           x1.shape[0], wp.data_ptr(), K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
-          1 if accumulate else 0)
+          1 if accumulate else 0, meta=meta)
     return out
 
 
@@ -250,7 +251,8 @@ class _SparseConv(torch.autograd.Function):
         w3 = _f32c(w3)
         K, cin, cout = w3.shape
         wp = packed_weights.get(weight)
-        y = conv_raw(x1, x2, wp, K, bias, rb_f, n_out, cout, tile_stats=tile_stats)
+        y = conv_raw(x1, x2, wp, K, bias, rb_f, n_out, cout, tile_stats=tile_stats,
+                     logical_cin=c1 if x1.shape[1] != c1 else None)
         ctx.save_for_backward(x1, x2, weight, bias)
         ctx.rb_f, ctx.rb_b, ctx.mirror, ctx.c1 = rb_f, rb_b, mirror, c1
         if passthrough:
@@ -279,12 +281,14 @@ class _SparseConv(torch.autograd.Function):
             dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1, out=acc, accumulate=acc is not None)
             if p1 is not None and acc is None:
                 dx1 = dx1 + p1
+            _own(dx1)
         if x2 is not None and ctx.needs_input_grad[1]:
             wt = packed_weights.get(weight, True, ctx.mirror, c1, x2.shape[1])
             acc = _accumulation_target(p2, x2.shape[0], x2.shape[1])
             dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1], out=acc, accumulate=acc is not None)
             if p2 is not None and acc is None:
                 dx2 = dx2 + p2
+            _own(dx2)
         if ctx.needs_input_grad[2]:
             # the weight's slot in the model's gradient arena (zeroed once per pass, adopted by autograd as .grad), else a
             # zero-filled tensor of the weight's own shape
@@ -318,11 +322,24 @@ class _SparseConv(torch.autograd.Function):
         return dx1, dx2, dw, db, None, None, None, None, None, None
 
 
+def _own(t):
+    """Mark a gradient tensor this package produced itself and returns to autograd for exactly ONE input (a data
+    gradient, BatchNorm's dx / residual gradient): nobody else holds it, so a later data-gradient kernel may add onto it
+    in place."""
+    if t is not None:
+        t._b2m_own = True
+    return t
+
+
 def _accumulation_target(g, n: int, c: int):
     """The gradient of a passed-through input, if the data gradient may be added onto it in place: a dense fp32 (n, c)
-    tensor that owns its memory (what BatchNorm's residual gradient, a convolution's data gradient or autograd's own sum
-    of several gradients are)."""
+    tensor that owns its memory AND was produced by one of this package's backward operators for this input alone
+    (`_own`).  A gradient that comes from a torch operator may be the same TensorImpl another branch still holds
+    (AddBackward0 hands one tensor to both inputs): adding in place would corrupt that branch, so those are summed out of
+    place."""
     if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n, c) or not g.is_contiguous() or g._base is not None:
+        return None
+    if not getattr(g, '_b2m_own', False):
         return None
     return g
 
@@ -457,7 +474,7 @@ class _BatchNorm(torch.autograd.Function):
             g = dy if not relu else dy * (y > 0)
             dx = g * mean.reshape(1, -1)
             gres = None if dres is None else (g.clone() if g is dy else g)       # (never the incoming tensor itself)
-            return dx, None, None, None, None, None, None, None, gres, None, None, None, None
+            return _own(dx), None, None, None, None, None, None, None, _own(gres), None, None, None, None
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned
@@ -477,8 +494,8 @@ class _BatchNorm(torch.autograd.Function):
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), gsums.data_ptr(),
               count, _ptr(ctx.count_dev), relu, _ptr(mscale), _ptr(mshift), dx.data_ptr(), dx.stride(0), _ptr(dres),
               dres.stride(0) if dres is not None else 0)
-        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, dres, None, None, None, None)
+        return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                None, None, None, None, None, _own(dres), None, None, None, None)
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None,

@@ -41,6 +41,7 @@ class GradArena:
         self.sequence = seq
         self.buffers = [None, None]      # allocated on first use (the second one only if gradients are ever kept)
         self.current = None              # index of the buffer of the pass in flight
+        self.handed = set()              # id(p) of the slots handed out since the last begin_pass
         for p in self.params:
             _registry[id(p)] = (weakref.ref(p), weakref.ref(self), id(p))
 
@@ -60,6 +61,7 @@ class GradArena:
     def begin_pass(self):
         """Pick a buffer no live gradient points into and clear it (one memset).  Called once per forward pass,
         before any backward operator of that pass can run."""
+        self.handed.clear()
         j = 0 if not self._owned(0) else 1
         if j == 1 and self._owned(1):
             # gradients from two earlier passes are both alive (the caller re-assigned .grad by hand): give up the
@@ -73,16 +75,21 @@ class GradArena:
         self.current = j
 
     def slot(self, p):
-        """Zero-initialised view for the gradient of `p` in the current pass, or None (no pass open / foreign tensor)."""
+        """Zero-initialised view for the gradient of `p` in the current pass, or None (no pass open / foreign tensor).
+        A slot is handed out ONCE per pass: when the backward operator of one parameter runs a second time inside the
+        same backward() -- two forward passes summed into one loss, a weight shared by two layers -- the first result is
+        still held by autograd (p.grad is None until AccumulateGrad runs), so the second caller gets None, allocates a
+        tensor of its own, and autograd adds the two."""
         if self.current is None:
             return None
         off = self.offset.get(id(p))
-        if off is None:
+        if off is None or id(p) in self.handed:
             return None
         view = self.buffers[self.current][off:off + p.numel()].view(p.shape)
         g = p.grad
         if g is not None and g.data_ptr() == view.data_ptr():
             return None          # a second backward of the same pass: .grad already lives here, it must not be its own addend
+        self.handed.add(id(p))
         return view
 
     # ---- for the all-reduce

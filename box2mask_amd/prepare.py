@@ -39,10 +39,7 @@ def _unique_inverse(keys: torch.Tensor):
     slot_of = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     ukeys = torch.full((_pow2(max(n, 2)),), -1, dtype=torch.int64, device=dev)       # 2^64-1 = padding, sorts last
     n_unique = torch.empty(1, dtype=torch.int32, device=dev)
-    lib = _lib.load()
-    nu = lib.b2m_unique_insert(ptr(keys), n, ptr(tkeys), cap, ptr(slot_of), ptr(ukeys), ptr(n_unique), _lib.stream())
-    if nu < 0:
-        raise _lib.B2MError('b2m_unique_insert failed (%d): %s' % (nu, lib.b2m_last_error().decode()))
+    nu = _lib.call_ret('b2m_unique_insert', ptr(keys), n, ptr(tkeys), cap, ptr(slot_of), ptr(ukeys), ptr(n_unique))
     _lib.call('b2m_sort_u64', ptr(ukeys), _pow2(max(nu, 2)))
     inverse = torch.empty(n, dtype=torch.int64, device=dev)
     _lib.call('b2m_unique_rank', ptr(ukeys), nu, ptr(tkeys), ptr(tvals), cap, ptr(slot_of), n, ptr(inverse))

@@ -33,6 +33,9 @@ const char* b2m_last_error(void);
 int b2m_version(void);
 /* 1 if the library was built for gfx950 and a device is present */
 int b2m_device_ok(void);
+/* The B2M_* tuning switches are read from the environment once per process; this makes the next call re-read them
+ * (tests and A/B tools that change a switch in-process).  Always returns 0. */
+int b2m_reload_env(void);
 
 /* ---------------------------------------------------------------- coordinate maps (integer) */
 

@@ -16,3 +16,30 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _b2m_env_switches(monkeypatch):
+    """The library reads its B2M_* switches once per process (b2m_reload_env re-reads them): a test that flips one through
+    `monkeypatch` must take effect at once, and nothing may leak into the next test."""
+    from box2mask_amd import _lib
+
+    def reload():
+        try:
+            _lib.reload_env()
+        except (ImportError, OSError):
+            pass
+    set0, del0 = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, prepend=None):
+        set0(name, value, prepend)
+        reload()
+
+    def delenv(name, raising=True):
+        del0(name, raising)
+        reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    reload()
+    yield
+    # (this runs before monkeypatch restores the environment: the next test's set-up reloads again)
+    reload()

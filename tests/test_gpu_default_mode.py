@@ -1,0 +1,239 @@
+"""The mode bench.py times -- weight gradients on the side stream, in-place pass-through gradients, atomic weight-gradient
+and split-K combines, BatchNorm statistics from the convolution epilogue, Model.prefetch beside the step -- against the
+oracle at NETWORK level (reference schedule: /root/reference/models/detection_net.py:234-364, resnet.py:70-83).
+
+No test in this file sets B2M_DETERMINISTIC: a missing stream join, a record_stream slip or an in-place accumulate onto a
+tensor another consumer still reads shows here as a wrong gradient.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from box2mask_amd import synth
+from box2mask_amd.config import scannet_config
+
+pytestmark = pytest.mark.gpu
+
+HEADS = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def _default_env(monkeypatch):
+    for k in ('B2M_DETERMINISTIC', 'B2M_WGRAD_STREAM', 'B2M_CONV_PASSTHROUGH', 'B2M_CONV_STATS', 'B2M_CONV_PIPE',
+              'B2M_CONV_FLOW_SPLIT', 'B2M_WGRAD_PIPE', 'B2M_XCD', 'B2M_CONV_1X1', 'B2M_CONV_TARGET'):
+        monkeypatch.delenv(k, raising=False)
+    from box2mask_amd import _lib
+    if hasattr(_lib, 'reload_env'):
+        _lib.reload_env()
+
+
+def _oracle_grads(sd, batch, gws, cfg, training, dtype):
+    from oracle import unet_ref
+    p = {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+             else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd.items()}
+    out = unet_ref.forward(p, batch['vox_coords'].numpy(), batch['vox_features'].to(dtype), batch['pooling_ids'], cfg,
+                           training=training, n_segments=batch['input_location'].shape[0])
+    sum((out[h] * gws[h].to(dtype)).sum() for h in HEADS).backward()
+    return p, out
+
+
+def test_default_mode_gradients_match_oracle_affine_batchnorm(monkeypatch):
+    """BatchNorm in eval mode is an affine map, so the backward pass is as well conditioned as the forward: EVERY
+    parameter gradient of the 8-level network must agree with the fp32 CPU oracle to 1e-3 of its maximum.  Three
+    different batches in one process (the caching allocator hands the previous step's blocks out again while the side
+    stream may still be reading them), the next batch's maps prefetched on a third stream beside each backward pass."""
+    _default_env(monkeypatch)
+    from box2mask_amd import functional as F_
+    from box2mask_amd.model import Model
+    assert F_.wgrad_on_side_stream() and F_.conv_passthrough() and not F_.deterministic()
+    cfg = scannet_config()
+    torch.manual_seed(11)
+    model = Model(cfg, *synth.scannet_tables())
+    net = model.detection_model
+    # scenes large enough that levels 0-1 run un-split, levels 2.. the split maps, and the weight gradients several chunks
+    batches = [synth.make_batch(6, seed0=300 + 10 * r, target_voxels=(5000, 8000, 3000)[r], pts_per_m2=8000.0) for r in range(3)]
+    # running statistics := statistics of batch 0 (momentum 1), affine parameters away from (1, 0): a normalising,
+    # non-trivial affine BatchNorm
+    from box2mask_amd import nn as ME
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, ME.MinkowskiBatchNorm):
+                m.bn.momentum = 1.0
+                m.bn.weight.uniform_(0.6, 1.4)
+                m.bn.bias.uniform_(-0.3, 0.3)
+        net.train()
+        net(ME.SparseTensor(batches[0]['vox_features'], batches[0]['vox_coords']), batches[0]['pooling_ids'].cuda(),
+            batches[0]['input_location'].shape[0])
+    net.eval()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    worst_all = 0.0
+    for r, batch in enumerate(batches):
+        S_ = batch['input_location'].shape[0]
+        torch.manual_seed(20 + r)
+        gws = {h: torch.randn(S_, {'mlp_offsets': 3, 'mlp_bounds': 3, 'mlp_bb_scores': 1, 'mlp_semantics': 20}[h]) for h in HEADS}
+        for p in net.parameters():
+            p.grad = None
+        out = net(ME.SparseTensor(batch['vox_features'], batch['vox_coords']), batch['pooling_ids'].cuda(), S_)
+        loss = sum((out[h].F * gws[h].cuda()).sum() for h in HEADS)
+        model.prefetch(batches[(r + 1) % 3], ready=True)         # third stream: the next batch's maps beside the backward pass
+        loss.backward()
+        # NO synchronize here: the gradients are read on the current stream, which backward's callback joined
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        model._prefetched = None
+        p32, o32 = _oracle_grads(sd, batch, gws, cfg, False, torch.float32)
+        for h in HEADS:
+            assert _rel(out[h].F, o32[h]) < 1e-3, (r, h, _rel(out[h].F, o32[h]))
+        rows = sorted(((_rel(grads[n], p32[n].grad), n) for n in grads), reverse=True)
+        assert len(rows) > 250
+        print('batch %d (%d voxels): worst gradient errors' % (r, batch['vox_coords'].shape[0]), rows[:3])
+        worst_all = max(worst_all, rows[0][0])
+        assert rows[0][0] < 1e-3, rows[:5]
+    print('worst relative gradient error over 3 batches: %.3e' % worst_all)
+
+
+def test_default_mode_train_batchnorm_many_scenes(monkeypatch):
+    """Train-mode BatchNorm, default mode, 48 small scenes: the deepest level keeps >= 48 rows, so the batch statistics are
+    well conditioned and the gradients can be held against the fp64 oracle directly: the GPU's error distribution must not
+    exceed the fp32 CPU oracle's by more than the stated factor."""
+    _default_env(monkeypatch)
+    from box2mask_amd.detection_net import SelectionNet
+    from box2mask_amd import nn as ME
+    cfg = scannet_config()
+    valid, _, _, is_fg = synth.scannet_tables()
+    torch.manual_seed(2)
+    net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6]).cuda().train()
+    batch = synth.make_batch(48, seed0=500, target_voxels=1500, pts_per_m2=6000.0)
+    S_ = batch['input_location'].shape[0]
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    torch.manual_seed(1)
+    gws = {h: torch.randn(S_, {'mlp_offsets': 3, 'mlp_bounds': 3, 'mlp_bb_scores': 1, 'mlp_semantics': 20}[h]) for h in HEADS}
+    sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'])
+    assert sin.manager.n(7) >= 48
+    out = net(sin, batch['pooling_ids'].cuda(), S_)
+    sum((out[h].F * gws[h].cuda()).sum() for h in HEADS).backward()
+    p32, o32 = _oracle_grads(sd, batch, gws, cfg, True, torch.float32)
+    p64, o64 = _oracle_grads(sd, batch, gws, cfg, True, torch.float64)
+    for h in HEADS:
+        assert _rel(out[h].F, o64[h]) < 1e-3, (h, _rel(out[h].F, o64[h]))
+    rows = []
+    for name, prm in net.named_parameters():
+        rows.append((_rel(prm.grad, p64[name].grad), _rel(p32[name].grad, p64[name].grad), name))
+    e_gpu = sorted(r[0] for r in rows); e_o32 = sorted(r[1] for r in rows)
+    q = lambda v, f: v[min(int(f * len(v)), len(v) - 1)]
+    print('gradient error vs fp64 (gpu | oracle32): median %.3e | %.3e, p90 %.3e | %.3e, max %.3e | %.3e'
+          % (q(e_gpu, .5), q(e_o32, .5), q(e_gpu, .9), q(e_o32, .9), e_gpu[-1], e_o32[-1]))
+    for r in sorted(rows, reverse=True)[:5]:
+        print('   worst: gpu %.3e oracle32 %.3e %s' % r)
+    assert q(e_gpu, .5) <= 2.0 * q(e_o32, .5)
+    assert q(e_gpu, .9) <= 2.0 * q(e_o32, .9)
+    assert e_gpu[-1] <= 2.0 * e_o32[-1]
+
+
+def test_default_mode_equals_deterministic_mode_on_a_block_chain(monkeypatch):
+    """conv-BN-ReLU-conv-BN (+1x1 shortcut-BN) add ReLU, twice, then the strided convolution and one more block on the
+    next level -- train-mode BatchNorm over tens of thousands of rows (no tiny levels): everything the default mode
+    adds (side stream, in-place pass-through accumulation, tile statistics, atomic combines) against the ordered
+    single-stream forms, <= 1e-4 on the output, the input gradient and every parameter gradient."""
+    from box2mask_amd import nn as ME
+    from box2mask_amd.resnet import BasicBlock
+    from box2mask_amd import functional as F_
+    from torch import nn
+    b = synth.make_batch(3, seed0=70, target_voxels=30000, pts_per_m2=8000.0)
+
+    class Chain(nn.Module):
+        def __init__(self):
+            super().__init__()
+            short = nn.Sequential(ME.MinkowskiConvolution(32, 64, kernel_size=1, dimension=3), ME.MinkowskiBatchNorm(64))
+            self.b0 = BasicBlock(32, 64, downsample=short, dimension=3)
+            self.b1 = BasicBlock(64, 64, dimension=3)
+            self.down = ME.MinkowskiConvolution(64, 64, kernel_size=2, stride=2, dimension=3)
+            self.bn = ME.MinkowskiBatchNorm(64)
+            self.b2 = BasicBlock(64, 64, dimension=3)
+            self.up = ME.MinkowskiConvolutionTranspose(64, 32, kernel_size=2, stride=2, dimension=3)
+            self.bnu = ME.MinkowskiBatchNorm(32)
+            short2 = nn.Sequential(ME.MinkowskiConvolution(96, 48, kernel_size=1, dimension=3), ME.MinkowskiBatchNorm(48))
+            self.b3 = BasicBlock(96, 48, downsample=short2, dimension=3)
+
+        def forward(self, x):
+            e = self.b1(self.b0(x))
+            d, e = self.down(e, passthrough=True)
+            d = d.new(self.bn.apply_bn(d.F, relu=True))
+            d = self.b2(d)
+            u = self.up(d)
+            u = u.new(self.bnu.apply_bn(u.F, relu=True))
+            y = self.b3(ME.cat(u, e))
+            ME.flush_batch_counters()
+            return y
+
+    def run():
+        from box2mask_amd import _lib
+        if hasattr(_lib, 'reload_env'):
+            _lib.reload_env()
+        torch.manual_seed(9)
+        net = Chain().cuda().train()
+        torch.manual_seed(10)
+        sin = ME.SparseTensor(torch.randn(b['vox_coords'].shape[0], 32), b['vox_coords'])
+        sin.F.requires_grad_(True)
+        F_.packed_weights.begin_pass()
+        y = net(sin).F
+        gy = torch.randn(y.shape, device='cuda')
+        (y * gy).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), sin.F.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()}
+
+    _default_env(monkeypatch)
+    assert F_.wgrad_on_side_stream()
+    y1, dx1, g1 = run()
+    y1b, dx1b, g1b = run()                                          # (a second default run: allocator reuse)
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    y0, dx0, g0 = run()
+    monkeypatch.delenv('B2M_DETERMINISTIC')
+    from box2mask_amd import _lib
+    if hasattr(_lib, 'reload_env'):
+        _lib.reload_env()
+    assert y1.shape[0] == b['vox_coords'].shape[0] and y1.shape[1] == 48
+    for what, (ya, da, ga) in (('default', (y1, dx1, g1)), ('default again', (y1b, dx1b, g1b))):
+        assert _rel(ya, y0) < 1e-4, (what, _rel(ya, y0))
+        assert _rel(da, dx0) < 1e-4, (what, _rel(da, dx0))
+        worst = max((_rel(ga[n], g0[n]), n) for n in g0)
+        print(what, 'output %.2e  input gradient %.2e  worst parameter gradient %.2e %s' % (_rel(ya, y0), _rel(da, dx0), worst[0], worst[1]))
+        assert worst[0] < 1e-4, (what, worst)
+
+
+def test_full_size_scene_forward_matches_oracle(monkeypatch):
+    """ONE 150 k-voxel scene (the metric's size), whole network, train-mode BatchNorm, default mode: every head and the
+    per-voxel trunk features against oracle/unet_ref.py within the north_star tolerance (1e-3 of the tensor's maximum).
+    The composition no per-layer test sees: epilogue statistics -> tile-statistics BatchNorm -> pass-through aliases ->
+    split maps exactly as they occur on a full scene."""
+    _default_env(monkeypatch)
+    from box2mask_amd.detection_net import SelectionNet
+    from box2mask_amd import nn as ME
+    from oracle import unet_ref
+    cfg = scannet_config()
+    valid, _, _, is_fg = synth.scannet_tables()
+    torch.manual_seed(0)
+    net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6]).cuda().train()
+    batch = synth.make_batch(1, seed0=0, target_voxels=150_000)
+    n = batch['vox_coords'].shape[0]
+    assert 135_000 <= n <= 165_000
+    S_ = batch['input_location'].shape[0]
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    net._trace = {}
+    with torch.no_grad():
+        sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'])
+        out = net(sin, batch['pooling_ids'].cuda(), S_)
+        trunk = net._trace['block8'][sin.manager.inv_perm] if sin.manager.inv_perm is not None else net._trace['block8']
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        ref = unet_ref.forward(sd, batch['vox_coords'].numpy(), batch['vox_features'], batch['pooling_ids'], cfg,
+                               training=True, n_segments=S_, return_trunk=True)
+    errs = {h: _rel(out[h].F, ref[h]) for h in HEADS}
+    errs['vox_feats'] = _rel(trunk, ref['_trunk'])
+    print('full-size scene (%d voxels, %d rows at level 7): rel errors %s' % (n, sin.manager.n(7), errs))
+    assert max(errs.values()) < 1e-3, errs

@@ -178,3 +178,54 @@ def test_single_process_is_a_noop():
     dp.all_reduce_mean()
     assert torch.equal(net.weight.grad, g)
     assert shard_scenes(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def test_arena_slot_is_handed_out_once_per_pass():
+    """Two forward passes summed into one backward, and a weight shared by two layers: the backward operator of one
+    parameter runs twice inside ONE backward() call; the second call must not receive the same arena slot (autograd would
+    add the view to itself: exactly 2x the gradient)."""
+    from box2mask_amd.grad_arena import GradArena, grad_slot
+
+    class ArenaLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, inp, w):
+            ctx.save_for_backward(inp, w)
+            return inp @ w
+
+        @staticmethod
+        def backward(ctx, g):
+            inp, w = ctx.saved_tensors
+            dw = grad_slot(w)
+            if dw is None:
+                dw = torch.zeros_like(w)
+            dw += inp.t() @ g
+            return g @ w.t(), dw
+
+    torch.manual_seed(3)
+    ws = [torch.nn.Parameter(torch.randn(6, 6) * 0.4) for _ in range(3)]
+    xa, xb = torch.randn(5, 6), torch.randn(7, 6)
+    arena = GradArena(ws)
+
+    def net(x, op):
+        h = x
+        for w_ in ws:
+            h = torch.tanh(op(h, w_))
+        return torch.tanh(op(h, ws[0])).pow(2).sum()          # ws[0] is shared by the first and the last layer
+
+    def forward(x):
+        arena.begin_pass()
+        return net(x, ArenaLinear.apply)
+    (forward(xa) + forward(xb)).backward()
+    ref = torch.autograd.grad(net(xa, torch.matmul) + net(xb, torch.matmul), ws)
+    for w_, r in zip(ws, ref):
+        assert torch.allclose(w_.grad, r, atol=1e-6), float((w_.grad / r).mean())
+    # the normal loop still lands in the arena
+    for w_ in ws:
+        w_.grad = None
+    arena.begin_pass()
+    h = xa
+    for w_ in ws:
+        h = torch.tanh(ArenaLinear.apply(h, w_))
+    h.sum().backward()
+    base = arena.buffers[arena.current].data_ptr()
+    assert all(w_.grad.data_ptr() == base + 4 * arena.offset[id(w_)] for w_ in ws)

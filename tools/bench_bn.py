@@ -5,7 +5,7 @@ import torch
 from box2mask_amd import _lib, functional as F_
 
 rec = []
-def hook(name, a):
+def hook(name, a, meta=None):
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True); s.record()
     def done():
         e.record(); rec.append((name, s, e))

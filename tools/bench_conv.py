@@ -9,7 +9,7 @@ flight), B2M_CONV_FAST32 / B2M_WGRAD_FAST32 (24-bit multiply addressing)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from box2mask_amd import synth, functional as F_
+from box2mask_amd import synth, functional as F_, _lib
 from box2mask_amd.sparse import CoordinateManager
 
 bs = int(os.environ.get('BS', '4'))
@@ -58,6 +58,7 @@ for name, rb, K, c1, c2, co in cases:
         for v, env in VARIANTS:
             for k_ in SWITCHES: os.environ.pop(k_, None)
             os.environ.update(env)
+            _lib.reload_env()
             wp = F_.weight_pack(w)          # the packed layout depends on the strip-width switch
             if rnd == 0: f_fwd(); f_wg(); torch.cuda.synchronize()
             res[v][0].append(timeit(f_fwd)); res[v][1].append(timeit(f_wg))

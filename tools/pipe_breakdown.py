@@ -3,7 +3,7 @@ what do the strip flush, the gathers and the weight loads cost on the level-0 96
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from box2mask_amd import synth, functional as F_
+from box2mask_amd import synth, functional as F_, _lib
 from box2mask_amd.sparse import CoordinateManager
 b = synth.make_batch(int(os.environ.get('BS', '4')), seed0=0)
 m = CoordinateManager(b['vox_coords'], reorder=True)
@@ -22,5 +22,6 @@ for rnd in range(2):
                       ('flow -weights', {'B2M_PIPE_DBG': '4'}), ('flow -gathers -weights', {'B2M_PIPE_DBG': '6'})]:
         for k in ('B2M_CONV_PIPE', 'B2M_PIPE_DBG'): os.environ.pop(k, None)
         os.environ.update(env)
+        _lib.reload_env()
         ms = t()
         print('%-26s %.3f ms  %.1f TFLOP/s' % (name, ms, fl / ms / 1e9))
