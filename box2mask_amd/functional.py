@@ -458,6 +458,7 @@ class _BatchNorm(torch.autograd.Function):
                                   scale if ctx.mask_from_x else None, shift if ctx.mask_from_x else None, beta)
         else:
             ctx.save_for_backward(x, y if relu else None, gamma, scale, None, None, None, beta)
+            ctx.eval_mean, ctx.eval_var, ctx.eval_eps = running_mean, running_var, eps
         return y
 
     @staticmethod
@@ -472,9 +473,18 @@ class _BatchNorm(torch.autograd.Function):
         if not ctx.training:
             # eval-mode BN is an affine map: dx = scale * g (mean holds `scale` here)
             g = dy if not relu else dy * (y > 0)
-            dx = g * mean.reshape(1, -1)
+            scale = mean.reshape(1, -1)
+            dx = g * scale
             gres = None if dres is None else (g.clone() if g is dy else g)       # (never the incoming tensor itself)
-            return _own(dx), None, None, None, None, None, None, None, _own(gres), None, None, None, None
+            dgamma = dbeta = None
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                # y = gamma * x_hat + beta with x_hat = (x - running_mean) / sqrt(running_var + eps): the affine parameters
+                # have gradients in eval mode too (torch.nn.BatchNorm1d gives them)
+                dbeta = g.sum(0)
+                invstd = torch.rsqrt(ctx.eval_var + ctx.eval_eps)
+                dgamma = ((g * x).sum(0) - dbeta * ctx.eval_mean) * invstd
+            return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                    None, None, None, None, None, _own(gres), None, None, None, None)
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned
