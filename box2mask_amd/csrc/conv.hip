@@ -1134,6 +1134,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
             }
 }
 
+// Weight gradient of an identity map (1x1 layer) with FEW output channels -- the last layer of every head (96 -> 3 / 1 /
+// 20 on the batch's segments): dW[ci][co] = sum_r x[r][ci] * dy[r][co] is a skinny reduction, not a GEMM.  The MFMA
+// kernels pad the output channels to 16 and, with a row pitch below 16 floats, fell back to scalar addressing: 87-128 us
+// per launch at 0.02-0.3 TFLOP/s (round 2).  Here a workgroup takes a chunk of rows, stages their dy in LDS, and thread
+// (part, ci) keeps the CO sums of its input channel in registers over its share of the rows (x is read coalesced, the dy
+// values are LDS broadcasts); one atomic per dW element and workgroup at the end.
+#define WGN_ROWS 128
+template <int CO>
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restrict__ x, int64_t ldx, int cin,
+                                                           const float* __restrict__ dy, int64_t lddy, int cout, int64_t n,
+                                                           float* __restrict__ dw, int64_t lddw) {
+    __shared__ float sdy[WGN_ROWS * CO];
+    const int64_t r0 = (int64_t)blockIdx.x * WGN_ROWS;
+    const int rows = (int)((n - r0) < WGN_ROWS ? (n - r0) : WGN_ROWS);
+    for (int e = threadIdx.x; e < rows * CO; e += 256) {
+        const int r = e / CO, co = e % CO;
+        sdy[e] = co < cout ? dy[(r0 + r) * lddy + co] : 0.f;
+    }
+    __syncthreads();
+    const int nparts = 256 / cin > 0 ? 256 / cin : 1;           // row shares per input channel
+    for (int ci0 = 0; ci0 < cin; ci0 += 256) {                  // (cin <= 256: one round)
+        const int ci = ci0 + (int)threadIdx.x % (cin < 256 ? cin : 256);
+        const int part = (int)threadIdx.x / (cin < 256 ? cin : 256);
+        if (ci >= cin || part >= nparts) continue;
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+        for (int r = part; r < rows; r += nparts) {
+            const float xv = x[(r0 + r) * ldx + ci];
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[co] = __builtin_fmaf(xv, sdy[r * CO + co], acc[co]);
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+            if (co < cout && acc[co] != 0.f) atomicAdd(&dw[(int64_t)ci * lddw + co], acc[co]);
+    }
+}
+
 template <int MI>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
     if (a.pipe) {
@@ -1199,6 +1237,16 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     static const float* zeros_addr = nullptr;
     if (!zeros_addr) B2M_HIP(hipGetSymbolAddress((void**)&zeros_addr, HIP_SYMBOL(g_zeros)));
     a.zeros = zeros_addr;
+    // 1x1 layer with few output channels (the heads' last layers): a plain reduction, see wgrad_narrow_kernel
+    if (rb_in == nullptr && cout <= 32 && cout % 16 != 0 && cin <= 1024 && !workspace && n_in >= n_out && env_flag("B2M_WGRAD_NARROW", 1)) {
+        const unsigned g = (unsigned)cdiv64(n_out, WGN_ROWS);
+        if (cout <= 4) wgrad_narrow_kernel<4><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
+        else if (cout <= 8) wgrad_narrow_kernel<8><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
+        else if (cout <= 16) wgrad_narrow_kernel<16><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
+        else wgrad_narrow_kernel<32><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
+        B2M_LAUNCH_CHECK();
+        return B2M_OK;
+    }
     const int MI = pick_blk(cin), NJ = pick_blk(cout);
     a.nmb = (cin + 16 * MI - 1) / (16 * MI);
     a.nnb = (cout + 16 * NJ - 1) / (16 * NJ);
@@ -1215,7 +1263,9 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     int64_t tpc = cdiv64(a.ntiles, want_chunks);
     // (floor 8 from 32 tiles up: level-3 128->128 58 -> 66, level-4 256->256 58 -> 67 TFLOP/s; the 11-tile level-5 maps lose
     // a quarter with it and keep 4)
-    const int min_tiles = env_flag("B2M_WGRAD_MIN_TILES", a.ntiles >= 32 ? 8 : 4);
+    // (identity maps of a few hundred tiles -- the heads' 96 -> 96 layers on ~10 k segments: 8-tile chunks left 20 workgroups
+    // on 256 CUs, 40 us per launch; one block's atomics per 2 tiles are nothing against that)
+    const int min_tiles = env_flag("B2M_WGRAD_MIN_TILES", (rb_in == nullptr && a.ntiles <= 1024) ? 2 : a.ntiles >= 32 ? 8 : 4);
     if (tpc < min_tiles) tpc = min_tiles;
     { int mx = env_flag("B2M_WGRAD_MAX_TILES", large ? 32 : 64); if (mx < 1) mx = 1; if (mx > 64) mx = 64; if (tpc > mx) tpc = mx; }
     // Deterministic mode (workspace given): at most B2M_WGRAD_DET_CHUNKS tile chunks, every chunk stores its partial

@@ -456,6 +456,363 @@ extern "C" int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, i
     return B2M_OK;
 }
 
+// ------------------------------------------------------------------ two BatchNorms that meet in one add
+// The last step of a BasicBlock with a shortcut convolution: y = relu(BN_a(conv2 out) + BN_b(1x1 shortcut out))
+// (/root/reference/models/resnet.py:73-82).  As two BatchNorm launches the shortcut's normalised tensor is written and
+// read back (2T of traffic), and backward writes the residual gradient g = dy * (y > 0) for the shortcut's BatchNorm to
+// read twice (3T).  Both normalisations depend on nothing but their own input, and both backward reductions need only
+// g, so: one apply over (x_a, x_b), one reduction for (sum g, sum g*xhat_a, sum g*xhat_b), one apply for (dx_a, dx_b) --
+// and under SyncBN ONE packed all-reduce per direction for the pair instead of two.
+__global__ __launch_bounds__(256) void bn_apply2_kernel(const float* __restrict__ xa, int64_t lda, const float* __restrict__ xb,
+                                                        int64_t ldb, int64_t n, int c4, const float* __restrict__ sa,
+                                                        const float* __restrict__ ba, const float* __restrict__ sb,
+                                                        const float* __restrict__ bb, int relu, float* __restrict__ y,
+                                                        int64_t ldy) {
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    if (rs >= nslots) return;
+    const f32x4 s1 = *(const f32x4*)(sa + cg * 4), b1 = *(const f32x4*)(ba + cg * 4);
+    const f32x4 s2 = *(const f32x4*)(sb + cg * 4), b2 = *(const f32x4*)(bb + cg * 4);
+    for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
+        f32x4 v = *(const f32x4*)(xa + r * lda + cg * 4);
+        f32x4 w = *(const f32x4*)(xb + r * ldb + cg * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {        // exactly the two roundings of the separate launches: fma, fma, add
+            v[u] = __builtin_fmaf(v[u], s1[u], b1[u]);
+            w[u] = __builtin_fmaf(w[u], s2[u], b2[u]);
+            v[u] = v[u] + w[u];
+            if (relu) v[u] = v[u] > 0.f ? v[u] : 0.f;
+        }
+        *(f32x4*)(y + r * ldy + cg * 4) = v;
+    }
+}
+extern "C" int b2m_bn_apply2(const float* xa, int64_t lda, const float* xb, int64_t ldb, int64_t n, int32_t c,
+                             const float* scale_a, const float* shift_a, const float* scale_b, const float* shift_b,
+                             int32_t relu, float* y, int64_t ldy, void* stream) {
+    B2M_CHECK_ARG(xa && xb && y && scale_a && shift_a && scale_b && shift_b && c > 0 && c % 4 == 0 && c <= 1024 &&
+                      lda % 4 == 0 && ldb % 4 == 0 && ldy % 4 == 0, "c and leading dimensions must be multiples of 4, c <= 1024");
+    if (n == 0) return B2M_OK;
+    bn_apply2_kernel<<<row_grid(n, c / 4), 256, 0, (hipStream_t)stream>>>(xa, lda, xb, ldb, n, c / 4, scale_a, shift_a, scale_b,
+                                                                          shift_b, relu, y, ldy);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+// backward reduction of the pair: partial[blk][3c] = (sum g, sum g*xhat_a, sum g*xhat_b), g = dy * (y > 0 if relu).
+// Same thread -> (column group, row slot) mapping, row ranges and summation order as column_reduce_staged, so the first two
+// sums are bit for bit those of bn_bwd_reduce_kernel on (dy, y, x_a).
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                             const float* __restrict__ y, int64_t ldy,
+                                                             const float* __restrict__ xa, int64_t lda,
+                                                             const float* __restrict__ xb, int64_t ldb, int64_t n, int c,
+                                                             const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
+                                                             const float* __restrict__ mean_b, const float* __restrict__ invstd_b,
+                                                             int relu, double* __restrict__ partial) {
+    extern __shared__ float red[];             // [nslots][c4][12]
+    const int c4 = c >> 2;
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    const int64_t rows_per_blk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > n) r1 = n;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (rs < nslots) {
+        const f32x4 ma = *(const f32x4*)(mean_a + cg * 4), ia = *(const f32x4*)(invstd_a + cg * 4);
+        const f32x4 mb = *(const f32x4*)(mean_b + cg * 4), ib = *(const f32x4*)(invstd_b + cg * 4);
+        auto term = [&](const f32x4& g0, const f32x4& yy, const f32x4& va, const f32x4& vb) {
+            f32x4 g = g0;
+            if (relu) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
+            }
+            s0 += g; s1 += g * ((va - ma) * ia); s2 += g * ((vb - mb) * ib);
+        };
+        int64_t r = r0 + rs;
+        for (; r + 3 * nslots < r1; r += 4 * nslots) {
+            f32x4 in[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r + (int64_t)u * nslots;
+                in[u][0] = *(const f32x4*)(dy + rr * lddy + cg * 4);
+                in[u][1] = *(const f32x4*)(y + rr * ldy + cg * 4);
+                in[u][2] = *(const f32x4*)(xa + rr * lda + cg * 4);
+                in[u][3] = *(const f32x4*)(xb + rr * ldb + cg * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) term(in[u][0], in[u][1], in[u][2], in[u][3]);
+        }
+        for (; r < r1; r += nslots)
+            term(*(const f32x4*)(dy + r * lddy + cg * 4), *(const f32x4*)(y + r * ldy + cg * 4),
+                 *(const f32x4*)(xa + r * lda + cg * 4), *(const f32x4*)(xb + r * ldb + cg * 4));
+        float* p = red + ((size_t)rs * c4 + cg) * 12;
+        *(f32x4*)p = s0; *(f32x4*)(p + 4) = s1; *(f32x4*)(p + 8) = s2;
+    }
+    __syncthreads();
+    if (rs == 0) {
+        double d[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s_ = 0; s_ < nslots; ++s_) {
+            const float* p = red + ((size_t)s_ * c4 + cg) * 12;
+#pragma unroll
+            for (int u = 0; u < 12; ++u) d[u] += (double)p[u];
+        }
+        double* o = partial + (size_t)blockIdx.x * 3 * c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[cg * 4 + u] = d[u]; o[c + cg * 4 + u] = d[4 + u]; o[2 * c + cg * 4 + u] = d[8 + u]; }
+    }
+}
+extern "C" int b2m_bn_bwd_reduce2(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* xa, int64_t lda,
+                                  const float* xb, int64_t ldb, int64_t n, int32_t c, const float* mean_a,
+                                  const float* invstd_a, const float* mean_b, const float* invstd_b, int32_t relu,
+                                  double* partial, double* sums, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(dy && y && xa && xb && mean_a && invstd_a && mean_b && invstd_b && partial && sums, "NULL argument");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldy % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0,
+                  "c and leading dimensions must be multiples of 4");
+    const int nblk = reduce_blocks(n);
+    const int c4 = c / 4, nslots = 256 / c4;
+    bn_bwd_reduce2_kernel<<<nblk, 256, (size_t)nslots * c4 * 12 * sizeof(float), st>>>(dy, lddy, y, ldy, xa, lda, xb, ldb, n, c,
+        mean_a, invstd_a, mean_b, invstd_b, relu, partial);
+    reduce_final_kernel<<<3 * c, 64, 0, st>>>(partial, nblk, 3 * c, sums, nullptr, nullptr);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ y, int64_t ldy,
+                                                            const float* __restrict__ xa, int64_t lda,
+                                                            const float* __restrict__ xb, int64_t ldb, int64_t n, int c,
+                                                            const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
+                                                            const float* __restrict__ gamma_a, const float* __restrict__ mean_b,
+                                                            const float* __restrict__ invstd_b, const float* __restrict__ gamma_b,
+                                                            const double* __restrict__ sums, double count_host,
+                                                            const double* __restrict__ count_dev, int relu,
+                                                            float* __restrict__ dxa, int64_t lddxa, float* __restrict__ dxb,
+                                                            int64_t lddxb, float* __restrict__ dbeta_a, float* __restrict__ dgamma_a,
+                                                            float* __restrict__ dbeta_b, float* __restrict__ dgamma_b) {
+    const int c4 = c >> 2;
+    const float inv_n = (float)(1.0 / (count_dev ? *count_dev : count_host));
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    if (rs >= nslots) return;
+    const f32x4 ma = *(const f32x4*)(mean_a + cg * 4), ia = *(const f32x4*)(invstd_a + cg * 4);
+    const f32x4 mb = *(const f32x4*)(mean_b + cg * 4), ib = *(const f32x4*)(invstd_b + cg * 4);
+    f32x4 sg, sga, sgb, ga, gb;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = cg * 4 + u;
+        sg[u] = (float)sums[j] * inv_n; sga[u] = (float)sums[c + j] * inv_n; sgb[u] = (float)sums[2 * c + j] * inv_n;
+        ga[u] = (gamma_a ? gamma_a[j] : 1.f) * ia[u]; gb[u] = (gamma_b ? gamma_b[j] : 1.f) * ib[u];
+        if (blockIdx.x == 0 && rs == 0) {        // the parameter gradients (fp32 copies of the global sums)
+            if (dbeta_a) dbeta_a[j] = (float)sums[j];
+            if (dbeta_b) dbeta_b[j] = (float)sums[j];
+            if (dgamma_a) dgamma_a[j] = (float)sums[c + j];
+            if (dgamma_b) dgamma_b[j] = (float)sums[2 * c + j];
+        }
+    }
+    for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
+        f32x4 g = *(const f32x4*)(dy + r * lddy + cg * 4);
+        const f32x4 va = *(const f32x4*)(xa + r * lda + cg * 4), vb = *(const f32x4*)(xb + r * ldb + cg * 4);
+        if (relu) {
+            const f32x4 yy = *(const f32x4*)(y + r * ldy + cg * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
+        }
+        f32x4 oa, ob;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            oa[u] = ga[u] * (g[u] - sg[u] - ((va[u] - ma[u]) * ia[u]) * sga[u]);
+            ob[u] = gb[u] * (g[u] - sg[u] - ((vb[u] - mb[u]) * ib[u]) * sgb[u]);
+        }
+        *(f32x4*)(dxa + r * lddxa + cg * 4) = oa;
+        *(f32x4*)(dxb + r * lddxb + cg * 4) = ob;
+    }
+}
+extern "C" int b2m_bn_bwd_apply2(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* xa, int64_t lda,
+                                 const float* xb, int64_t ldb, int64_t n, int32_t c, const float* mean_a,
+                                 const float* invstd_a, const float* gamma_a, const float* mean_b, const float* invstd_b,
+                                 const float* gamma_b, const double* sums, double count, const double* count_dev,
+                                 int32_t relu, float* dxa, int64_t lddxa, float* dxb, int64_t lddxb, float* dbeta_a,
+                                 float* dgamma_a, float* dbeta_b, float* dgamma_b, void* stream) {
+    B2M_CHECK_ARG(dy && y && xa && xb && mean_a && invstd_a && mean_b && invstd_b && sums && dxa && dxb, "NULL argument");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldy % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+                      lddxa % 4 == 0 && lddxb % 4 == 0 && (count_dev || count >= 1),
+                  "c and leading dimensions must be multiples of 4");
+    if (n == 0) return B2M_OK;
+    bn_bwd_apply2_kernel<<<row_grid(n, c / 4), 256, 0, (hipStream_t)stream>>>(dy, lddy, y, ldy, xa, lda, xb, ldb, n, c, mean_a,
+        invstd_a, gamma_a, mean_b, invstd_b, gamma_b, sums, count, count_dev, relu, dxa, lddxa, dxb, lddxb, dbeta_a, dgamma_a,
+        dbeta_b, dgamma_b);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ BatchNorm of small maps in ONE launch
+// The deep U-Net levels (a few hundred to a few thousand rows) and the heads' segment rows: the tensors live in L2, and the
+// five launches per layer (statistics, their final sum + finalize, apply; backward: reduce, final sum, apply) were latency,
+// not bandwidth -- 38 of the 89 BatchNorm layers of a ScanNet step have <= 4 k rows.  Here one workgroup owns FOUR
+// channels (one 16-byte column group) for ALL rows: pass 1 sums in fp64 per thread (thread = row slot, fixed order), the
+// block combines in a fixed tree, the finalize math runs in the block, pass 2 re-reads the rows (L2 hits) and writes.
+// Deterministic; the statistics are fp64 sums of the fp32 inputs exactly like the two-stage kernels (other grouping).
+#define BN_SMALL_THREADS 256
+// block-wide sum of NV doubles per thread -> every thread gets the totals (fixed order: lanes by shuffle, waves in order)
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sh /* [4][NV] */) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        double t = v[u];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d, 64);
+        v[u] = t;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                                    // (sh may still be read from a previous use)
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) sh[wave * NV + u] = v[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NV; ++u) v[u] = (sh[u] + sh[NV + u]) + (sh[2 * NV + u] + sh[3 * NV + u]);
+}
+__global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_fwd_kernel(
+        const float* __restrict__ x, int64_t ldx, int n, int c, const float* __restrict__ gamma, const float* __restrict__ beta,
+        float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+        float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+        const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ y, int64_t ldy) {
+    __shared__ double sh[4 * 8];
+    __shared__ float sc[8];
+    const int col = blockIdx.x * 4;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = threadIdx.x; r < n; r += BN_SMALL_THREADS) {
+        const f32x4 v = *(const f32x4*)(x + (int64_t)r * ldx + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const double d = (double)v[u]; s[u] += d; s[4 + u] = fma(d, d, s[4 + u]); }
+    }
+    block_sum<8>(s, sh);
+    if (threadIdx.x < 4) {
+        const int j = col + threadIdx.x, u = threadIdx.x;
+        const double count = (double)n;
+        const double m = s[u] / count;
+        double var = s[4 + u] / count - m * m;
+        if (var < 0) var = 0;
+        if (running_mean) {
+            const double unb = count > 1 ? var * count / (count - 1) : var;
+            running_mean[j] = (float)((1.0 - momentum) * (double)running_mean[j] + momentum * m);
+            running_var[j] = (float)((1.0 - momentum) * (double)running_var[j] + momentum * unb);
+        }
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma ? (double)gamma[j] : 1.0, b = beta ? (double)beta[j] : 0.0;
+        mean[j] = (float)m; invstd[j] = (float)is;
+        const float fs = (float)(g * is), fb = (float)(b - m * g * is);
+        scale[j] = fs; shift[j] = fb;
+        sc[u] = fs; sc[4 + u] = fb;
+    }
+    __syncthreads();
+    f32x4 a, b;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = sc[u]; b[u] = sc[4 + u]; }
+    for (int r = threadIdx.x; r < n; r += BN_SMALL_THREADS) {
+        f32x4 v = *(const f32x4*)(x + (int64_t)r * ldx + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_fmaf(v[u], a[u], b[u]);       // (the backward recomputes this sign)
+        if (res) v += *(const f32x4*)(res + (int64_t)r * ldr + col);
+        if (relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = v[u] > 0.f ? v[u] : 0.f;
+        }
+        *(f32x4*)(y + (int64_t)r * ldy + col) = v;
+    }
+}
+extern "C" int b2m_bn_small_fwd(const float* x, int64_t ldx, int64_t n, int32_t c, const float* gamma, const float* beta,
+                                float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                float* invstd, float* scale, float* shift, const float* residual, int64_t ldr, int32_t relu,
+                                float* y, int64_t ldy, void* stream) {
+    B2M_CHECK_ARG(x && y && mean && invstd && scale && shift && n >= 1 && n <= B2M_BN_SMALL_MAX_ROWS, "bad arguments / too many rows");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) && ldx >= c && ldy >= c,
+                  "c and leading dimensions must be multiples of 4");
+    B2M_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)residual % 16) == 0, "16-byte alignment");
+    B2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics: both or none");
+    bn_small_fwd_kernel<<<c / 4, BN_SMALL_THREADS, 0, (hipStream_t)stream>>>(x, ldx, (int)n, c, gamma, beta, eps, momentum,
+        running_mean, running_var, mean, invstd, scale, shift, residual, ldr, relu, y, ldy);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+template <bool RELU, bool HASY>
+__global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_bwd_kernel(
+        const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy, const float* __restrict__ x,
+        int64_t ldx, int n, int c, const float* __restrict__ mean, const float* __restrict__ invstd,
+        const float* __restrict__ gamma, const float* __restrict__ mscale, const float* __restrict__ mshift,
+        float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ dx, int64_t lddx,
+        float* __restrict__ dres, int64_t lddres) {
+    __shared__ double sh[4 * 8];
+    const int col = blockIdx.x * 4;
+    const f32x4 m = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
+    f32x4 ms = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
+    if (RELU && !HASY) { ms = *(const f32x4*)(mscale + col); mb = *(const f32x4*)(mshift + col); }
+    auto masked = [&](int r, f32x4& g, f32x4& xx) {
+        g = *(const f32x4*)(dy + (int64_t)r * lddy + col);
+        xx = *(const f32x4*)(x + (int64_t)r * ldx + col);
+        if constexpr (RELU) {
+            f32x4 yy;
+            if constexpr (HASY) yy = *(const f32x4*)(y + (int64_t)r * ldy + col);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yy[u] = __builtin_fmaf(xx[u], ms[u], mb[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
+        }
+    };
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = threadIdx.x; r < n; r += BN_SMALL_THREADS) {
+        f32x4 g, xx;
+        masked(r, g, xx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[u] += (double)g[u]; s[4 + u] += (double)(g[u] * ((xx[u] - m[u]) * is[u])); }
+    }
+    block_sum<8>(s, sh);
+    if (threadIdx.x < 4) {
+        if (dbeta) dbeta[col + threadIdx.x] = (float)s[threadIdx.x];
+        if (dgamma) dgamma[col + threadIdx.x] = (float)s[4 + threadIdx.x];
+    }
+    const float inv_n = (float)(1.0 / (double)n);
+    f32x4 sg, sgx, ga;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        sg[u] = (float)s[u] * inv_n; sgx[u] = (float)s[4 + u] * inv_n;
+        ga[u] = (gamma ? gamma[col + u] : 1.f) * is[u];
+    }
+    for (int r = threadIdx.x; r < n; r += BN_SMALL_THREADS) {
+        f32x4 g, xx, out;
+        masked(r, g, xx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xh = (xx[u] - m[u]) * is[u];
+            out[u] = ga[u] * (g[u] - sg[u] - xh * sgx[u]);
+        }
+        *(f32x4*)(dx + (int64_t)r * lddx + col) = out;
+        if (dres) *(f32x4*)(dres + (int64_t)r * lddres + col) = g;
+    }
+}
+extern "C" int b2m_bn_small_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                                int64_t n, int32_t c, const float* mean, const float* invstd, const float* gamma, int32_t relu,
+                                const float* mask_scale, const float* mask_shift, float* dbeta_f32, float* dgamma_f32,
+                                float* dx, int64_t lddx, float* dres, int64_t lddres, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(dy && x && mean && invstd && dx && (!relu || y || (mask_scale && mask_shift)) && n >= 1 &&
+                      n <= B2M_BN_SMALL_MAX_ROWS, "NULL argument / too many rows");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!(relu && y) || ldy % 4 == 0) &&
+                      (!dres || lddres % 4 == 0), "c and leading dimensions must be multiples of 4");
+    B2M_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
+                      ((uintptr_t)y % 16) == 0 && ((uintptr_t)dres % 16) == 0, "16-byte alignment");
+    const dim3 grid(c / 4);
+    if (!relu) bn_small_bwd_kernel<false, false><<<grid, BN_SMALL_THREADS, 0, st>>>(dy, lddy, nullptr, 0, x, ldx, (int)n, c, mean, invstd, gamma, nullptr, nullptr, dbeta_f32, dgamma_f32, dx, lddx, dres, lddres);
+    else if (y) bn_small_bwd_kernel<true, true><<<grid, BN_SMALL_THREADS, 0, st>>>(dy, lddy, y, ldy, x, ldx, (int)n, c, mean, invstd, gamma, nullptr, nullptr, dbeta_f32, dgamma_f32, dx, lddx, dres, lddres);
+    else bn_small_bwd_kernel<true, false><<<grid, BN_SMALL_THREADS, 0, st>>>(dy, lddy, nullptr, 0, x, ldx, (int)n, c, mean, invstd, gamma, mask_scale, mask_shift, dbeta_f32, dgamma_f32, dx, lddx, dres, lddres);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 // ------------------------------------------------------------------ elementwise
 __global__ void relu_fwd_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {

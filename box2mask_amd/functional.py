@@ -350,6 +350,12 @@ def conv_tile_stats() -> bool:
     return os.environ.get('B2M_CONV_STATS', '1') == '1'
 
 
+def bn_small_rows() -> int:
+    """B2M_BN_SMALL_ROWS: training-mode BatchNorm of maps with at most this many rows runs as ONE launch each way
+    (b2m_bn_small_fwd / _bwd; 0 switches it off).  Not under SyncBN."""
+    return int(os.environ.get('B2M_BN_SMALL_ROWS', '4096'))
+
+
 def conv_passthrough() -> bool:
     """B2M_CONV_PASSTHROUGH=0: residual / shortcut branches take the block input itself and autograd adds the two
     gradients of that input with a kernel of its own."""
@@ -410,11 +416,23 @@ class _BatchNorm(torch.autograd.Function):
         shift = torch.empty(c, dtype=torch.float32, device=dev)
         mean = invstd = count_dev = None
         count = float(n)
+        small = False
         if training:
-            partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             invstd = torch.empty(c, dtype=torch.float32, device=dev)
             group = _sync_group() if sync else None
+            small = group is None and n <= bn_small_rows() and c % 4 == 0 and x.stride(0) % 4 == 0
+        if small:
+            # few rows (deep levels, the heads): statistics + finalize + apply in ONE launch (b2m_bn_small_fwd)
+            if residual is not None:
+                residual = _f32c(residual)
+            y = torch.empty_like(x)
+            _call('b2m_bn_small_fwd', x.data_ptr(), x.stride(0), n, c, _ptr(gamma), _ptr(beta), eps, momentum,
+                  _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                  shift.data_ptr(), _ptr(residual), residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                  y.data_ptr(), y.stride(0))
+        elif training:
+            partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
             if tile_stats is not None and (tile_stats[0].shape[2] != c or tile_stats[1] != (n + 63) // 64):
                 tile_stats = None                  # not this tensor's sums
             if group is None:
@@ -443,12 +461,14 @@ class _BatchNorm(torch.autograd.Function):
         else:
             _call('b2m_bn_finalize', None, 1.0, None, c, _ptr(gamma), _ptr(beta), eps, momentum, running_mean.data_ptr(),
                   running_var.data_ptr(), None, None, scale.data_ptr(), shift.data_ptr())
-        if residual is not None:
-            residual = _f32c(residual)
-        y = torch.empty_like(x)
-        _call('b2m_bn_apply', x.data_ptr(), x.stride(0), n, c, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
-              residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
+        if not small:
+            if residual is not None:
+                residual = _f32c(residual)
+            y = torch.empty_like(x)
+            _call('b2m_bn_apply', x.data_ptr(), x.stride(0), n, c, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
+                  residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
         ctx.training, ctx.relu, ctx.count, ctx.sync, ctx.count_dev = training, relu, count, sync, count_dev
+        ctx.small = small
         ctx.has_res = residual is not None
         if training:
             # without a fused residual the ReLU mask is the sign of fmaf(x, scale, shift): the backward recomputes it
@@ -485,13 +505,20 @@ class _BatchNorm(torch.autograd.Function):
                 dgamma = ((g * x).sum(0) - dbeta * ctx.eval_mean) * invstd
             return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
                     None, None, None, None, None, _own(gres), None, None, None, None)
-        partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
-        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned
         dbeta, dgamma = grad_slot(beta), grad_slot(gamma)
         if dbeta is None or dgamma is None:
             dbeta = torch.empty(c, dtype=torch.float32, device=dev)
             dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        if ctx.small and dy.stride(0) % 4 == 0:
+            _call('b2m_bn_small_bwd', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
+                  x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), relu, _ptr(mscale), _ptr(mshift),
+                  dbeta.data_ptr(), dgamma.data_ptr(), dx.data_ptr(), dx.stride(0), _ptr(dres),
+                  dres.stride(0) if dres is not None else 0)
+            return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                    None, None, None, None, None, _own(dres), None, None, None, None)
+        partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _ptr(mscale), _ptr(mshift),
               partial.data_ptr(), sums.data_ptr(), dbeta.data_ptr(), dgamma.data_ptr())
@@ -506,6 +533,135 @@ class _BatchNorm(torch.autograd.Function):
               dres.stride(0) if dres is not None else 0)
         return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
                 None, None, None, None, None, _own(dres), None, None, None, None)
+
+
+def bn_pair() -> bool:
+    """B2M_BN_PAIR=0: the two BatchNorms at the end of a BasicBlock with a shortcut convolution run as two launches
+    (the shortcut's normalised tensor is stored and read back, two SyncBN exchanges per direction) instead of as one
+    paired operator (_BatchNormPair)."""
+    return os.environ.get('B2M_BN_PAIR', '1') == '1'
+
+
+class _BatchNormPair(torch.autograd.Function):
+    """y = relu?(BN_a(x_a) + BN_b(x_b)): norm2 + downsample.1 + add + ReLU of a BasicBlock
+    (/root/reference/models/resnet.py:73-82) as one operator.  Neither normalisation depends on the other, and both
+    backward reductions need only g = dy * (y > 0): one apply, one reduction (sum g, sum g*xhat_a, sum g*xhat_b), one
+    backward apply -- and under SyncBN ONE packed all-reduce per direction for the two layers."""
+
+    @staticmethod
+    def forward(ctx, xa, ga, ba, rma, rva, xb, gb, bb, rmb, rvb, training, mom_a, eps_a, mom_b, eps_b, relu, sync,
+                tile_stats_a=None, tile_stats_b=None):
+        xa, xb = _f32c(xa), _f32c(xb)
+        n, c = xa.shape
+        assert xb.shape == (n, c)
+        dev = xa.device
+        f32 = lambda: torch.empty(c, dtype=torch.float32, device=dev)
+        sca, sha, scb, shb = f32(), f32(), f32(), f32()
+        mean_a = inv_a = mean_b = inv_b = count_dev = None
+        if training:
+            mean_a, inv_a, mean_b, inv_b = f32(), f32(), f32(), f32()
+            partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
+            group = _sync_group() if sync else None
+            sides = ((xa, ga, ba, rma, rva, mom_a, eps_a, mean_a, inv_a, sca, sha, tile_stats_a),
+                     (xb, gb, bb, rmb, rvb, mom_b, eps_b, mean_b, inv_b, scb, shb, tile_stats_b))
+            if group is None:
+                for x, g, b, rm, rv, mom, eps, mean, inv, sc, sh, ts in sides:
+                    if ts is not None and (ts[0].shape[2] != c or ts[1] != (n + 63) // 64):
+                        ts = None
+                    if ts is not None:
+                        _call('b2m_bn_tilestats_finalize', ts[0].data_ptr(), ts[1], n, c, partial.data_ptr(), None, _ptr(g),
+                              _ptr(b), eps, mom, _ptr(rm), _ptr(rv), mean.data_ptr(), inv.data_ptr(), sc.data_ptr(),
+                              sh.data_ptr())
+                    else:
+                        _call('b2m_bn_stats_finalize', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), None, _ptr(g),
+                              _ptr(b), eps, mom, _ptr(rm), _ptr(rv), mean.data_ptr(), inv.data_ptr(), sc.data_ptr(),
+                              sh.data_ptr())
+            else:
+                # SyncBN: the local column sums of BOTH layers and the local row count in one packed all-reduce
+                stats = torch.empty(4 * c + 1, dtype=torch.float64, device=dev)
+                for j, (x, g, b, rm, rv, mom, eps, mean, inv, sc, sh, ts) in enumerate(sides):
+                    if ts is not None and (ts[0].shape[2] != c or ts[1] != (n + 63) // 64):
+                        ts = None
+                    dst = stats.data_ptr() + 8 * 2 * c * j
+                    if ts is not None:
+                        _call('b2m_bn_tilestats', ts[0].data_ptr(), ts[1], c, partial.data_ptr(), dst)
+                    else:
+                        _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), dst)
+                stats[4 * c:].fill_(float(n))
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+                count_dev = stats[4 * c:]
+                for j, (x, g, b, rm, rv, mom, eps, mean, inv, sc, sh, ts) in enumerate(sides):
+                    _call('b2m_bn_finalize', stats.data_ptr() + 8 * 2 * c * j, 0.0, count_dev.data_ptr(), c, _ptr(g), _ptr(b),
+                          eps, mom, _ptr(rm), _ptr(rv), mean.data_ptr(), inv.data_ptr(), sc.data_ptr(), sh.data_ptr())
+        else:
+            _call('b2m_bn_finalize', None, 1.0, None, c, _ptr(ga), _ptr(ba), eps_a, mom_a, rma.data_ptr(), rva.data_ptr(),
+                  None, None, sca.data_ptr(), sha.data_ptr())
+            _call('b2m_bn_finalize', None, 1.0, None, c, _ptr(gb), _ptr(bb), eps_b, mom_b, rmb.data_ptr(), rvb.data_ptr(),
+                  None, None, scb.data_ptr(), shb.data_ptr())
+        y = torch.empty_like(xa)
+        _call('b2m_bn_apply2', xa.data_ptr(), xa.stride(0), xb.data_ptr(), xb.stride(0), n, c, sca.data_ptr(), sha.data_ptr(),
+              scb.data_ptr(), shb.data_ptr(), 1 if relu else 0, y.data_ptr(), y.stride(0))
+        ctx.training, ctx.relu, ctx.sync, ctx.count, ctx.count_dev = training, relu, sync, float(n), count_dev
+        if training:
+            ctx.save_for_backward(xa, xb, y, ga, gb, mean_a, inv_a, mean_b, inv_b, ba, bb)
+        else:
+            ctx.save_for_backward(xa, xb, y, ga, gb, sca, None, scb, None, ba, bb)
+            ctx.eval_stats = (rma, rva, eps_a, rmb, rvb, eps_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, y, ga, gb, mean_a, inv_a, mean_b, inv_b, ba, bb = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, c = xa.shape
+        dev = xa.device
+        relu = 1 if ctx.relu else 0
+        need = ctx.needs_input_grad
+        if not ctx.training:
+            g = dy if not relu else dy * (y > 0)
+            outs = []
+            for x, gam, scale, (rm, rv, eps), ig, ib in ((xa, ga, mean_a, ctx.eval_stats[0:3], 1, 2),
+                                                          (xb, gb, mean_b, ctx.eval_stats[3:6], 6, 7)):
+                dgam = dbet = None
+                if need[ig] or need[ib]:
+                    dbet = g.sum(0)
+                    dgam = ((g * x).sum(0) - dbet * rm) * torch.rsqrt(rv + eps)
+                outs.append((_own(g * scale.reshape(1, -1)), dgam if need[ig] else None, dbet if need[ib] else None))
+            (dxa, dga, dba), (dxb, dgb, dbb) = outs
+            return (dxa, dga, dba, None, None, dxb, dgb, dbb, None, None) + (None,) * 9
+        dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+        partial = torch.empty(3 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
+        sums = torch.empty(3 * c, dtype=torch.float64, device=dev)
+
+        def slots(beta, gamma):
+            db, dg = grad_slot(beta), grad_slot(gamma)
+            if db is None or dg is None:
+                db = torch.empty(c, dtype=torch.float32, device=dev)
+                dg = torch.empty(c, dtype=torch.float32, device=dev)
+            return db, dg
+        dba, dga = slots(ba, ga)
+        dbb, dgb = slots(bb, gb)
+        _call('b2m_bn_bwd_reduce2', dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), xa.data_ptr(), xa.stride(0),
+              xb.data_ptr(), xb.stride(0), n, c, mean_a.data_ptr(), inv_a.data_ptr(), mean_b.data_ptr(), inv_b.data_ptr(),
+              relu, partial.data_ptr(), sums.data_ptr())
+        group = _sync_group() if ctx.sync else None
+        if group is not None:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        _call('b2m_bn_bwd_apply2', dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), xa.data_ptr(), xa.stride(0),
+              xb.data_ptr(), xb.stride(0), n, c, mean_a.data_ptr(), inv_a.data_ptr(), _ptr(ga), mean_b.data_ptr(),
+              inv_b.data_ptr(), _ptr(gb), sums.data_ptr(), ctx.count, _ptr(ctx.count_dev), relu, dxa.data_ptr(),
+              dxa.stride(0), dxb.data_ptr(), dxb.stride(0), dba.data_ptr(), dga.data_ptr(), dbb.data_ptr(), dgb.data_ptr())
+        return (_own(dxa), dga if need[1] else None, dba if need[2] else None, None, None,
+                _own(dxb), dgb if need[6] else None, dbb if need[7] else None, None, None) + (None,) * 9
+
+
+def batch_norm_pair(xa, bn_a, xb, bn_b, training, relu=True, sync=False, count_key=None):
+    """bn_a / bn_b: (gamma, beta, running_mean, running_var, momentum, eps) of the two layers.  count_key: the row family
+    of the inputs (nn.count_key_of), for observers only."""
+    ts_a = getattr(xa, '_b2m_tile_stats', None) if training else None
+    ts_b = getattr(xb, '_b2m_tile_stats', None) if training else None
+    return _BatchNormPair.apply(xa, bn_a[0], bn_a[1], bn_a[2], bn_a[3], xb, bn_b[0], bn_b[1], bn_b[2], bn_b[3], training,
+                                bn_a[4], bn_a[5], bn_b[4], bn_b[5], relu, sync, ts_a, ts_b)
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, residual=None,

@@ -156,6 +156,37 @@ class MinkowskiBatchNorm(nn.Module):
     def forward(self, x: SparseTensor) -> SparseTensor:
         return x.new(self.apply_bn(x.F, count_key=count_key_of(x)))
 
+    def _begin(self, feats, defer_counter):
+        """The bookkeeping of apply_bn for a layer that runs inside a paired operator: (training?, parameter tuple)."""
+        bn = self.bn
+        training = self.training or not bn.track_running_stats
+        if training and feats.shape[0] == 1:
+            raise ValueError('Expected more than 1 value per channel when training, got input size %s'
+                             % (tuple(feats.shape),))
+        if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            if defer_counter:
+                _pending_counters.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
+        return training, (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+
+
+def batch_norm_add_relu(norm_a: MinkowskiBatchNorm, feats_a, norm_b: MinkowskiBatchNorm, feats_b, relu=True,
+                        defer_counter=False, count_key=None):
+    """relu(norm_a(feats_a) + norm_b(feats_b)) -- the end of a BasicBlock with a shortcut convolution (resnet.py:73-82) --
+    or None when the paired operator does not apply (different modes of the two layers, small maps outside SyncBN:
+    those take the one-launch kernels of functional._BatchNorm)."""
+    if not F_.bn_pair() or norm_a.training != norm_b.training or norm_a.sync != norm_b.sync:
+        return None
+    n = feats_a.shape[0]
+    sync = norm_a.sync and F_._sync_group() is not None
+    if norm_a.training and not sync and n <= F_.bn_small_rows():
+        return None
+    tr_a, pa = norm_a._begin(feats_a, defer_counter)
+    tr_b, pb = norm_b._begin(feats_b, defer_counter)
+    assert tr_a == tr_b
+    return F_.batch_norm_pair(feats_a, pa, feats_b, pb, tr_a, relu, norm_a.sync, count_key)
+
 
 _pending_counters = []
 

@@ -36,6 +36,12 @@ class BasicBlock(nn.Module):
         out = self.conv2(out)
         if self.downsample is not None:
             res = self.downsample[0](x)
+            # norm2 and the shortcut's BatchNorm are independent and meet in the add: one paired operator (one apply, one
+            # backward reduction, one SyncBN exchange per direction for both layers) where it applies
+            y = ME.batch_norm_add_relu(self.norm2, out.F, self.downsample[1], res.F, relu=True, defer_counter=True,
+                                       count_key=ck)
+            if y is not None:
+                return out.new(y)
             residual = self.downsample[1].apply_bn(res.F, count_key=ck, defer_counter=True)
         else:
             residual = x.F

@@ -242,6 +242,40 @@ int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy,
                      const double* sums, double count, const double* count_dev, int32_t relu, const float* mask_scale,
                      const float* mask_shift, float* dx, int64_t lddx, float* dres, int64_t lddres, void* stream);
 
+/* Two BatchNorms that meet in one add -- the end of a BasicBlock with a shortcut convolution:
+ *   y = relu?(BN_a(x_a) + BN_b(x_b))      (/root/reference/models/resnet.py:73-82: norm2 + downsample.1 + add + ReLU)
+ * b2m_bn_apply2: both affine maps, the add and the ReLU in one pass (the shortcut's normalised tensor is never stored);
+ * b2m_bn_bwd_reduce2: sums[0:c] = sum g, sums[c:2c] = sum g*xhat_a, sums[2c:3c] = sum g*xhat_b with g = dy * (y > 0 if relu)
+ *   (partial: double[3*c*1280] scratch) -- under SyncBN ONE all-reduce of 3c doubles for the pair;
+ * b2m_bn_bwd_apply2: dx_a, dx_b and the four parameter gradients (fp32 copies of the sums; any may be NULL). */
+int b2m_bn_apply2(const float* xa, int64_t lda, const float* xb, int64_t ldb, int64_t n, int32_t c,
+                  const float* scale_a, const float* shift_a, const float* scale_b, const float* shift_b,
+                  int32_t relu, float* y, int64_t ldy, void* stream);
+int b2m_bn_bwd_reduce2(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* xa, int64_t lda,
+                       const float* xb, int64_t ldb, int64_t n, int32_t c, const float* mean_a, const float* invstd_a,
+                       const float* mean_b, const float* invstd_b, int32_t relu, double* partial, double* sums,
+                       void* stream);
+int b2m_bn_bwd_apply2(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* xa, int64_t lda,
+                      const float* xb, int64_t ldb, int64_t n, int32_t c, const float* mean_a, const float* invstd_a,
+                      const float* gamma_a, const float* mean_b, const float* invstd_b, const float* gamma_b,
+                      const double* sums, double count, const double* count_dev, int32_t relu, float* dxa, int64_t lddxa,
+                      float* dxb, int64_t lddxb, float* dbeta_a, float* dgamma_a, float* dbeta_b, float* dgamma_b,
+                      void* stream);
+
+/* Training-mode BatchNorm of a SMALL map (n <= B2M_BN_SMALL_MAX_ROWS rows: the deep U-Net levels, the heads' segment
+ * rows) in ONE launch each way: b2m_bn_small_fwd = statistics (fp64) + finalize (mean / invstd / scale / shift, running
+ * statistics) + apply (+residual)(+ReLU); b2m_bn_small_bwd = b2m_bn_bwd_reduce + b2m_bn_bwd_apply (dbeta / dgamma may be
+ * NULL).  Same arguments and meaning as the multi-launch entries; not for SyncBN (the statistics never leave the kernel). */
+#define B2M_BN_SMALL_MAX_ROWS 16384
+int b2m_bn_small_fwd(const float* x, int64_t ldx, int64_t n, int32_t c, const float* gamma, const float* beta,
+                     float eps, float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                     float* scale, float* shift, const float* residual, int64_t ldr, int32_t relu, float* y, int64_t ldy,
+                     void* stream);
+int b2m_bn_small_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                     int64_t n, int32_t c, const float* mean, const float* invstd, const float* gamma, int32_t relu,
+                     const float* mask_scale, const float* mask_shift, float* dbeta_f32, float* dgamma_f32,
+                     float* dx, int64_t lddx, float* dres, int64_t lddres, void* stream);
+
 /* out = relu(a) (b == NULL) or a + b, optional relu; grad helper: dx = dy * (y > 0). */
 int b2m_relu_fwd(const float* x, int64_t n_elem, float* y, void* stream);
 int b2m_relu_bwd(const float* dy, const float* y, int64_t n_elem, float* dx, void* stream);

@@ -62,14 +62,22 @@ class _MaskRecorder:
             y = relu0(x)
             self.masks.append((None, y.detach() > 0))
             return y
+        pair0 = F_.batch_norm_pair
+
+        def pair(xa, bn_a, xb, bn_b, training, relu=True, sync=False, count_key=None):
+            y = pair0(xa, bn_a, xb, bn_b, training, relu, sync, count_key)
+            if relu:
+                self.masks.append((count_key[2] if count_key[0] == 'level' else None, y.detach() > 0))
+            return y
         monkeypatch.setattr(F_, 'batch_norm', bn)
         monkeypatch.setattr(F_, 'relu', relu)
+        monkeypatch.setattr(F_, 'batch_norm_pair', pair)
 
     def replay(self, manager, hier, n_seg, monkeypatch):
         """torch.relu of the oracle := multiplication with the recorded masks, in call order."""
         from oracle import sparse_ref
         to_gpu = {}                                   # rows of level l: oracle row r <-> device row to_gpu[l][r]
-        for l in range(8):
+        for l in range(len(hier.coords)):
             kg = sparse_ref.pack_keys(manager.coords[l].cpu().numpy())
             ko = sparse_ref.pack_keys(hier.coords[l])
             order = np.argsort(kg)
@@ -88,6 +96,7 @@ class _MaskRecorder:
             assert m.shape == x.shape
             return x * m.to(x.dtype)
         monkeypatch.setattr(torch, 'relu', masked)
+        self.to_gpu = to_gpu
         return it
 
 
@@ -216,14 +225,20 @@ def test_default_mode_train_batchnorm_many_scenes(monkeypatch):
     assert e_gpu[-1] <= 2.0 * e_o32[-1]
 
 
-def test_default_mode_equals_deterministic_mode_on_a_block_chain(monkeypatch):
-    """conv-BN-ReLU-conv-BN (+1x1 shortcut-BN) add ReLU, twice, then the strided convolution and one more block on the
-    next level -- train-mode BatchNorm over tens of thousands of rows (no tiny levels): everything the default mode
-    adds (side stream, in-place pass-through accumulation, tile statistics, atomic combines) against the ordered
-    single-stream forms, <= 1e-4 on the output, the input gradient and every parameter gradient."""
-    from box2mask_amd import nn as ME
+def test_default_and_deterministic_mode_on_a_block_chain(monkeypatch):
+    """conv-BN-ReLU-conv-BN (+1x1 shortcut-BN) add ReLU twice, the strided convolution, a block on the next level, the
+    transposed convolution back, ME.cat with the skip and a block with a two-source shortcut -- train-mode BatchNorm over
+    tens of thousands of rows (no tiny levels).  The default mode (side stream, in-place pass-through accumulation, epilogue
+    statistics, split maps, paired BatchNorm) and the ordered single-stream mode are BOTH held against the fp64 oracle with
+    the ReLU decisions of the respective device run: output, input gradient and every parameter gradient <= 1e-4 (observed
+    2e-6).  The two modes' outputs agree to 1e-4 directly; their GRADIENTS are not compared with each other: the two
+    forwards differ by 5e-7, a handful of the 2.9 M units of a layer land on the other side of zero, and one such unit moves
+    a weight gradient that is a sum over N pairs by about 1/sqrt(N) of its size -- measured 4e-2 on the 8 x 64 x 32
+    transposed-convolution kernel between two CORRECT runs (tools/debug_chain.py)."""
+    from box2mask_amd import nn as ME, _lib
     from box2mask_amd.resnet import BasicBlock
     from box2mask_amd import functional as F_
+    from oracle import sparse_ref as S
     from torch import nn
     b = synth.make_batch(3, seed0=70, target_voxels=30000, pts_per_m2=8000.0)
 
@@ -244,54 +259,71 @@ def test_default_mode_equals_deterministic_mode_on_a_block_chain(monkeypatch):
         def forward(self, x):
             e = self.b1(self.b0(x))
             d, e = self.down(e, passthrough=True)
-            d = d.new(self.bn.apply_bn(d.F, relu=True))
+            d = d.new(self.bn.apply_bn(d.F, relu=True, count_key=ME.count_key_of(d)))
             d = self.b2(d)
             u = self.up(d)
-            u = u.new(self.bnu.apply_bn(u.F, relu=True))
+            u = u.new(self.bnu.apply_bn(u.F, relu=True, count_key=ME.count_key_of(u)))
             y = self.b3(ME.cat(u, e))
             ME.flush_batch_counters()
             return y
 
-    def run():
-        from box2mask_amd import _lib
-        if hasattr(_lib, 'reload_env'):
-            _lib.reload_env()
+    def oracle(sd, x, gy, hier):
+        """The chain on oracle/sparse_ref.py in fp64 (resnet.py:70-83 per block), rows in input order."""
+        p = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
+             for k, v in sd.items()}
+        bn = lambda name, t: S.batch_norm(t, p[name + '.bn.weight'], p[name + '.bn.bias'], None, None, True)
+
+        def block(name, t, nbr, short):
+            out = torch.relu(bn(name + '.norm1', S.conv_nbr(t, p[name + '.conv1.kernel'], nbr)))
+            out = bn(name + '.norm2', S.conv_nbr(out, p[name + '.conv2.kernel'], nbr))
+            res = bn(name + '.downsample.1', S.conv_nbr(t, p[name + '.downsample.0.kernel'], None)) if short else t
+            return torch.relu(out + res)
+        x = x.double().clone().requires_grad_(True)
+        e = block('b1', block('b0', x, hier.k3(0), True), hier.k3(0), False)
+        d = torch.relu(bn('bn', S.conv_nbr(e, p['down.kernel'], hier.down(0))))
+        d = block('b2', d, hier.k3(1), False)
+        u = torch.relu(bn('bnu', S.conv_nbr(d, p['up.kernel'], hier.up(0))))
+        y = block('b3', torch.cat([u, e], 1), hier.k3(0), True)
+        (y * gy.double()).sum().backward()
+        return y.detach(), x.grad, {k: v.grad for k, v in p.items() if torch.is_tensor(v) and v.requires_grad}
+
+    hier = S.Hierarchy(b['vox_coords'].numpy(), n_levels=2)
+    torch.manual_seed(10)
+    feats = torch.randn(b['vox_coords'].shape[0], 32)
+    gy = torch.randn(b['vox_coords'].shape[0], 48)
+    outputs = {}
+    for mode in ('default', 'default again', 'deterministic'):
+        _default_env(monkeypatch)
+        if mode == 'deterministic':
+            monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+        else:
+            assert F_.wgrad_on_side_stream()
         torch.manual_seed(9)
         net = Chain().cuda().train()
-        torch.manual_seed(10)
-        sin = ME.SparseTensor(torch.randn(b['vox_coords'].shape[0], 32), b['vox_coords'])
-        sin.F.requires_grad_(True)
-        F_.packed_weights.begin_pass()
-        y = net(sin).F
-        gy = torch.randn(y.shape, device='cuda')
-        (y * gy).sum().backward()
-        torch.cuda.synchronize()
-        return y.detach().clone(), sin.F.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()}
-
-    _default_env(monkeypatch)
-    assert F_.wgrad_on_side_stream()
-    y1, dx1, g1 = run()
-    y1b, dx1b, g1b = run()                                          # (a second default run: allocator reuse)
-    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
-    y0, dx0, g0 = run()
+        sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        with monkeypatch.context() as mp:
+            rec = _MaskRecorder(mp)
+            sin = ME.SparseTensor(feats, b['vox_coords'])          # (rows permuted to Morton order inside)
+            sin.F.requires_grad_(True)
+            F_.packed_weights.begin_pass()
+            y = net(sin).F
+        perm, inv = sin.manager.perm, sin.manager.inv_perm
+        (y * gy.cuda()[perm]).sum().backward()
+        # no synchronize: read on the current stream
+        y_in, dx_in = y.detach()[inv].cpu(), sin.F.grad[inv].cpu()      # back to input row order
+        g = {n: q.grad.cpu() for n, q in net.named_parameters()}
+        with monkeypatch.context() as mp:
+            it = rec.replay(sin.manager, hier, -1, mp)
+            oy, odx, og = oracle(sd, feats, gy, hier)
+            assert next(it, None) is None
+        worst = max((_rel(g[n], og[n]), n) for n in g)
+        print('%-14s vs fp64 oracle: output %.2e  input gradient %.2e  worst parameter gradient %.2e %s'
+              % (mode, _rel(y_in, oy), _rel(dx_in, odx), worst[0], worst[1]))
+        assert _rel(y_in, oy) < 1e-4 and _rel(dx_in, odx) < 1e-4 and worst[0] < 1e-4, (mode, worst)
+        outputs[mode] = y_in
     monkeypatch.delenv('B2M_DETERMINISTIC')
-    from box2mask_amd import _lib
-    if hasattr(_lib, 'reload_env'):
-        _lib.reload_env()
-    assert y1.shape[0] == b['vox_coords'].shape[0] and y1.shape[1] == 48
-    for what, (ya, da, ga) in (('default', (y1, dx1, g1)), ('default again', (y1b, dx1b, g1b))):
-        worst = max((_rel(ga[n], g0[n]), n) for n in g0)
-        # the input gradient is a per-row quantity: ONE unit whose pre-activation sits within rounding of zero and comes out
-        # on the other side (the two modes add in different orders) changes the rows around it by O(1).  Such rows are
-        # counted, everything else is held to 1e-4.
-        err_rows = (da - dx0).abs().amax(1) / float(dx0.abs().max())
-        bad = float((err_rows > 1e-4).float().mean())
-        l2 = float((da - dx0).norm() / dx0.norm())
-        print(what, 'output %.2e  worst parameter gradient %.2e %s  input gradient: max %.2e, L2 %.2e, rows beyond 1e-4: %.2e'
-              % (_rel(ya, y0), worst[0], worst[1], float(err_rows.max()), l2, bad))
-        assert _rel(ya, y0) < 1e-4, (what, _rel(ya, y0))
-        assert worst[0] < 1e-4, (what, worst)
-        assert bad < 1e-3 and l2 < 1e-3, (what, bad, l2)
+    assert _rel(outputs['default'], outputs['deterministic']) < 1e-4
+    assert _rel(outputs['default again'], outputs['deterministic']) < 1e-4
 
 
 def test_full_size_scene_forward_matches_oracle(monkeypatch):

@@ -123,11 +123,12 @@ def test_conv_accumulate_and_empty_tiles(maps):
     _close(out, ref, 'accumulate')
 
 
+@pytest.mark.parametrize('n', [5000, 700, 9])          # two-stage kernels | one-launch small-map kernels (functional.bn_small_rows)
 @pytest.mark.parametrize('c,relu,res', [(32, True, False), (96, True, True), (96, False, False), (256, True, False)])
-def test_batch_norm(c, relu, res):
+def test_batch_norm(c, relu, res, n):
     from box2mask_amd import functional as F_
+    assert (n <= F_.bn_small_rows()) == (n < 5000)
     torch.manual_seed(c)
-    n = 5000
     x = torch.randn(n, c) * 2 + 0.5
     r = torch.randn(n, c) if res else None
     gy = torch.randn(n, c)
@@ -155,6 +156,36 @@ def test_batch_norm(c, relu, res):
     ye = bn(x)
     yge = F_.batch_norm(x.cuda(), g.weight, g.bias, g.running_mean, g.running_var, False, 0.1, 1e-5, None, False, False)
     _close(yge, ye, 'bn eval', 1e-5)
+    # eval-mode gradients, affine parameters included (torch.nn.BatchNorm1d has them)
+    bn.zero_grad(); g.zero_grad()
+    xo2 = x.clone().requires_grad_(True); xg2 = x.cuda().requires_grad_(True)
+    yo2 = torch.relu(bn(xo2)) if relu else bn(xo2)
+    yo2.backward(gy)
+    F_.batch_norm(xg2, g.weight, g.bias, g.running_mean, g.running_var, False, 0.1, 1e-5, None, relu, False).backward(gy.cuda())
+    _close(xg2.grad, xo2.grad, 'bn eval dx', 1e-5)
+    _close(g.weight.grad, bn.weight.grad, 'bn eval dgamma', 1e-4); _close(g.bias.grad, bn.bias.grad, 'bn eval dbeta', 1e-4)
+
+
+def test_batch_norm_small_and_two_stage_kernels_agree(monkeypatch):
+    """The one-launch BatchNorm of small maps against the two-stage kernels on the same tensors (B2M_BN_SMALL_ROWS=0),
+    with residual + ReLU, at the row counts of levels 4-7 and of the heads."""
+    from box2mask_amd import functional as F_
+    for n, c in ((3214, 256), (674, 256), (109, 256), (2, 256), (9752, 96), (4096, 32)):
+        outs = []
+        for small in (1, 0):
+            monkeypatch.setenv('B2M_BN_SMALL_ROWS', '16384' if small else '0')
+            torch.manual_seed(n)
+            x = (torch.randn(n, c, device='cuda') * 1.7 + 0.3).requires_grad_(True)
+            r = torch.randn(n, c, device='cuda').requires_grad_(True)
+            gam = (torch.rand(c, device='cuda') + 0.5).requires_grad_(True); bet = torch.randn(c, device='cuda').requires_grad_(True)
+            rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+            y = F_.batch_norm(x, gam, bet, rm, rv, True, 0.1, 1e-5, r, True, False)
+            y.backward(torch.randn(n, c, device='cuda', generator=torch.Generator('cuda').manual_seed(1)))
+            outs.append((y.detach(), x.grad, r.grad, gam.grad, bet.grad, rm, rv))
+        for a, b, what in zip(outs[0], outs[1], ('y', 'dx', 'dres', 'dgamma', 'dbeta', 'running_mean', 'running_var')):
+            if n == 2 and what in ('dx', 'dgamma'):
+                continue          # two rows: x_hat = +-1 exactly, dx is a difference of equal numbers (pure rounding noise)
+            _close(a, b, 'n=%d %s' % (n, what), 2e-5)
 
 
 @pytest.mark.parametrize('mode', ['avg', 'max'])
@@ -178,3 +209,39 @@ def test_relu_and_set_ious():
     xg = x.cuda().requires_grad_(True)
     y = F_.relu(xg); y.backward(torch.ones_like(y))
     assert torch.equal(y.cpu(), torch.relu(x)) and torch.equal(xg.grad.cpu(), (x > 0).float())
+
+
+@pytest.mark.parametrize('n,c', [(20000, 96), (5000, 256), (300, 64)])
+def test_batch_norm_pair_equals_two_batch_norms(n, c, monkeypatch):
+    """relu(BN_a(x_a) + BN_b(x_b)) as one paired operator (functional._BatchNormPair: the end of a BasicBlock with a shortcut
+    convolution, resnet.py:73-82) against the two separate BatchNorm operators: the forward bit for bit (same fma / fma /
+    add), the gradients to rounding; train and eval mode."""
+    from box2mask_amd import functional as F_
+    monkeypatch.setenv('B2M_BN_SMALL_ROWS', '0')
+    gen = torch.Generator('cuda').manual_seed(n + c)
+    rnd = lambda *s: torch.randn(*s, device='cuda', generator=gen)
+    xa0, xb0, gy = rnd(n, c) * 1.5 + 0.2, rnd(n, c) * 0.7 - 0.4, rnd(n, c)
+    for training in (True, False):
+        res = []
+        for paired in (True, False):
+            xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+            prm = [(torch.rand(c, device='cuda', generator=gen) + 0.5).requires_grad_(True) for _ in range(2)] + \
+                  [rnd(c).requires_grad_(True) for _ in range(2)]
+            gen.manual_seed(7)          # (same parameters for both forms)
+            with torch.no_grad():
+                for t in prm:
+                    t.copy_(torch.rand(c, device='cuda', generator=gen) + 0.5)
+            ga, gb, ba, bb = prm
+            rma, rva, rmb, rvb = rnd(c) * 0.1, torch.rand(c, device='cuda', generator=gen) + 0.5, rnd(c) * 0.1, \
+                torch.rand(c, device='cuda', generator=gen) + 0.5
+            gen.manual_seed(n + c + 1)
+            if paired:
+                y = F_.batch_norm_pair(xa, (ga, ba, rma, rva, 0.1, 1e-5), xb, (gb, bb, rmb, rvb, 0.1, 1e-5), training, True, False)
+            else:
+                r = F_.batch_norm(xb, gb, bb, rmb, rvb, training, 0.1, 1e-5, None, False, False)
+                y = F_.batch_norm(xa, ga, ba, rma, rva, training, 0.1, 1e-5, r, True, False)
+            y.backward(gy)
+            res.append((y.detach(), xa.grad, xb.grad, ga.grad, ba.grad, gb.grad, bb.grad, rma, rva, rmb, rvb))
+        assert torch.equal(res[0][0], res[1][0]), 'paired forward differs from the two launches'
+        for a, b, what in zip(res[0][1:], res[1][1:], ('dxa', 'dxb', 'dgamma_a', 'dbeta_a', 'dgamma_b', 'dbeta_b', 'rm_a', 'rv_a', 'rm_b', 'rv_b')):
+            _close(a, b, '%s training=%s' % (what, training), 2e-6)
