@@ -420,7 +420,7 @@ def main():
     # ---- second half of configs[1] ("+ iou_nms on HIP"): votes -> instance masks of the same 8 scenes, reported
     # beside the headline value (never part of it)
     if args.votes and world == 1:          # N=1 only: the other ranks of a scaling run wait at the final barrier
-        result['votes_to_masks'] = votes_leg(model, batch, cfg, cpu=bool(args.cpu_baseline))
+        result['votes_to_masks'] = votes_leg(model, batch, cfg, cpu=bool(args.cpu_baseline), pmc=pmc, pmc_src=pmc_src)
 
     # ---- raw scene points -> voxelised, collated device batch (what feeds the step above)
     if args.prepare and world == 1:
@@ -538,7 +538,11 @@ def spawn_ranks(n):
     return rc
 
 
-def votes_leg(model, batch, cfg, cpu):
+KERNEL_OF = {'nmc_batch': 'nmc_batch_kernel', 'mask_project': 'mask_project_batch_kernel', 'mask_nms': 'mask_inter_batch_kernel',
+             'label_hist': 'label_hist_batch_kernel', 'mask_gather': 'mask_gather_batch_kernel'}
+
+
+def votes_leg(model, batch, cfg, cpu, pmc=None, pmc_src=None):
     """Evaluater flow (evaluation.py:86-97) on synthetic votes: every segment of the batch votes for the box of
     its ground-truth object with 2.5 cm noise on offset and bounds, score logits ~ N(0,2), semantics = ground
     truth.  Times Model.pred2mask(batch, pred, 'eval') over the whole batch; with `cpu`, scene 0 is
@@ -571,36 +575,26 @@ def votes_leg(model, batch, cfg, cpu):
     rec = []
 
     def hook(name, a, meta_in=None):
-        # algorithmic bytes per launch (every operand once)
-        if name == 'b2m_nmc_batch':        # boxes, desc, n_scenes, max_n, th, ...: boxes once + the heat-map rows written
-            nb = None                      # filled below from the results (needs the cluster counts)
-        elif name == 'b2m_mask_project':   # heat, n_fg, sel, ksel, fg_slot, seg2vox, n_vox, th, bits, words
-            nb = 12.0 * a[6] + 4.0 * a[3] * a[1] + 8.0 * a[3] * a[9]
-        elif name == 'b2m_mask_nms':       # bits, k, words, th, inter, keep, n_keep
-            nb = 8.0 * a[1] * a[2] + 4.0 * a[1] * a[1]
-        elif name == 'b2m_label_hist':     # bits, words, rows, k, sem, n_vox, n_class, labels
-            nb = 8.0 * a[3] * a[1] + 4.0 * a[5]
-        elif name == 'b2m_mask_gather':    # bits, words, rows, k, index, n_pts, out
-            nb = 8.0 * a[3] * a[1] + 8.0 * a[5] + 1.0 * a[3] * a[5]
-        else:
+        if name not in ('b2m_nmc_batch', 'b2m_mask_project_batch', 'b2m_mask_nms_batch', 'b2m_label_hist_batch',
+                        'b2m_mask_gather_batch'):
             return None
         s_ = torch.cuda.Event(enable_timing=True); e_ = torch.cuda.Event(enable_timing=True)
         s_.record()
 
         def done():
             e_.record()
-            rec.append((name, s_, e_, nb))
+            rec.append((name, s_, e_, None))
         return done
     _lib.set_hook(hook)
     model.pred2mask(cpu_batch, pred, 'eval')
     torch.cuda.synchronize()
     _lib.set_hook(None)
     kern = {}
+    d2m_bytes = getattr(model.detection_model, '_d2m_bytes', {})        # algorithmic bytes per stage (every operand once)
     for name, s_, e_, nb in rec:
-        k_ = kern.setdefault(name[4:], dict(ms=0.0, bytes=0.0, launches=0))
+        k_ = kern.setdefault(name[4:].replace('_batch', '') if name != 'b2m_nmc_batch' else 'nmc_batch', dict(ms=0.0, bytes=0.0, launches=0))
         k_['ms'] += s_.elapsed_time(e_); k_['launches'] += 1
-        if nb is not None:
-            k_['bytes'] += nb
+        k_['bytes'] += d2m_bytes.get(name, 0.0)
     n_scenes = len(batch['scene'])
     fg_votes = int(is_fg(valid[sem_idx].long()).sum())
     # the clustering launch: 28 B per foreground vote read + one fp32 heat-map row per cluster written (the cluster
@@ -626,7 +620,11 @@ def votes_leg(model, batch, cfg, cpu):
            # per scene over a few hundred boxes: latency-bound by construction, the fraction says so
            'roofline': None if dom is None else {
                'bound': 'hbm', 'kernel': dom, 'achieved': table[dom]['gb_per_s'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-               'frac': round(table[dom]['gb_per_s'] / PEAK_HBM_GBS, 6), 'traffic': None,
+               'frac': round(table[dom]['gb_per_s'] / PEAK_HBM_GBS, 6),
+               # HBM-side bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+               'traffic': (pmc or {}).get(KERNEL_OF.get(dom, dom), {}).get('traffic_bytes'),
+               'traffic_source': pmc_src if (pmc or {}).get(KERNEL_OF.get(dom, dom), {}).get('traffic_bytes') is not None else None,
+               'traffic_all_kernels': {k: (pmc or {}).get(KERNEL_OF.get(k, k), {}).get('traffic_bytes') for k in kern},
                'device_ms_all_kernels': round(sum(v['ms'] for v in kern.values()), 3)},
            'flow': "Model.pred2mask(batch, pred, 'eval') with eval_ths %s; pred on the host as in "
                    "evaluation.py:86, masks returned to the host" % (list(cfg.eval_ths),)}

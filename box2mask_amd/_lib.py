@@ -62,6 +62,10 @@ PROTOTYPES = {
     'b2m_mask_nms': [P, I32, I64, F32, P, P, P, P],
     'b2m_label_hist': [P, I64, P, I32, P, I64, I32, P, P],
     'b2m_mask_gather': [P, I64, P, I32, P, I64, P, P],
+    'b2m_mask_project_batch': [P, I32, I64, I64, F32, P],
+    'b2m_mask_nms_batch': [P, I32, I32, F32, P],
+    'b2m_label_hist_batch': [P, I32, I64, I32, P],
+    'b2m_mask_gather_batch': [P, I32, I64, I64, P],
     'b2m_mask_hist': [P, I64, I32, P, I64, I32, P, P],
     'b2m_mask_pack': [P, I32, I64, P, I64, P],
     'b2m_set_ious': [P, P, I64, P, P],

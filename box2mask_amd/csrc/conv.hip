@@ -1140,12 +1140,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
 // per launch at 0.02-0.3 TFLOP/s (round 2).  Here a workgroup takes a chunk of rows, stages their dy in LDS, and thread
 // (part, ci) keeps the CO sums of its input channel in registers over its share of the rows (x is read coalesced, the dy
 // values are LDS broadcasts); one atomic per dW element and workgroup at the end.
-#define WGN_ROWS 128
+#define WGN_ROWS 512
 template <int CO>
 __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restrict__ x, int64_t ldx, int cin,
                                                            const float* __restrict__ dy, int64_t lddy, int cout, int64_t n,
                                                            float* __restrict__ dw, int64_t lddw) {
-    __shared__ float sdy[WGN_ROWS * CO];
+    __shared__ __attribute__((aligned(16))) float sdy[WGN_ROWS * CO];      // later reused for the partial sums of the row shares
     const int64_t r0 = (int64_t)blockIdx.x * WGN_ROWS;
     const int rows = (int)((n - r0) < WGN_ROWS ? (n - r0) : WGN_ROWS);
     for (int e = threadIdx.x; e < rows * CO; e += 256) {
@@ -1153,22 +1153,62 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restri
         sdy[e] = co < cout ? dy[(r0 + r) * lddy + co] : 0.f;
     }
     __syncthreads();
-    const int nparts = 256 / cin > 0 ? 256 / cin : 1;           // row shares per input channel
-    for (int ci0 = 0; ci0 < cin; ci0 += 256) {                  // (cin <= 256: one round)
-        const int ci = ci0 + (int)threadIdx.x % (cin < 256 ? cin : 256);
-        const int part = (int)threadIdx.x / (cin < 256 ? cin : 256);
-        if (ci >= cin || part >= nparts) continue;
+    const int cw = cin < 256 ? cin : 256;                       // input channels per round
+    const int nparts = 256 / cw;                                // row shares per input channel
+    for (int ci0 = 0; ci0 < cin; ci0 += cw) {
+        const int ci = ci0 + (int)threadIdx.x % cw, part = (int)threadIdx.x / cw;
+        const bool active = ci < cin && part < nparts;
         float acc[CO];
 #pragma unroll
         for (int co = 0; co < CO; ++co) acc[co] = 0.f;
-        for (int r = part; r < rows; r += nparts) {
-            const float xv = x[(r0 + r) * ldx + ci];
+        if (active) {
+            const float* xp = x + r0 * ldx + ci;
+            int r = part;
+            for (; r + 3 * nparts < rows; r += 4 * nparts) {         // four rows' loads in flight
+                float xv[4];
 #pragma unroll
-            for (int co = 0; co < CO; ++co) acc[co] = __builtin_fmaf(xv, sdy[r * CO + co], acc[co]);
+                for (int u = 0; u < 4; ++u) xv[u] = xp[(int64_t)(r + u * nparts) * ldx];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4* d4 = (const f32x4*)&sdy[(r + u * nparts) * CO];
+#pragma unroll
+                    for (int c4 = 0; c4 < CO / 4; ++c4) {
+                        const f32x4 d = d4[c4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[4 * c4 + v] = __builtin_fmaf(xv[u], d[v], acc[4 * c4 + v]);
+                    }
+                }
+            }
+            for (; r < rows; r += nparts) {
+                const float xv = xp[(int64_t)r * ldx];
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[co] = __builtin_fmaf(xv, sdy[r * CO + co], acc[co]);
+            }
         }
+        // the row shares of one input channel meet in LDS; ONE atomic per dW element and workgroup
+        __syncthreads();
+        float* red = sdy;                                       // [part][cw][CO] <= 256 * CO floats <= WGN_ROWS * CO
+        if (active) {
 #pragma unroll
-        for (int co = 0; co < CO; ++co)
-            if (co < cout && acc[co] != 0.f) atomicAdd(&dw[(int64_t)ci * lddw + co], acc[co]);
+            for (int co = 0; co < CO; ++co) red[(part * cw + (ci - ci0)) * CO + co] = acc[co];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < cw * CO; e += 256) {
+            const int cl = e / CO, co = e % CO;
+            if (ci0 + cl < cin && co < cout) {
+                float s = 0.f;
+                for (int p = 0; p < nparts; ++p) s += red[(p * cw + cl) * CO + co];
+                if (s != 0.f) atomicAdd(&dw[(int64_t)(ci0 + cl) * lddw + co], s);
+            }
+        }
+        if (ci0 + cw < cin) {                                   // (more than 256 input channels: dy is staged again)
+            __syncthreads();
+            for (int e = threadIdx.x; e < rows * CO; e += 256) {
+                const int r = e / CO, co = e % CO;
+                sdy[e] = co < cout ? dy[(r0 + r) * lddy + co] : 0.f;
+            }
+            __syncthreads();
+        }
     }
 }
 

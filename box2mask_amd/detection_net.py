@@ -273,38 +273,73 @@ class SelectionNet(ResNetBase):
             o += r.k
             sel = np.nonzero(scores > np.float32(score_th))[0] if score_filtering else np.arange(r.k)
             d['sel'] = sel.astype(np.int64)
-            d['sel32'] = torch.from_numpy(sel.astype(np.int32)).to(dev)
         # ---------- heat-maps -> voxel masks (436-446): zero-padded background, seg2vox projection; duplicate removal
-        # (448): mask NMS, skipped for per-voxel predictions (449-451)
-        for d, r in zip(sc, rs):
-            ksel = d['sel'].shape[0]
-            d['bits'] = torch.empty((max(ksel, 1), max(d['words'], 1)), dtype=torch.int64, device=dev)
-            _call('b2m_mask_project', r.heat.data_ptr(), d['n_fg'], d['sel32'].data_ptr(), ksel, d['fg_slot'].data_ptr(),
-                  d['s2v'].data_ptr(), d['n_vox'], float(mask_bin_th), d['bits'].data_ptr(), d['words'])
-            d['keep'] = None
-            if not self.requires_voxel_outputs and ksel > 0:
-                d['keep'], _ = iou_nms.mask_nms_device(d['bits'], ksel, d['words'], mask_nms_th)
-        flags = [d['keep'] for d in sc if d['keep'] is not None]
-        keep_host = torch.cat(flags).cpu().numpy() if flags else np.zeros(0, np.int32)
+        # (448): mask NMS, skipped for per-voxel predictions (449-451).  One launch per stage for ALL scenes: a table of
+        # B2M_MASK_DESC fields per scene (include/b2m.h) carries the scene's pointers and sizes.
+        S = len(sc)
+        desc = np.zeros((S, 20), np.int64)
+        ksels = [int(d['sel'].shape[0]) for d in sc]
+        sel_all = torch.from_numpy(np.concatenate([d['sel'] for d in sc]).astype(np.int32)).to(dev) if sum(ksels) else \
+            torch.zeros(1, dtype=torch.int32, device=dev)
+        bits_all = torch.empty(max(sum(k * max(d['words'], 1) for k, d in zip(ksels, sc)), 1), dtype=torch.int64, device=dev)
+        inter_all = torch.empty(max(sum(k * k for k in ksels), 1), dtype=torch.int32, device=dev)
+        keep_all = torch.empty(max(sum(ksels), 1), dtype=torch.int32, device=dev)
+        do_nms = not self.requires_voxel_outputs
+        keep_host = np.zeros(0, np.int32)
+        row0 = boff = ioff = 0
+        for s_, (d, r, ksel) in enumerate(zip(sc, rs, ksels)):
+            d['bits_off'] = boff
+            desc[s_, 0:9] = (r.heat.data_ptr(), d['n_fg'], sel_all.data_ptr() + 4 * row0, ksel, d['fg_slot'].data_ptr(),
+                             d['s2v'].data_ptr(), d['n_vox'], bits_all.data_ptr() + 8 * boff, d['words'])
+            desc[s_, 9] = inter_all.data_ptr() + 4 * ioff
+            desc[s_, 10] = keep_all.data_ptr() + 4 * row0 if (do_nms and ksel > 0) else 0
+            desc[s_, 18] = row0
+            row0 += ksel; boff += ksel * max(d['words'], 1); ioff += ksel * ksel
+        total_sel = row0
+        desc_dev = torch.from_numpy(desc).to(dev)
+        _call('b2m_mask_project_batch', desc_dev.data_ptr(), S, total_sel, max(d['words'] for d in sc), float(mask_bin_th))
+        if do_nms and total_sel:
+            _call('b2m_mask_nms_batch', desc_dev.data_ptr(), S, max(ksels), float(mask_nms_th))
+            keep_host = keep_all[:total_sel].cpu().numpy()           # the one host read of the stage
         o = 0
-        for d in sc:
-            ksel = d['sel'].shape[0]
-            if d['keep'] is not None:
-                d['kept'] = np.nonzero(keep_host[o:o + ksel])[0].astype(np.int64)
-                o += ksel
-            else:
-                d['kept'] = np.arange(ksel, dtype=np.int64)
-            d['kept32'] = torch.from_numpy(d['kept'].astype(np.int32)).to(dev)
+        for d, ksel in zip(sc, ksels):
+            d['kept'] = np.nonzero(keep_host[o:o + ksel])[0].astype(np.int64) if do_nms else np.arange(ksel, dtype=np.int64)
+            o += ksel
         # ---------- label per instance: argmax of the label histogram inside the mask (461-466)
-        for d in sc:
-            kk = d['kept'].shape[0]
-            d['labels'] = torch.zeros(max(kk, 1), dtype=torch.int32, device=dev)
-            _call('b2m_label_hist', d['bits'].data_ptr(), d['words'], d['kept32'].data_ptr(), kk, d['sem32'].data_ptr(),
-                  d['n_vox'], n_class, d['labels'].data_ptr())
-        labels_host = torch.cat([d['labels'][:d['kept'].shape[0]] for d in sc]).cpu().numpy().astype('int32')
+        kks = [int(d['kept'].shape[0]) for d in sc]
+        total_kept = sum(kks)
+        kept_all = torch.from_numpy(np.concatenate([d['kept'] for d in sc]).astype(np.int32)).to(dev) if total_kept else \
+            torch.zeros(1, dtype=torch.int32, device=dev)
+        labels_all = torch.zeros(max(total_kept, 1), dtype=torch.int32, device=dev)
+        outs, v2ps = [], []
+        row0 = 0
+        for s_, (d, kk) in enumerate(zip(sc, kks)):
+            if mode == 'eval':
+                v2p = torch.as_tensor(batch['vox2point'][d['idx']]).long().to(dev)
+                n_pts, idx_ptr = int(v2p.shape[0]), v2p.data_ptr()
+                v2ps.append(v2p)
+            else:
+                n_pts, idx_ptr = d['n_vox'], 0
+            out = torch.empty((kk, n_pts), dtype=torch.uint8, device=dev)
+            outs.append(out)
+            desc[s_, 11:18] = (kept_all.data_ptr() + 4 * row0, kk, d['sem32'].data_ptr(), labels_all.data_ptr() + 4 * row0,
+                               idx_ptr, n_pts, out.data_ptr())
+            desc[s_, 19] = row0
+            row0 += kk
+        desc_dev = torch.from_numpy(desc).to(dev)
+        _call('b2m_label_hist_batch', desc_dev.data_ptr(), S, total_kept, n_class)
+        _call('b2m_mask_gather_batch', desc_dev.data_ptr(), S, total_kept, max(int(o_.shape[1]) for o_ in outs))
+        labels_host = labels_all[:total_kept].cpu().numpy().astype('int32')
+        # bytes every implementation of the four stages moves (for bench.py's roofline of the leg; nothing on the path reads it)
+        self._d2m_bytes = {
+            'b2m_mask_project_batch': float(sum(12 * d['n_vox'] + 4 * k * d['n_fg'] + 8 * k * d['words'] for d, k in zip(sc, ksels))),
+            'b2m_mask_nms_batch': float(sum(8 * k * d['words'] + 4 * k * k for d, k in zip(sc, ksels))) if do_nms else 0.0,
+            'b2m_label_hist_batch': float(sum(8 * kk * d['words'] + 4 * d['n_vox'] for d, kk in zip(sc, kks))),
+            'b2m_mask_gather_batch': float(sum(8 * kk * d['words'] + 8 * o_.shape[1] + kk * o_.shape[1] for d, kk, o_ in zip(sc, kks, outs))),
+        }
         results = {}
         o = 0
-        for d, r in zip(sc, rs):
+        for d, r, out in zip(sc, rs, outs):
             kk = d['kept'].shape[0]
             instance_labels = labels_host[o:o + kk]
             o += kk
@@ -312,16 +347,8 @@ class SelectionNet(ResNetBase):
             rep_rows = torch.from_numpy(d['reps'][final_rows]).to(pdev)
             bb_scores = d['bbs'][rep_rows, 0]
             if mode == 'eval':
-                v2p = torch.as_tensor(batch['vox2point'][d['idx']]).long().to(dev)
-                n_pts = v2p.shape[0]
-                out = torch.empty((kk, n_pts), dtype=torch.uint8, device=dev)
-                _call('b2m_mask_gather', d['bits'].data_ptr(), d['words'], d['kept32'].data_ptr(), kk, v2p.data_ptr(), n_pts,
-                      out.data_ptr())
                 results[d['name']] = {'conf': bb_scores, 'label_id': instance_labels, 'mask': out.bool().to(pdev)}
             else:
-                out = torch.empty((kk, d['n_vox']), dtype=torch.uint8, device=dev)
-                _call('b2m_mask_gather', d['bits'].data_ptr(), d['words'], d['kept32'].data_ptr(), kk, None, d['n_vox'],
-                      out.data_ptr())
                 fr = torch.from_numpy(final_rows).to(dev)
                 heat_w_bg = torch.zeros((kk, d['fg_dev'].shape[0]), device=dev)
                 heat_w_bg[:, d['fg_dev']] = r.heat[fr]

@@ -365,6 +365,25 @@ int b2m_mask_pack(const uint8_t* masks, int32_t k, int64_t n, uint64_t* bits, in
 /* Row-wise IoU of two (n,6) [min,max] box sets: set_IOUs, models/iou_nms.py:4-22. */
 int b2m_set_ious(const float* a, const float* b, int64_t n, float* out, void* stream);
 
+/* ---- the mask stages of detection2mask for ALL scenes of a batch: one launch per stage
+ * (/root/reference/models/detection_net.py:390-477 walks the scenes one by one).  `desc`: device array of n_scenes records of
+ * B2M_MASK_DESC int64 fields (pointers stored as integers):
+ *    0 heat (float*, K x n_fg)       1 n_fg            2 sel (int32*, clusters that passed the score filter)   3 ksel
+ *    4 fg_slot (int32*, per segment) 5 seg2vox (int64*) 6 n_vox            7 bits (uint64*, ksel x words, written by project)
+ *    8 words = ceil(n_vox / 64)      9 inter (int32*, ksel x ksel scratch)  10 keep (int32*, ksel flags; NULL: no mask NMS)
+ *   11 rows (int32*, surviving rows of bits, NULL = 0..kk-1)   12 kk       13 sem (int32*, label per voxel)
+ *   14 labels (int32*, kk out)      15 index (int64*, voxel of every output point; NULL = identity)     16 n_pts
+ *   17 out (uint8*, kk x n_pts)     18 first global row of this scene among the `sel` rows of the batch  19 ... among the kept rows
+ * Each entry reads only the fields of its stage, so the table may be completed between the stages (sel after the score
+ * filter, rows / kk after the keep flags were read).  Results are those of b2m_mask_project / b2m_mask_nms / b2m_label_hist /
+ * b2m_mask_gather scene by scene. */
+#define B2M_MASK_DESC 20
+int b2m_mask_project_batch(const int64_t* desc, int32_t n_scenes, int64_t total_sel, int64_t max_words, float mask_bin_th,
+                           void* stream);
+int b2m_mask_nms_batch(const int64_t* desc, int32_t n_scenes, int32_t max_k, float mask_nms_th, void* stream);
+int b2m_label_hist_batch(const int64_t* desc, int32_t n_scenes, int64_t total_kept, int32_t n_class, void* stream);
+int b2m_mask_gather_batch(const int64_t* desc, int32_t n_scenes, int64_t total_kept, int64_t max_pts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,7 +61,12 @@ def test_network_forward_backward_matches_oracle(monkeypatch):
     finally:
         sparse_mod.REORDER_DEFAULT = True
     net._trace = {}
-    out = net(sin, batch['pooling_ids'].cuda(), S_)
+    from _parity import MaskRecorder
+    from oracle import sparse_ref
+    hier = sparse_ref.Hierarchy(batch['vox_coords'].numpy())
+    with monkeypatch.context() as mp:
+        rec = MaskRecorder(mp)
+        out = net(sin, batch['pooling_ids'].cuda(), S_)
     heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
     torch.manual_seed(1)
     gws = {h: torch.randn(out[h].F.shape) for h in heads}
@@ -86,25 +91,30 @@ def test_network_forward_backward_matches_oracle(monkeypatch):
     errs = {h: _rel(out[h].F, o32[h]) for h in heads}
     print('forward rel errors', errs)
     assert max(errs.values()) < 3e-4, errs                      # north_star: within 1e-3 fp32; observed 4e-5 .. 8e-5
-    # Gradients: BatchNorm over the 8-row deepest levels makes the backward pass ill-conditioned in fp32
-    # (the fp32 oracle itself is ~2e-2 away from the fp64 oracle), so every gradient is judged against the
-    # fp64 truth and must be no worse than a small multiple of the fp32 oracle's own error.
+    # Gradients.  Held directly against the fp64 oracle they measure ReLU sign flips, not the backward pass: units whose
+    # pre-activation lies within the forward rounding error of zero come out on different sides on the device and on the
+    # CPU, and one such unit moves a weight gradient summed over N pairs by ~1/sqrt(N) (the fp32 oracle itself is ~1e-2 from
+    # the fp64 one; tests/_parity.py).  So the oracle is run once more with the device's ReLU decisions: every gradient must
+    # then agree to 1e-3 of its maximum.  The unshared figures are printed for the record.
+    with monkeypatch.context() as mp:
+        rec.replay(sin.manager, hier, S_, mp)
+        p_req = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+                     else (v.double() if v.is_floating_point() else v)) for k, v in p_cpu.items()}
+        oo = unet_ref.forward(p_req, batch['vox_coords'].numpy(), batch['vox_features'].double(), batch['pooling_ids'],
+                              cfg, training=True, n_segments=S_, hier=hier)
+        sum((oo[h] * gws[h].double()).sum() for h in heads).backward()
     rows = []
     for name, prm in net.named_parameters():
         g64 = p64[name].grad
         assert g64 is not None and prm.grad is not None, name
-        rows.append((_rel(prm.grad, g64), _rel(p32[name].grad, g64), name))
-    e_gpu = sorted(r[0] for r in rows); e_o32 = sorted(r[1] for r in rows)
+        rows.append((_rel(prm.grad, p_req[name].grad), _rel(prm.grad, g64), _rel(p32[name].grad, g64), name))
+    e_gpu = sorted(r[1] for r in rows); e_o32 = sorted(r[2] for r in rows)
     q = lambda v, f: v[min(int(f * len(v)), len(v) - 1)]
-    print('gradient error vs fp64  (gpu | oracle32): median %.3e | %.3e, p90 %.3e | %.3e, max %.3e | %.3e'
+    print('gradient error vs fp64 without shared decisions (gpu | oracle32): median %.3e | %.3e, p90 %.3e | %.3e, max %.3e | %.3e'
           % (q(e_gpu, .5), q(e_o32, .5), q(e_gpu, .9), q(e_o32, .9), e_gpu[-1], e_o32[-1]))
     for r in sorted(rows, reverse=True)[:5]:
-        print('   worst: gpu %.3e oracle32 %.3e %s' % r)
-    # the error DISTRIBUTION of the GPU gradients must be no worse than that of the fp32 oracle
-    # (deterministic mode: observed ratios gpu / oracle32 = 0.75 median, 0.74 p90, 0.48 max)
-    assert q(e_gpu, .5) <= 1.25 * q(e_o32, .5)
-    assert q(e_gpu, .9) <= 1.25 * q(e_o32, .9)
-    assert e_gpu[-1] <= 1.25 * e_o32[-1]
+        print('   worst (shared decisions): %.3e   unshared: gpu %.3e oracle32 %.3e %s' % r)
+    assert max(r[0] for r in rows) < 1e-3, sorted(rows, reverse=True)[:5]
     # running statistics were updated like BatchNorm1d
     sd = net.state_dict()
     assert int(sd['bn0.bn.num_batches_tracked']) == 1

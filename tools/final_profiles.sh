@@ -23,7 +23,7 @@ stats default
 stats one_stream B2M_WGRAD_STREAM=0 B2M_BENCH_PREFETCH=0
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && export B2M_WGRAD_STREAM=0 B2M_BENCH_PREFETCH=0 && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/$out/pmc_$c -- \
-     python3 $root/bench.py --steps 1 --warmup 1 --cpu-baseline 0 --votes 0 --prepare 0 > $root/$out/pmc_$c.log 2>&1)
+     python3 $root/bench.py --steps 1 --warmup 1 --cpu-baseline 0 --votes 1 --prepare 0 > $root/$out/pmc_$c.log 2>&1)
 done
 python3 tools/pmc_traffic.py $(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
     $(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) > $out/traffic.json

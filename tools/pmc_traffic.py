@@ -27,7 +27,7 @@ def main():
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
     out = {'_units': 'bytes per launch; fetch = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024',
            '_source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 '
-                      '--cpu-baseline 0 --votes 0 --prepare 0 (two passes)'}
+                      '--cpu-baseline 0 --votes 1 --prepare 0 (two passes)'}
     cal = None
     if 'bn_stats_kernel' in fetch and 'bn_apply_kernel' in write:
         cal = fetch['bn_stats_kernel'][0] / max(write['bn_apply_kernel'][0], 1e-9)
