@@ -509,16 +509,32 @@ __global__ __launch_bounds__(256) void label_hist_batch_kernel(const MaskScene* 
         d.labels[r] = best;
     }
 }
-__global__ void mask_gather_batch_kernel(const MaskScene* __restrict__ sc, int n_scenes) {
-    int64_t r;
-    const int s = scene_of_row(sc, n_scenes, blockIdx.y, true, r);
-    if (s < 0) return;
-    const MaskScene d = sc[s];
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= d.n_pts) return;
-    const int64_t row = d.rows ? d.rows[r] : r;
-    const int64_t v = d.index ? d.index[p] : p;
-    d.out[r * d.n_pts + p] = (uint8_t)((d.bits[row * d.words + (v >> 6)] >> (v & 63)) & 1ull);
+// bit rows -> byte masks of ALL kept rows of a scene: a thread owns four consecutive output points, reads their voxel
+// indices ONCE (the per-row kernel re-read the 8-byte index for every instance: 99 x 9.6 MB on the benchmark batch) and
+// writes one 4-byte word per row
+__global__ __launch_bounds__(256) void mask_gather_batch_kernel(const MaskScene* __restrict__ sc) {
+    const MaskScene d = sc[blockIdx.y];
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= d.n_pts || d.kk == 0) return;
+    int64_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t p = p0 + u < d.n_pts ? p0 + u : d.n_pts - 1;
+        v[u] = d.index ? d.index[p] : p;
+    }
+    const bool whole = p0 + 3 < d.n_pts && ((d.n_pts & 3) == 0);     // the row pitch keeps 4-byte alignment
+    for (int64_t r = 0; r < d.kk; ++r) {
+        const uint64_t* brow = d.bits + (d.rows ? (int64_t)d.rows[r] : r) * d.words;
+        uint32_t w = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w |= (uint32_t)((brow[v[u] >> 6] >> (v[u] & 63)) & 1ull) << (8 * u);
+        uint8_t* o = d.out + r * d.n_pts + p0;
+        if (whole) *(uint32_t*)o = w;
+        else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (p0 + u < d.n_pts) o[u] = (uint8_t)(w >> (8 * u));
+        }
+    }
 }
 extern "C" int b2m_mask_project_batch(const int64_t* desc, int32_t n_scenes, int64_t total_sel, int64_t max_words,
                                       float mask_bin_th, void* stream) {
@@ -549,11 +565,11 @@ extern "C" int b2m_label_hist_batch(const int64_t* desc, int32_t n_scenes, int64
     return B2M_OK;
 }
 extern "C" int b2m_mask_gather_batch(const int64_t* desc, int32_t n_scenes, int64_t total_kept, int64_t max_pts, void* stream) {
-    B2M_CHECK_ARG(n_scenes >= 0 && total_kept >= 0 && total_kept <= 65535 && max_pts >= 0, "bad sizes (at most 65535 rows per batch)");
+    B2M_CHECK_ARG(n_scenes >= 0 && n_scenes <= 65535 && total_kept >= 0 && max_pts >= 0, "bad sizes");
     if (n_scenes == 0 || total_kept == 0 || max_pts == 0) return B2M_OK;
     B2M_CHECK_ARG(desc, "NULL argument");
-    mask_gather_batch_kernel<<<dim3((unsigned)cdiv64(max_pts, 256), (unsigned)total_kept), 256, 0, (hipStream_t)stream>>>(
-        (const MaskScene*)desc, n_scenes);
+    mask_gather_batch_kernel<<<dim3((unsigned)cdiv64(max_pts, 1024), (unsigned)n_scenes), 256, 0, (hipStream_t)stream>>>(
+        (const MaskScene*)desc);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
