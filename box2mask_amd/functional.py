@@ -229,27 +229,6 @@ def join_side_streams():
         torch.cuda.current_stream(dev).wait_stream(st)
 
 
-# ---- the shortcut branch of a BasicBlock on a stream of its own
-# conv1 -> norm1 -> conv2 and the 1x1 shortcut convolution of a block read the same input and meet only in the last
-# BatchNorm (resnet.py:70-83).  The forward pass is otherwise one dependency chain on one stream, so the 1x1 layer (a
-# streaming GEMM without LDS) is issued on a second stream BESIDE conv1 and fills the slots the LDS-bound convolution
-# waves leave; autograd runs a node's backward on the stream of its forward, so the shortcut's data / weight gradients
-# overlap the main chain's in the backward pass too.  B2M_FWD_FORK=0 (and the deterministic mode) keep one stream.
-_fork = {'streams': {}}
-
-
-def forward_fork() -> bool:
-    return os.environ.get('B2M_FWD_FORK', '1') == '1' and not deterministic()
-
-
-def fork_stream(device):
-    st = _fork['streams'].get(device)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _fork['streams'][device] = st
-    return st
-
-
 class _SparseConv(torch.autograd.Function):
     """Sparse convolution Y[o] = sum_k X[in_k(o)] W[k] (+bias).  [ME-mem] MinkowskiConvolution /
     MinkowskiConvolutionTranspose forward+backward (/root/reference/models/resnet.py:61-65,

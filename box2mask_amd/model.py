@@ -67,25 +67,6 @@ class Model:
         self._id2idx_dev = None
         self._pf_stream = None
         self._prefetched = None
-        self._step_marks = []
-
-    def _bound_run_ahead(self):
-        """The host enqueues a step in a quarter of the time the device needs for it, and nothing in the step makes it wait:
-        in a loop that never reads a loss it ends up many steps ahead.  Every tensor a second stream touched
-        (record_stream: the weight-gradient stream, the prefetched maps) can be handed out again only once that stream's
-        work is known to be done WHEN THE NEXT ALLOCATION IS MADE -- which, that far ahead, it never is: the caching
-        allocator grew to 30.6 GB over 25 steps (round 2, `peak_mem_gb` of the driver's run) where a step needs 15.8.
-        So a step is enqueued only once the device has begun the step before it (B2M_MAX_RUN_AHEAD steps, default 1;
-        0 = unbounded): the queue stays full, the footprint stays that of one step.  The reference's loop reads every
-        loss with .item() in every iteration (training.py:170-174) and never runs ahead at all."""
-        n = int(os.environ.get('B2M_MAX_RUN_AHEAD', '1'))
-        if n <= 0 or not torch.cuda.is_available():
-            return
-        while len(self._step_marks) >= n:
-            self._step_marks.pop(0).synchronize()
-        ev = torch.cuda.Event()
-        ev.record()
-        self._step_marks.append(ev)
 
     def compute_loss(self, batch, epoch):
         losses_dict, pred = self.compute_loss_detection(batch, epoch)
@@ -152,7 +133,6 @@ class Model:
         """model.py:38-225: same loss terms, keys and weights."""
         device = self.device
         cfg = self.cfg
-        self._bound_run_ahead()
         on_fg = cfg.loss_on_fg_instances or cfg.bb_supervision
         # The reference selects the foreground rows with a boolean mask in every loss term (model.py:65-66 ...): each such
         # indexing is a host read of the row count.  Here the row list is made ONCE, BEFORE the forward pass is enqueued (the

@@ -6,10 +6,8 @@ The block's forward is the reference's conv-BN-ReLU-conv-BN (+1x1conv-BN residua
 """
 from __future__ import annotations
 
-import torch
 from torch import nn
 
-from . import functional as F_
 from . import nn as ME
 
 
@@ -30,29 +28,14 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        # The 1x1 shortcut convolution depends on the block input only: with a shortcut, remember the point of the stream
-        # where that input is complete, so that the shortcut can be issued on a second stream beside conv1 .. conv2
-        first = ME._sources(x)[0]                      # (never x.F: on an ME.cat result that would materialise the concat)
-        fork = self.downsample is not None and first.is_cuda and F_.forward_fork()
-        ready = torch.cuda.current_stream().record_event() if fork else None
         # (x from here on: the alias conv1 hands back -- the residual / shortcut gradient is then summed with conv1's data
         # gradient inside the convolution kernel, not by an add kernel per block)
         out, x = self.conv1(x, passthrough=True)
         ck = ME.count_key_of(out)
-        res = None
-        if fork:
-            main, side = torch.cuda.current_stream(), F_.fork_stream(first.device)
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                res = self.downsample[0](x)
         out = out.new(self.norm1.apply_bn(out.F, relu=True, count_key=ck, defer_counter=True))
         out = self.conv2(out)
         if self.downsample is not None:
-            if res is None:
-                res = self.downsample[0](x)
-            else:
-                main.wait_stream(side)
-                res.F.record_stream(main)            # allocated on the side stream, consumed (and later freed) on this one
+            res = self.downsample[0](x)
             # norm2 and the shortcut's BatchNorm are independent and meet in the add: one paired operator (one apply, one
             # backward reduction, one SyncBN exchange per direction for both layers) where it applies
             y = ME.batch_norm_add_relu(self.norm2, out.F, self.downsample[1], res.F, relu=True, defer_counter=True,
