@@ -418,6 +418,168 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 #endif
 }
 
+// conv_stem_kernel: the network's first layer -- 5x5x5, 6 (padded 8) -> 32 channels on the level-0 map: 125 offsets with
+// ~15 pairs each per tile, 4 MFMAs of work per (tile, offset).  In conv_fwd_kernel every offset is a chain of two
+// dependent memory round trips (pair list, then the gathered rows) in front of those 4 MFMAs and an LDS update behind
+// them: 1.12 ms at 12 TFLOP/s, all of it latency, and as the first kernel of a step nothing runs beside it.  Here the walk
+// over the tile's ACTIVE offsets is software-pipelined by hand: while offset k multiplies and updates the strip, the rows of
+// the next active offset are in flight and the pair list of the one after is being fetched.
+// One wave per tile (cout <= 32: one strip), 4 tiles per workgroup; single source, 8-channel chunk, un-split maps.
+__global__ __launch_bounds__(256, 3) void conv_stem_kernel(ConvArgs a) {
+    constexpr int TW = 2, SW = 32;
+    __shared__ float smem[4 * (B2M_TILE + 1) * SW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t wg = wg_index(a.nwg, a.xcd_per);
+    if (wg < 0) return;
+    const int64_t tile = wg * 4 + wave;
+    if (tile >= a.ntiles) return;
+    const int64_t ldr = a.ntiles * B2M_TILE, row0 = tile * B2M_TILE;
+    float* Cs = smem + wave * ((B2M_TILE + 1) * SW);
+    for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+        const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int64_t grow = row0 + row;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int col = c4 + u;
+            if (col < a.cout) {
+                float t = a.bias ? a.bias[col] : 0.f;
+                if (a.accumulate && grow < a.n_out) t += a.y[grow * a.ldy + col];
+                v[u] = t;
+            }
+        }
+        *(f32x4*)&Cs[cs_index<TW>(row, c4)] = v;
+    }
+    int cnt0 = 0, cnt1 = 0;
+    if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
+    if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
+    const uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
+    auto next_active = [&](int k) -> int {
+        int kk = k + 1;
+        if (kk < 64) {
+            const uint64_t r = m0 >> kk;
+            if (r) return kk + __builtin_ctzll(r);
+            kk = 64;
+        }
+        if (kk < 128) {
+            const uint64_t r = m1 >> (kk - 64);
+            if (r) return kk + __builtin_ctzll(r);
+        }
+        return -1;
+    };
+    auto count_of = [&](int k) { return k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64); };
+    const uint32_t ld4 = (uint32_t)a.ldx1 * 4u;
+    // operands of offset k: lane (i, q) gathers channels 2q, 2q + 1 of its row per group; one 16-byte weight piece
+    auto load_ops = [&](int k, const int (&idx)[NG], f32x2 (&av)[NG], f32x4& wv) {
+        const int Gk = (count_of(k) + 15) >> 4;                             // row groups the offset has: the others are not fetched
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g < Gk) {                                                   // wave-uniform
+                const uint32_t r = idx[g] < 0 ? 0u : (uint32_t)idx[g];      // padded slots read row 0, their result is never used
+                av[g] = *(const f32x2*)((const char*)a.x1 + (__umul24(r, ld4) + 8u * (uint32_t)q));
+            }
+        }
+        wv = *(const f32x4*)((const char*)a.wp + (size_t)k * 1024 + (size_t)lane * 16);   // block (k, strip 0, chunk 0): [lane][s][t]
+    };
+    // Three active offsets in the pipe: offset t multiplies while the rows of t + 1 have been in flight for one offset and those of
+    // t + 2 are issued now; the input-row list of t + 3 goes out with them, its output-row words behind the strip update.  With a
+    // single offset of look-ahead one memory latency per offset was the whole run time (0.72 ms; the layer's MFMAs are 0.15 ms).
+    // The three operand sets take turns under a period-3 unroll: NO register of an in-flight load is ever moved (a v_mov of a
+    // load destination needs vmcnt(0): a first version that rotated the sets by copying ran exactly as fast as no pipeline).
+    auto load_idx = [&](int k, int (&idx)[NG]) {
+        const int64_t base = (int64_t)k * ldr + row0;
+        const int Gk = (count_of(k) + 15) >> 4;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) if (g < Gk) idx[g] = a.rb_in[base + 16 * g + i];
+    };
+    auto load_out = [&](int k, uint32_t (&out)[NG]) {
+        const int64_t base = (int64_t)k * ldr + row0;
+        const int Gk = (count_of(k) + 15) >> 4;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) if (g < Gk) out[g] = *(const uint32_t*)(a.rb_out + base + 16 * g + 4 * q);
+    };
+    int k0 = next_active(-1);
+    if (k0 >= 0) {
+        int idx[NG];
+        uint32_t out[3][NG];
+        f32x2 av[3][NG];
+        f32x4 w[3];
+        // (a drained queue position repeats the last valid offset: harmless loads, never used)
+        int k1 = next_active(k0);
+        int k2 = k1 < 0 ? -1 : next_active(k1);
+        int k3 = k2 < 0 ? -1 : next_active(k2);
+        auto valid = [&](int k, int fallback) { return k < 0 ? fallback : k; };
+        {
+            const int k1c = valid(k1, k0), k2c = valid(k2, k1c);
+            int idx0[NG], idx1[NG];
+            load_idx(k0, idx0); load_idx(k1c, idx1); load_idx(k2c, idx);
+            load_out(k0, out[0]); load_out(k1c, out[1]); load_out(k2c, out[2]);
+            load_ops(k0, idx0, av[0], w[0]);
+            load_ops(k1c, idx1, av[1], w[1]);
+        }
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (k0 < 0) { more = false; break; }            // (wave-uniform)
+                const int n = count_of(k0);
+                const int G = (n + 15) >> 4;
+                const int k2c = valid(k2, valid(k1, k0)), k3c = valid(k3, k2c);
+                load_ops(k2c, idx, av[(u + 2) % 3], w[(u + 2) % 3]);       // idx = input rows of offset t + 2 (fetched one offset ago)
+                load_idx(k3c, idx);
+                f32x4 acc[NG][TW];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g < G) {                                    // wave-uniform
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) {
+                            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g][0], w[u][t], c, 0, 0, 0);          // w = [s][t]: s = 0
+                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][g][1], w[u][2 + t], c, 0, 0, 0);
+                        }
+                    }
+                }
+                // add into the strip: D[row = 4q + r][col = i]; the pairs of an offset have distinct output rows; padded pairs go
+                // to the spare row B2M_TILE
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g < G) {
+                        int ad[4];
+                        float old[4][TW];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ad[r] = (16 * g + 4 * q + r < n) ? (int)((out[u][g] >> (8 * r)) & 255) : B2M_TILE;
+#pragma unroll
+                            for (int t = 0; t < TW; ++t) old[r][t] = Cs[cs_index<TW>(ad[r], 16 * t + i)];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int t = 0; t < TW; ++t) Cs[cs_index<TW>(ad[r], 16 * t + i)] = old[r][t] + acc[g][t][r];
+                    }
+                }
+                load_out(k3c, out[u]);                          // (this set's words have just been used)
+                k0 = k1; k1 = k2; k2 = k3;
+                k3 = k2 < 0 ? -1 : next_active(k2);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+        const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
+        const int64_t grow = row0 + row;
+        if (grow >= a.n_out) continue;
+        const f32x4 v = *(const f32x4*)&Cs[cs_index<TW>(row, c4)];
+        float* dst = a.y + grow * a.ldy + c4;
+        if (a.vec_store && c4 + 3 < a.cout) *(f32x4*)dst = v;
+        else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (c4 + u < a.cout) dst[u] = v[u];
+        }
+    }
+}
+
 #include "conv_fwd_flow.h"
 #include "conv_1x1.h"
 
@@ -760,6 +922,13 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
             B2M_LAUNCH_CHECK();
             return B2M_OK;
         }
+    }
+    // the first layer's shape (one 8-channel chunk, one 32-column strip, un-split): the hand-pipelined walk over the offsets
+    if (KC == 8 && !ident && fast && cin == 8 && c2 == 0 && nslice == 1 && a.nstrips == 1 && TW == 2 && a.fast32 &&
+        !tile_stats && env_flag("B2M_CONV_STEM", 1)) {
+        conv_stem_kernel<<<grid, 256, 0, st>>>(a);
+        B2M_LAUNCH_CHECK();
+        return B2M_OK;
     }
     const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (fast ? 0 : 1);
     // chunks of loads in flight per wave: 2 pays on the 48-column-strip layers with >= 4 chunks (+7 % in the A/B of
