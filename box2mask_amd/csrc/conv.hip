@@ -564,6 +564,27 @@ __global__ __launch_bounds__(256, 3) void conv_stem_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
+    if (a.stats && lane < a.cout) {
+        // column sums of the finished strip for the BatchNorm that follows (fp64, four independent chains), as
+        // strip_column_sums does for the flow kernel: bn0 then needs no pass over the 1.2 M x 32 output
+        const int64_t rem = a.n_out - row0;
+        const int rows = rem < B2M_TILE ? (int)rem : B2M_TILE;
+        double s1[4] = {0., 0., 0., 0.}, s2[4] = {0., 0., 0., 0.};
+        int r = 0;
+        for (; r + 3 < rows; r += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double v = (double)Cs[cs_index<TW>(r + u, lane)];
+                s1[u] += v; s2[u] = fma(v, v, s2[u]);
+            }
+        }
+        for (; r < rows; ++r) {
+            const double v = (double)Cs[cs_index<TW>(r, lane)];
+            s1[0] += v; s2[0] = fma(v, v, s2[0]);
+        }
+        double* o = a.stats + tile * 2 * a.cout + lane;
+        o[0] = (s1[0] + s1[1]) + (s1[2] + s1[3]); o[a.cout] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    }
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
@@ -923,7 +944,11 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     }
     // the first layer's shape (one 8-channel chunk, one 32-column strip, un-split): the hand-pipelined walk over the offsets
     if (KC == 8 && !ident && fast && cin == 8 && c2 == 0 && nslice == 1 && a.nstrips == 1 && TW == 2 && a.fast32 &&
-        !tile_stats && env_flag("B2M_CONV_STEM", 1)) {
+        env_flag("B2M_CONV_STEM", 1)) {
+        if (tile_stats) {                      // the workgroup that writes a tile sees its final values (un-split)
+            a.stats = tile_stats;
+            if (wrote_stats) *wrote_stats = 1;
+        }
         conv_stem_kernel<<<grid, 256, 0, st>>>(a);
         B2M_LAUNCH_CHECK();
         return B2M_OK;

@@ -302,3 +302,38 @@ def test_conv_tile_stats_feed_batchnorm(maps, monkeypatch, regime, cin, cout):
     _close(rv1, rv0, 'running var', 1e-5)
     for a, b, nm in zip(g1, g0, ('dW', 'dgamma', 'dbeta')):
         _close(a, b, nm, 1e-4)
+
+
+@pytest.mark.parametrize('stem', ['1', '0'])
+def test_stem_kernel_and_its_tile_stats(maps, monkeypatch, stem):
+    """The network's first layer (5x5x5, 6 -> 32: conv_stem_kernel, B2M_CONV_STEM=0: conv_fwd_kernel) through the autograd
+    operator with its 6-channel input: output and the per-tile column sums against the oracle / the output itself, and the
+    two kernels against each other bit for bit (same summation order)."""
+    from box2mask_amd import functional as F_
+    from oracle import sparse_ref as S
+    m, h = maps
+    rb = m.rulebook_same(0, 5)
+    n = rb.n_out
+    torch.manual_seed(5)
+    x = torch.randn(n, 6)
+    w = torch.randn(125, 6, 32) * 0.05
+    monkeypatch.setenv('B2M_CONV_STEM', stem)
+    y = F_.sparse_conv(x.cuda(), None, w.cuda(), None, rb, rb, True, n, collect_stats=True)
+    ts = getattr(y, '_b2m_tile_stats', None)
+    # oracle on the manager's (Morton) row order: permute the oracle's rows by coordinates
+    kg = S.pack_keys(m.coords[0].cpu().numpy()); ko = S.pack_keys(h.coords[0])
+    order = np.argsort(kg); to_gpu = torch.from_numpy(order[np.searchsorted(kg[order], ko)])
+    xo = torch.empty_like(x); xo[:] = x[to_gpu]            # oracle row r holds the device row to_gpu[r]
+    yo = S.conv_nbr(xo, w, h.k_first())
+    _close(y.cpu()[to_gpu], yo, 'stem forward (B2M_CONV_STEM=%s)' % stem)
+    if stem == '1':
+        assert ts is not None and ts[1] == (n + 63) // 64
+        pad = torch.zeros(ts[1] * 64 - n, 32, device='cuda')
+        yt = torch.cat([y, pad]).reshape(ts[1], 64, 32).double()
+        _close(ts[0][:, 0].double(), yt.sum(1), 'tile sums', 1e-5)
+        _close(ts[0][:, 1].double(), (yt * yt).sum(1), 'tile sums of squares', 1e-5)
+        monkeypatch.setenv('B2M_CONV_STEM', '0')
+        y_old = F_.sparse_conv(x.cuda(), None, w.cuda(), None, rb, rb, True, n)
+        assert torch.equal(y, y_old), 'the two stem kernels differ'
+    else:
+        assert ts is None
