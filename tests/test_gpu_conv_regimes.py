@@ -318,6 +318,7 @@ def test_stem_kernel_and_its_tile_stats(maps, monkeypatch, stem):
     x = torch.randn(n, 6)
     w = torch.randn(125, 6, 32) * 0.05
     monkeypatch.setenv('B2M_CONV_STEM', stem)
+    monkeypatch.setenv('B2M_CONV_TARGET', '0')          # un-split, as the 19 k-tile map of a benchmark batch runs (small maps are split)
     y = F_.sparse_conv(x.cuda(), None, w.cuda(), None, rb, rb, True, n, collect_stats=True)
     ts = getattr(y, '_b2m_tile_stats', None)
     # oracle on the manager's (Morton) row order: permute the oracle's rows by coordinates
