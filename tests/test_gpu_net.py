@@ -240,11 +240,11 @@ def test_training_trajectory_matches_oracle(monkeypatch):
     monkeypatch.setenv('B2M_DETERMINISTIC', '1')       # ordered reductions: reproducible trajectory
     """Three normalised-gradient steps of the whole network (train-mode BatchNorm, all heads) on the device and on the
     CPU oracle from the same initial weights.  Catches anything that only shows up once the weights move (stale
-    packed weights, gradient accumulation, state carried between steps).  BatchNorm over the 8 rows of the deepest
-    levels amplifies rounding noise into the gradient direction (the fp32 oracle drifts 2 % from the fp64 one in
-    three steps, and two runs of the device path -- atomics order -- differ by as much), so this is a check of the
-    loop, not of the last digits: same first loss, every later loss within 4 % of the fp64 oracle (the run is in
-    deterministic mode, so the numbers are reproducible), and it trains."""
+    packed weights, gradient accumulation, state carried between steps).  32 small scenes: the deepest level keeps >= 32
+    rows, so the batch statistics are well conditioned and the trajectories stay together (with 8 scenes -- 8 rows at level
+    7 -- rounding noise and ReLU sign flips were amplified into the gradient direction: the fp32 oracle drifted 1.4 % from
+    the fp64 one in three steps and the device 1 ... 4 % depending on which kernel summed the first layer's statistics).
+    Same first loss, every later loss within 1.5 % of the fp64 oracle, and it trains."""
     from box2mask_amd.detection_net import SelectionNet
     from box2mask_amd import nn as ME
     from oracle import unet_ref, sparse_ref
@@ -253,7 +253,7 @@ def test_training_trajectory_matches_oracle(monkeypatch):
     torch.manual_seed(3)
     net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6]).cuda()
     net.train()
-    batch = synth.make_batch(8, seed0=12, target_voxels=2000, pts_per_m2=6000.0)
+    batch = synth.make_batch(32, seed0=12, target_voxels=1500, pts_per_m2=6000.0)
     S_ = batch['input_location'].shape[0]
     heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
     sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
@@ -300,4 +300,4 @@ def test_training_trajectory_matches_oracle(monkeypatch):
     assert abs(dev[0] - o64[0]) <= 1e-5 * abs(o64[0])
     assert all(x > y for x, y in zip(dev, dev[1:])) and o64[-1] < o64[0]       # it trains, every step
     for a, c in zip(dev, o64):
-        assert abs(a - c) <= 0.04 * abs(c), (dev, o32, o64)     # deterministic mode: observed 1.0 % / 1.7 % (fp32 oracle: 1.7 %)
+        assert abs(a - c) <= 0.015 * abs(c), (dev, o32, o64)
