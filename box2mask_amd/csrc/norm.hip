@@ -254,6 +254,16 @@ extern "C" int b2m_bn_tilestats(const double* tile_stats, int64_t ntiles, int32_
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
+extern "C" int b2m_bn_bwd_tilesums(const double* tile_sums, int64_t ntiles, int32_t c, double* partial, double* sums,
+                                   float* dbeta_f32, float* dgamma_f32, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(tile_sums && partial && sums && ntiles >= 1 && c > 0 && c <= 1024, "bad arguments");
+    const int nblk = tilestats_blocks(ntiles);
+    bn_tilestats_kernel<<<nblk, 256, 0, st>>>(tile_sums, ntiles, 2 * c, partial);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, dbeta_f32, dgamma_f32);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
 extern "C" int b2m_bn_tilestats_finalize(const double* tile_stats, int64_t ntiles, int64_t n, int32_t c, double* partial,
                                          double* stats, const float* gamma, const float* beta, float eps, float momentum,
                                          float* running_mean, float* running_var, float* mean, float* invstd, float* scale,

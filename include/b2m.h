@@ -190,6 +190,24 @@ int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const
 
 /* ---------------------------------------------------------------- batch norm / elementwise (fp32, HBM-bound) */
 
+/* b2m_conv_fwd for a DATA-GRADIENT launch whose output Y is the gradient of a BatchNorm's output y = [relu](BN(x))
+ * (this convolution's forward input): the kernel also leaves, per tile of 64 rows, the backward reduction of that BatchNorm --
+ *   tile_sums[tile][0][col] = sum g,   tile_sums[tile][1][col] = sum g * xhat,   g = Y * (bn_y > 0 if bn_y), xhat = (bn_x - mean) * invstd
+ * (fp64, [ceil(n_out / 64)][2][cout]) -- which b2m_bn_bwd_tilesums turns into the sums b2m_bn_bwd_apply needs: the pass of
+ * b2m_bn_bwd_reduce over (dy, x) disappears (/root/reference/models/resnet.py:63-82: every BatchNorm is fed by and feeds a
+ * convolution).  *wrote (host) = 1 if this shape's kernel provided them (whole 16-channel chunks, a real rulebook, un-split map
+ * or exactly 4 slices without accumulate, cout % 4 == 0, 16-byte aligned rows), else 0 and the caller reduces as before.
+ * Y must be the COMPLETE gradient when the launch ends (accumulate = 1 onto the other consumers' gradient is fine). */
+int b2m_conv_fwd_bnbwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2, int64_t n_in,
+                       const float* wp, int32_t K, const float* bias, const int32_t* rb_in, const uint8_t* rb_out,
+                       const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy, int32_t cout, int32_t accumulate,
+                       const float* bn_x, int64_t ld_bn_x, const float* bn_y, int64_t ld_bn_y, const float* bn_mean,
+                       const float* bn_invstd, double* tile_sums, int32_t* wrote, void* stream);
+/* tile_sums of b2m_conv_fwd_bnbwd -> sums[0:c] = sum g, sums[c:2c] = sum g * xhat (+ fp32 copies dbeta / dgamma, may be NULL):
+ * what b2m_bn_bwd_reduce returns.  partial: double[2*c*1280] scratch.  Fixed summation order. */
+int b2m_bn_bwd_tilesums(const double* tile_sums, int64_t ntiles, int32_t c, double* partial, double* sums, float* dbeta_f32,
+                        float* dgamma_f32, void* stream);
+
 /* Column sums for BatchNorm: stats[0:c] = sum x, stats[c:2c] = sum x^2 (double), deterministic
  * two-stage reduction.  partial: double[2*c*nblk_max] scratch with nblk_max = 4096.
  * Replaces the reduction inside torch.nn.BatchNorm1d wrapped by ME.MinkowskiBatchNorm
