@@ -360,8 +360,8 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(maps, monkeypat
     x0 = torch.randn(n, cin, device='cuda')
     r0 = torch.randn(n, cmid, device='cuda')
     w1_0 = torch.randn(27, cin, cmid, device='cuda') * 0.05
-    w2_0 = torch.randn(27, cmid, 48, device='cuda') * 0.05
-    gy = torch.randn(n, 48, device='cuda')
+    w2_0 = torch.randn(27, cmid, 64, device='cuda') * 0.05          # (64: an even number of 16-channel chunks, as every layer of the network has)
+    gy = torch.randn(n, 64, device='cuda')
 
     def run(flag):
         monkeypatch.setenv('B2M_BN_BWD_FROM_CONV', flag)
