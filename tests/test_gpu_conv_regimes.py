@@ -390,6 +390,9 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(maps, monkeypat
         assert 'b2m_bn_bwd_tilesums' not in c1 and 'b2m_bn_bwd_reduce' in c1        # the kernel could not provide the sums
     else:
         assert 'b2m_bn_bwd_tilesums' in c1 and 'b2m_bn_bwd_reduce' not in c1
-    assert torch.equal(y1, y0)
+    if regime == 'many_slices':
+        _close(y1, y0, 'forward', 1e-5)            # (atomic combine: the order of the additions differs from run to run)
+    else:
+        assert torch.equal(y1, y0)
     for a, b, what in zip(g1, g0, ('dx', 'dw1', 'dw2', 'dgamma', 'dbeta', 'dres')):
         _close(a, b, '%s (%s)' % (what, regime), 2e-5)
