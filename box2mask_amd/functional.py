@@ -374,9 +374,13 @@ def conv_tile_stats() -> bool:
 
 
 def bn_bwd_from_conv() -> bool:
-    """B2M_BN_BWD_FROM_CONV=0: the backward reduction of a BatchNorm (sum g, sum g * xhat) is always a pass of its own over
-    (dy, x) (b2m_bn_bwd_reduce) instead of coming from the epilogue of the data-gradient kernel that produced dy."""
-    return os.environ.get('B2M_BN_BWD_FROM_CONV', '1') == '1' and not deterministic()
+    """B2M_BN_BWD_FROM_CONV=1: the backward reduction of a BatchNorm (sum g, sum g * xhat) comes from the epilogue of the
+    data-gradient kernel that produced dy (b2m_conv_fwd_bnbwd + b2m_bn_bwd_tilesums) instead of a pass of its own over
+    (dy, x) (b2m_bn_bwd_reduce).  OFF by default: measured on the benchmark step it moves 0.9 ms from the HBM-bound
+    reduction into the MFMA-bound kernel's epilogue (20 launches, +46 us each: a wave's LDS-bound slot waits for the
+    tile's x and y rows) -- the sum of the kernels is unchanged, the step 0.3 ms shorter (inside the noise), and the
+    dominant kernel's roofline fraction 0.010 lower."""
+    return os.environ.get('B2M_BN_BWD_FROM_CONV', '0') == '1' and not deterministic()
 
 
 def bn_small_rows() -> int:
