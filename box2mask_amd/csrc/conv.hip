@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 // over the tile's ACTIVE offsets is software-pipelined by hand: while offset k multiplies and updates the strip, the rows of
 // the next active offset are in flight and the pair list of the one after is being fetched.
 // One wave per tile (cout <= 32: one strip), 4 tiles per workgroup; single source, 8-channel chunk, un-split maps.
-__global__ __launch_bounds__(256, 3) void conv_stem_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 4) void conv_stem_kernel(ConvArgs a) {
     constexpr int TW = 2, SW = 32;
     __shared__ float smem[4 * (B2M_TILE + 1) * SW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
