@@ -1433,82 +1433,6 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restri
     }
 }
 
-// wgrad_stem_kernel: weight gradient of the network's first layer (5x5x5, 6 -> 32).  On the MFMA kernels a (16 ci x 32 co)
-// block holds 6 useful rows: 0.3 ms of its 0.71 ms were MFMAs on padding, the rest 4-byte gathers -- and as the LAST kernel of
-// a step nothing runs beside it.  With 6 x 32 products per pair this is vector work: lane (pair slot p of 4, output-channel
-// quad c4 of 8) keeps dW[k][0..CI)[4 c4 .. 4 c4 + 3] of ITS pairs in 4 CI registers; per step a wave takes eight pairs: one
-// 16-byte dy load per lane (128 contiguous bytes per pair), the pair's input row as two 16-byte loads (the 8 lanes of a slot
-// read the same address), 4 CI FMAs.  Same (offset, tile chunk) -> wave decomposition and pair lists as the MFMA kernels
-// (wgrad_item, kpack = 4: the four waves of a workgroup are four offsets on one tile chunk, its dy rows shared in L1); the
-// eight pair slots meet by cross-lane adds, one atomic per dW element and wave.
-template <int CI>
-__global__ __launch_bounds__(256) void wgrad_stem_kernel(WgradArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = lane & 15;                 // list entry this lane loads
-    const int c4 = lane & 7, p = lane >> 3;  // output channels 4 c4 .. + 3 of pair slot p (8 slots)
-    int k, blk;
-    int64_t chunk, t0, t1;
-    if (!wgrad_item(a, wave, k, blk, chunk, t0, t1)) return;
-    const int64_t ldr = a.ntiles * B2M_TILE;
-    const int nt = (int)(t1 - t0);
-    int cnt = 0;
-    if (lane < nt) cnt = a.rb_cnt[(int64_t)k * a.ntiles + t0 + lane];
-    uint64_t live = __ballot(cnt > 0);
-    if (live == 0) return;
-    const int64_t kbase = (int64_t)k * ldr + t0 * B2M_TILE;
-    const uint32_t ldx4 = (uint32_t)a.ldx * 4u, lddy4 = (uint32_t)a.lddy * 4u;
-    float acc[CI][4];
-#pragma unroll
-    for (int c = 0; c < CI; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f;
-    while (live) {
-        const int ti = __builtin_ctzll(live);
-        live &= live - 1;
-        const int n = __builtin_amdgcn_readlane(cnt, ti);
-        const uint32_t row0 = (uint32_t)((t0 + ti) * B2M_TILE);
-        for (int g = 0; 16 * g < n; ++g) {
-            // the slot's 16 pairs: lane (i, .) loads entry i; word = input row | row inside the tile << 24, bit 31 = no pair
-            const int64_t base = kbase + (int64_t)ti * B2M_TILE + 16 * g + i;
-            const int r_in = a.rb_in[base];
-            const int r_out = a.rb_out[base];
-            const uint32_t word = r_in < 0 ? 0x80000000u : ((uint32_t)r_in | ((uint32_t)r_out << 24));
-            const int steps = ((n - 16 * g < 16 ? n - 16 * g : 16) + 7) >> 3;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (s < steps) {                                  // wave-uniform
-                    const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((8 * s + p) << 2, (int)word);
-                    const bool ok = (int)w >= 0;
-                    const char* px = (const char*)a.x + __umul24(ok ? (w & 0xFFFFFFu) : 0u, ldx4);
-                    const char* py = (const char*)a.dy + (__umul24(row0 + (ok ? ((w >> 24) & 63u) : 0u), lddy4) + 16u * (uint32_t)c4);
-                    const f32x4 x0 = *(const f32x4*)px;
-                    f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (CI > 4) x1 = *(const f32x4*)(px + 16);
-                    f32x4 d = *(const f32x4*)py;
-                    if (!ok) d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < CI; ++c) {
-                        const float xv = c < 4 ? x0[c] : x1[c - 4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[c][u] = __builtin_fmaf(xv, d[u], acc[c][u]);
-                    }
-                }
-            }
-        }
-    }
-    // the eight pair slots hold partial sums of the same (ci, co): add across lane groups, slot 0 adds into dW
-#pragma unroll
-    for (int c = 0; c < CI; ++c)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float v = acc[c][u];
-            v += __shfl_xor(v, 8, 64);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (p == 0 && c < a.cin && 4 * c4 + u < a.cout && v != 0.f)
-                atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)c * a.lddw + 4 * c4 + u], v);
-        }
-}
-
 template <int MI>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
     if (a.pipe) {
@@ -1581,31 +1505,6 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
         else if (cout <= 8) wgrad_narrow_kernel<8><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
         else if (cout <= 16) wgrad_narrow_kernel<16><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
         else wgrad_narrow_kernel<32><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
-        B2M_LAUNCH_CHECK();
-        return B2M_OK;
-    }
-    // the first layer's shape (<= 8 input channels in 32-byte-aligned rows of >= 8 floats, 32 output channels): vector FMAs
-    if (rb_in != nullptr && cin <= 8 && cout == 32 && K >= 4 && !workspace && ldx >= 8 && ldx % 4 == 0 && lddy % 4 == 0 &&
-        ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && n_out < (1 << 24) && n_in < (1 << 24) && ldx < (1 << 22) &&
-        lddy < (1 << 22) && n_out * lddy * 4 < (1ll << 32) && n_in * ldx * 4 < (1ll << 32) && env_flag("B2M_WGRAD_STEM", 1)) {
-        a.nmb = a.nnb = 1; a.nz = 1; a.kpack = 4; a.kgroups = (K + 3) / 4; a.partial = nullptr; a.pipe = 0; a.fast32 = 1;
-        const bool large = a.ntiles >= 2048;
-        int64_t tpc = cdiv64(a.ntiles, cdiv64(large ? 32768 : 16384, K));
-        if (tpc < 8) tpc = 8;
-        if (tpc > 64) tpc = 64;
-        a.tiles_per_chunk = (int)tpc;
-        a.nwg = (int64_t)a.kgroups * cdiv64(a.ntiles, tpc);
-        const XcdOrder xo = xcd_order(a.nwg, env_flag("B2M_XCD", 1) ? (int64_t)(1 << 20) * a.kgroups : 0);
-        a.xcd_per = xo.chunk;
-        dim3 grid(xo.grid);
-        a.xcd_start = nullptr;
-        if (rb_cnt && a.ntiles >= B2M_BALANCE_MIN_TILES && env_flag("B2M_XCD", 1) && env_flag("B2M_XCD_BALANCE", 1)) {
-            a.xcd_start = rb_cnt + (int64_t)K * a.ntiles;
-            grid = dim3((unsigned)(8 * a.kgroups * cdiv64(B2M_XCD_CAP(a.ntiles), tpc)));
-        }
-        if (cin <= 4) wgrad_stem_kernel<4><<<grid, 256, 0, st>>>(a);
-        else if (cin <= 6) wgrad_stem_kernel<6><<<grid, 256, 0, st>>>(a);
-        else wgrad_stem_kernel<8><<<grid, 256, 0, st>>>(a);
         B2M_LAUNCH_CHECK();
         return B2M_OK;
     }
