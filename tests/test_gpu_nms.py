@@ -186,3 +186,63 @@ def test_detection2mask_no_cluster_survives_the_score_filter():
             assert len(r['conf']) == 0 and len(r['label_id']) == 0 and r['mask'].shape[0] == 0
             n = len(batch['vox2point'][b]) if mode == 'eval' else len(batch['seg2vox'][b])
             assert r['mask'].shape == (0, n)
+
+
+def test_detection2mask_batch_stages_with_an_empty_scene_against_oracle():
+    """The batched mask stages (one launch per stage over a descriptor table): 6 scenes of different sizes, one of them with
+    no cluster above the score threshold (ksel = 0 in the middle of the table) -- every scene bit for bit against the CPU
+    oracle's per-scene walk (oracle/nms_ref.py, pinned to the reference)."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    from oracle import nms_ref
+    cfg = scannet_config()
+    items = [synth.make_scene(50 + s, target_voxels=tv, pts_per_m2=7000.0) for s, tv in enumerate((3000, 9000, 1500, 6000, 12000, 2500))]
+    batch = synth.collate(items)
+    valid, id2idx, _, is_fg = synth.scannet_tables()
+    S = batch['input_location'].shape[0]
+    g = torch.Generator().manual_seed(11)
+    sem_idx = id2idx[batch['gt_semantics']].clamp_min(0)
+    scores = 2.0 * torch.randn(S, 1, generator=g)
+    scores[batch['batch_ids'] == 2] = -20.0                     # scene 2: nothing survives the score filter
+    pred = {cfg.mlp_offsets: batch['gt_bb_offsets'] + 0.025 * torch.randn(S, 3, generator=g),
+            cfg.mlp_bounds: (batch['gt_bb_bounds'] + 0.025 * torch.randn(S, 3, generator=g)).clamp_min(cfg.min_bb_size),
+            cfg.mlp_bb_scores: scores,
+            cfg.mlp_semantics: torch.nn.functional.one_hot(sem_idx, len(valid)).float()}
+    model = Model(cfg, *synth.scannet_tables())
+    res = model.pred2mask(batch, pred, 'eval')
+    total = 0
+    for b, sc in enumerate(batch['scene']):
+        m = (batch['batch_ids'] == b).numpy()
+        bbs = nms_ref.to_bbs_min_max(batch['input_location'][m].numpy(), pred[cfg.mlp_offsets][m].numpy(),
+                                     pred[cfg.mlp_bounds][m].numpy(), torch.sigmoid(pred[cfg.mlp_bb_scores])[m].numpy())
+        sem = valid[sem_idx[m]].long().numpy()
+        ref = nms_ref.detection2mask_scene(bbs, sem, lambda x: (x > 2) & (x != 22), np.asarray(batch['seg2vox'][b]),
+                                           np.asarray(batch['vox2point'][b]), list(cfg.eval_ths), 'eval')
+        got = res[sc['name']]
+        assert np.array_equal(ref['conf'], got['conf'].numpy()), b
+        assert np.array_equal(ref['label_id'], got['label_id']), b
+        assert np.array_equal(ref['mask'], got['mask'].numpy()), b
+        if b == 2:
+            assert got['mask'].shape[0] == 0
+        total += got['mask'].shape[0]
+    assert total > 10
+
+
+def test_unique_insert_few_distinct_keys_and_mixed_waves():
+    """b2m_unique_insert through prepare._unique_inverse against np.unique: ground-truth-id-like input (1 M keys, 30 values,
+    long runs and random order: the wave-level election path), all-distinct keys (the per-lane path) and waves that mix both."""
+    from box2mask_amd import prepare
+    rng = np.random.default_rng(0)
+    vals = np.sort(rng.choice(10 ** 9, 30, replace=False)).astype(np.int64)
+    runs = np.repeat(vals[rng.integers(0, 30, 4000)], 250)                       # long runs
+    rnd = vals[rng.integers(0, 30, 300_000)]                                      # random order, few values
+    distinct = rng.permutation(500_000).astype(np.int64) * 7 + 1                  # all different
+    mixed = np.where(rng.random(400_000) < 0.5, vals[rng.integers(0, 30, 400_000)], rng.integers(0, 10 ** 12, 400_000))
+    for name, keys in (('runs', runs), ('random few', rnd), ('distinct', distinct), ('mixed', mixed), ('one', vals[:1]),
+                       ('same', np.full(1000, 42, np.int64))):
+        u, nu, inv, *_ = prepare._unique_inverse(torch.from_numpy(keys).cuda())
+        ru, rinv = np.unique(keys, return_inverse=True)
+        assert nu == len(ru), name
+        assert np.array_equal(u[:nu].cpu().numpy(), ru), name
+        assert np.array_equal(inv.cpu().numpy(), rinv.reshape(-1)), name

@@ -245,3 +245,23 @@ def test_batch_norm_pair_equals_two_batch_norms(n, c, monkeypatch):
         assert torch.equal(res[0][0], res[1][0]), 'paired forward differs from the two launches'
         for a, b, what in zip(res[0][1:], res[1][1:], ('dxa', 'dxb', 'dgamma_a', 'dbeta_a', 'dgamma_b', 'dbeta_b', 'rm_a', 'rv_a', 'rm_b', 'rv_b')):
             _close(a, b, '%s training=%s' % (what, training), 2e-6)
+
+
+@pytest.mark.parametrize('cin,cout,n', [(96, 3, 9752), (96, 1, 9752), (96, 20, 9752), (256, 13, 700), (320, 28, 1500), (32, 6, 5)])
+def test_narrow_weight_gradient_of_a_1x1_layer(cin, cout, n, monkeypatch):
+    """wgrad_narrow_kernel (1x1 layers with few output channels: the heads' last layers) against x^T dy, accumulating onto
+    a non-zero dW, incl. more than 256 input channels (two rounds) and fewer rows than a workgroup's chunk; and against the
+    MFMA kernels it replaces (B2M_WGRAD_NARROW=0)."""
+    from box2mask_amd import functional as F_
+    torch.manual_seed(cin * 100 + cout)
+    x = torch.randn(n, cin, device='cuda'); dy = torch.randn(n, cout, device='cuda')
+    dw0 = torch.randn(1, cin, cout, device='cuda')
+    ref = dw0[0].double() + x.double().t() @ dy.double()
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('B2M_WGRAD_NARROW', flag)
+        dw = dw0.clone()
+        F_.wgrad_raw(x, dy, None, 1, dw, 0)
+        _close(dw[0], ref, 'narrow wgrad %dx%d (B2M_WGRAD_NARROW=%s)' % (cin, cout, flag), 1e-5)
+        outs.append(dw)
+    _close(outs[0], outs[1], 'narrow vs MFMA kernel', 1e-5)
