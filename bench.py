@@ -50,7 +50,7 @@ class LaunchTimer:
         if name == 'b2m_bn_apply':
             # x, ldx, n, c, scale, shift, residual, ldr, relu, y, ldy: streams x (+ residual) in and y out
             meta = dict(bytes=4.0 * args[2] * args[3] * (3 if args[6] else 2))
-        elif name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_fwd_bnbwd'):      # same leading arguments
+        elif name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats'):      # same leading arguments
             # x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, acc
             # (the 6-channel network input is read through a zero-padded 8-channel view: its FLOPs count the logical 6)
             cin = (meta_in or {}).get('cin', args[2] + args[5])
@@ -198,7 +198,7 @@ def main():
     # (b2m_conv_fwd: `roofline_timed_region`, as it ran), and K more steps AFTER the H2D-inclusive repeat run with the side
     # stream off and all three kernels bracketed (`roofline`, `roofline_wgrad`, `roofline_bn_apply`: every kernel alone on
     # the chip, which is what a roofline fraction is about).
-    timer = LaunchTimer(['b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_fwd_bnbwd'])
+    timer = LaunchTimer(['b2m_conv_fwd', 'b2m_conv_fwd_stats'])
     _lib.set_hook(timer.hook)
 
     # Model.prefetch: the NEXT batch's sparse tensor (Morton order, coordinate hash, 7 strided + 16 kernel maps) is built
@@ -308,7 +308,7 @@ def main():
     timed_records = timer.records
     timer.records = []
     timer._drained = 0
-    timer.names = {'b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_fwd_bnbwd', 'b2m_conv_wgrad', 'b2m_bn_apply'}
+    timer.names = {'b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_wgrad', 'b2m_bn_apply'}
     prev_wgrad_stream = os.environ.get('B2M_WGRAD_STREAM')        # (a user-set value is restored afterwards)
     os.environ['B2M_WGRAD_STREAM'] = '0'
     _lib.reload_env()
@@ -343,7 +343,7 @@ def main():
         if name == 'b2m_bn_apply':
             hbm['ms'] += ms; hbm['bytes'] += meta['bytes']; hbm['launches'] += 1
             continue
-        if name in ('b2m_conv_fwd_stats', 'b2m_conv_fwd_bnbwd'):
+        if name == 'b2m_conv_fwd_stats':
             name = 'b2m_conv_fwd'
         P = pairs_of(meta, cache, rb_lookup)
         flops = 2.0 * P * meta['cin'] * meta['cout']
@@ -361,7 +361,7 @@ def main():
         for name, s_, e_, meta in timer.records:
             if name == 'b2m_bn_apply':
                 continue
-            key = ('conv_fwd' if name in ('b2m_conv_fwd_stats', 'b2m_conv_fwd_bnbwd') else name[4:], meta['K'], meta['cin'], meta['cout'], meta['n_out'])
+            key = ('conv_fwd' if name == 'b2m_conv_fwd_stats' else name[4:], meta['K'], meta['cin'], meta['cout'], meta['n_out'])
             d = shapes.setdefault(key, [0.0, 0.0, 0])
             d[0] += s_.elapsed_time(e_); d[1] += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']; d[2] += 1
         print('%-11s %4s %4s %4s %9s %6s %9s %8s' % ('kernel', 'K', 'cin', 'cout', 'n_out', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)
@@ -399,7 +399,7 @@ def main():
     # the heaviest layer shapes of the dominant kernel, each with its own fraction (same isolated-kernel pass)
     shp = {}
     for name, s_, e_, meta in timer.records:
-        if name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_fwd_bnbwd'):
+        if name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats'):
             d_ = shp.setdefault((meta['K'], meta['cin'], meta['cout'], meta['n_out']), [0.0, 0.0, 0])
             d_[0] += s_.elapsed_time(e_); d_[1] += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']; d_[2] += 1
     roofline['top_shapes'] = [

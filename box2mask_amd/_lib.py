@@ -34,8 +34,6 @@ PROTOTYPES = {
     'b2m_rulebook_balance': [P, I32, I64, P],
     'b2m_conv_fwd': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],
     'b2m_conv_fwd_stats': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P, P, P],
-    'b2m_conv_fwd_bnbwd': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P, I64, P, I64, P, P, P, P, P],
-    'b2m_bn_bwd_tilesums': [P, I64, I32, P, P, P, P, P],
     'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
     'b2m_weight_pack_run': [P, I32, I64, P],
     'b2m_conv_wgrad': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P, P],
@@ -49,7 +47,7 @@ PROTOTYPES = {
     'b2m_bn_bwd_apply': [P, I64, P, I64, P, I64, I64, I32, P, P, P, P, F64, P, I32, P, P, P, I64, P, I64, P],
     'b2m_bn_apply2': [P, I64, P, I64, I64, I32, P, P, P, P, I32, P, I64, P],
     'b2m_bn_bwd_reduce2': [P, I64, P, I64, P, I64, P, I64, I64, I32, P, P, P, P, I32, P, P, P],
-    'b2m_bn_bwd_apply2': [P, I64, P, I64, P, I64, P, I64, I64, I32, P, P, P, P, P, P, P, F64, P, I32, P, I64, P, I64, P, P, P, P, P],
+    'b2m_bn_bwd_apply2': [P, I64, P, I64, P, I64, P, I64, I64, I32, P, P, P, P, P, P, P, F64, P, I32, P, I64, P, I64, P, P, P, P, P, P],
     'b2m_bn_small_fwd': [P, I64, I64, I32, P, P, F32, F32, P, P, P, P, P, P, P, I64, I32, P, I64, P],
     'b2m_bn_small_bwd': [P, I64, P, I64, P, I64, I64, I32, P, P, P, I32, P, P, P, P, P, I64, P, I64, P],
     'b2m_relu_fwd': [P, I64, P, P],

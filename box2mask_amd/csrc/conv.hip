@@ -35,14 +35,6 @@ struct ConvArgs {
     const int32_t* tile_order; //          tile worked on at position j of that order (heavy tiles of a run's end first)
     double* stats;   // != NULL: per-tile column sums of the finished output, [tile][2][cout] (sum, sum of squares): the
                      // BatchNorm statistics of the following layer without another pass over Y (conv_fwd_flow_kernel only)
-    // Data-gradient launches whose output is the gradient of a BatchNorm's output y = [relu](BN(x)): the kernel also leaves
-    // the backward reduction of THAT BatchNorm per tile -- bsum[tile][0][col] = sum g, [1][col] = sum g * xhat with
-    // g = Y * (y > 0 if bn_y) and xhat = (x - mean) * invstd over the tile's rows -- so that b2m_bn_bwd_reduce's pass over
-    // (dy, x) disappears (conv_fwd_flow_kernel only; cout % 4 == 0, 16-byte aligned rows).
-    double* bsum;
-    const float* bn_x; int64_t ld_bn_x;
-    const float* bn_y; int64_t ld_bn_y;      // mask source (the BatchNorm's output = this convolution's forward input), or NULL
-    const float* bn_mean; const float* bn_invstd;
 };
 
 // loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
@@ -802,12 +794,10 @@ extern "C" int b2m_weight_pack_run(const void* plan_dev, int32_t n, int64_t tota
     return B2M_OK;
 }
 
-struct BnBwdReq { const float* x; int64_t ldx; const float* y; int64_t ldy; const float* mean; const float* invstd; double* sums; };
 static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
                          int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
                          const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
-                         int32_t cout, int32_t accumulate, double* tile_stats, int32_t* wrote_stats, void* stream,
-                         const BnBwdReq* bnreq = nullptr) {
+                         int32_t cout, int32_t accumulate, double* tile_stats, int32_t* wrote_stats, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (wrote_stats) *wrote_stats = 0;
     B2M_CHECK_ARG(x1 && wp && y && c1 > 0 && c2 >= 0 && cout > 0 && K >= 1 && K <= 128, "bad pointers/sizes (K<=128)");
@@ -833,7 +823,6 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
     a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
     a.stats = nullptr;
-    a.bsum = nullptr; a.bn_x = a.bn_y = a.bn_mean = a.bn_invstd = nullptr; a.ld_bn_x = a.ld_bn_y = 0;
     a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr;
     const int TW = conv_tw(cout, K);
     a.nstrips = (cout + 16 * TW - 1) / (16 * TW);
@@ -916,12 +905,6 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 a.stats = tile_stats;
                 if (wrote_stats) *wrote_stats = 1;
             }
-            if (bnreq && (nslice == 1 || (nslice == 4 && !accumulate)) && cout % 4 == 0 && a.vec_store &&
-                bnreq->ldx % 4 == 0 && ((uintptr_t)bnreq->x % 16) == 0 && (!bnreq->y || (bnreq->ldy % 4 == 0 && ((uintptr_t)bnreq->y % 16) == 0))) {
-                a.bsum = bnreq->sums; a.bn_x = bnreq->x; a.ld_bn_x = bnreq->ldx; a.bn_y = bnreq->y; a.ld_bn_y = bnreq->ldy;
-                a.bn_mean = bnreq->mean; a.bn_invstd = bnreq->invstd;
-                if (wrote_stats) *wrote_stats = 1;
-            }
             a.nwg = cdiv64(items, wpb);
             XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
             a.xcd_per = fo.chunk;
@@ -1001,18 +984,6 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
                             int32_t cout, int32_t accumulate, void* stream) {
     return conv_fwd_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, accumulate,
                          nullptr, nullptr, stream);
-}
-extern "C" int b2m_conv_fwd_bnbwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
-                                  int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
-                                  const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
-                                  int32_t cout, int32_t accumulate, const float* bn_x, int64_t ld_bn_x, const float* bn_y,
-                                  int64_t ld_bn_y, const float* bn_mean, const float* bn_invstd, double* tile_sums,
-                                  int32_t* wrote, void* stream) {
-    B2M_CHECK_ARG(bn_x && bn_mean && bn_invstd && tile_sums && wrote && ld_bn_x >= cout && (!bn_y || ld_bn_y >= cout),
-                  "NULL argument / leading dimension too small");
-    const BnBwdReq req = {bn_x, ld_bn_x, bn_y, ld_bn_y, bn_mean, bn_invstd, tile_sums};
-    return conv_fwd_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, accumulate,
-                         nullptr, wrote, stream, &req);
 }
 extern "C" int b2m_conv_fwd_stats(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
                                   int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,

@@ -58,55 +58,6 @@ __device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float
 }
 #define tile_column_sums(a, strip, tile, row0, col0, lane) strip_column_sums<SW>(a, strip, tile, row0, col0, lane)
 
-// Backward reduction of the BatchNorm whose output gradient this strip is (ConvArgs::bsum): g = dY * (y > 0), xhat = (x - mean)
-// * invstd; per column sum g and sum g * xhat over the tile's rows.  Pass 1 (before the strip is written out): lane (row slot,
-// 16-byte column group) adds up its rows in fp64 from the strip and two coalesced reads (x, y); pass 2 (after the write-out:
-// the strip's LDS is free) the row slots meet in LDS and lane c writes column c.  `scratch`: >= (64 / (SW / 4)) * SW * 2 doubles.
-template <int SW>
-struct BnBwdPart { double s0[4], s1[4]; };
-template <int SW>
-__device__ __forceinline__ void strip_bn_bwd_partial(const ConvArgs& a, const float* strip, int64_t row0, int col0, int lane,
-                                                     BnBwdPart<SW>& p) {
-    constexpr int PITCH = SW + 4, V = SW / 4, NRS = 64 / V;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { p.s0[u] = 0.; p.s1[u] = 0.; }
-    const int rs = lane / V, cv = lane % V;
-    const int col = col0 + 4 * cv;
-    if (rs >= NRS || col >= a.cout) return;
-    const int64_t rem = a.n_out - row0;
-    const int rows = rem < B2M_TILE ? (int)rem : B2M_TILE;
-    const f32x4 m = *(const f32x4*)(a.bn_mean + col), is = *(const f32x4*)(a.bn_invstd + col);
-    for (int r = rs; r < rows; r += NRS) {
-        f32x4 g = *(const f32x4*)&strip[r * PITCH + 4 * cv];
-        const f32x4 x = *(const f32x4*)(a.bn_x + (row0 + r) * a.ld_bn_x + col);
-        if (a.bn_y) {
-            const f32x4 y = *(const f32x4*)(a.bn_y + (row0 + r) * a.ld_bn_y + col);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) g[u] = y[u] > 0.f ? g[u] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { p.s0[u] += (double)g[u]; p.s1[u] += (double)(g[u] * ((x[u] - m[u]) * is[u])); }
-    }
-}
-template <int SW>
-__device__ __forceinline__ void strip_bn_bwd_finish(const ConvArgs& a, double* scratch, int64_t tile, int col0, int lane,
-                                                    const BnBwdPart<SW>& p) {
-    constexpr int V = SW / 4, NRS = 64 / V;
-    const int rs = lane / V, cv = lane % V;
-    if (rs < NRS) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { scratch[(rs * SW + 4 * cv + u) * 2] = p.s0[u]; scratch[(rs * SW + 4 * cv + u) * 2 + 1] = p.s1[u]; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if (lane < SW && col0 + lane < a.cout) {
-        double t0 = 0., t1 = 0.;
-#pragma unroll
-        for (int r = 0; r < NRS; ++r) { t0 += scratch[(r * SW + lane) * 2]; t1 += scratch[(r * SW + lane) * 2 + 1]; }
-        double* o = a.bsum + tile * 2 * a.cout + col0 + lane;
-        o[0] = t0; o[a.cout] = t1;
-    }
-}
-
 // DBG (diagnostic builds of tools/pipe_breakdown.py only, results are WRONG): 1 = no strip flush, 2 = no gathers inside
 // the loop, 4 = no weight loads inside the loop -- each removes one component so that its cost shows in the launch time
 // WPB = 4: split maps (deep U-Net levels).  The four waves of a workgroup are four slices of ONE (tile, strip): the
@@ -371,7 +322,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             f32x4 v = *(const f32x4*)&smem[row * PITCH + c4];
 #pragma unroll
             for (int w = 1; w < WPB; ++w) v += *(const f32x4*)&smem[w * STRIP + row * PITCH + c4];
-            if (a.stats || a.bsum) *(f32x4*)&smem[row * PITCH + c4] = v;  // keep the combined strip for the column sums below
+            if (a.stats) *(f32x4*)&smem[row * PITCH + c4] = v;  // keep the combined strip for the column sums below
             const int col = col0 + c4;
             float* dst = a.y + grow * a.ldy + col;
             if (plain && a.vec_store && col + 3 < a.cout) {
@@ -390,18 +341,9 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             tile_column_sums(a, smem, tile, row0, col0, lane);
         }
-        if (a.bsum) {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            BnBwdPart<SW> part;
-            strip_bn_bwd_partial<SW>(a, smem, row0, col0, lane, part);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            strip_bn_bwd_finish<SW>(a, (double*)(smem + STRIP), tile, col0, lane, part);     // (wave 1's strip: combined already)
-        }
         return;
     }
     if (a.stats) tile_column_sums(a, Cs, tile, row0, col0, lane);
-    BnBwdPart<SW> part;
-    if (a.bsum) strip_bn_bwd_partial<SW>(a, Cs, row0, col0, lane, part);
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
@@ -415,10 +357,6 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (col + u < a.cout) dst[u] = v[u];
         }
-    }
-    if (a.bsum) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // the strip has been read out: its LDS is scratch now
-        strip_bn_bwd_finish<SW>(a, (double*)Cs, tile, col0, lane, part);
     }
 }
 #undef tile_column_sums

@@ -254,16 +254,6 @@ extern "C" int b2m_bn_tilestats(const double* tile_stats, int64_t ntiles, int32_
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
-extern "C" int b2m_bn_bwd_tilesums(const double* tile_sums, int64_t ntiles, int32_t c, double* partial, double* sums,
-                                   float* dbeta_f32, float* dgamma_f32, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(tile_sums && partial && sums && ntiles >= 1 && c > 0 && c <= 1024, "bad arguments");
-    const int nblk = tilestats_blocks(ntiles);
-    bn_tilestats_kernel<<<nblk, 256, 0, st>>>(tile_sums, ntiles, 2 * c, partial);
-    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, dbeta_f32, dgamma_f32);
-    B2M_LAUNCH_CHECK();
-    return B2M_OK;
-}
 extern "C" int b2m_bn_tilestats_finalize(const double* tile_stats, int64_t ntiles, int64_t n, int32_t c, double* partial,
                                          double* stats, const float* gamma, const float* beta, float eps, float momentum,
                                          float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
@@ -598,7 +588,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const float* __restr
                                                             const double* __restrict__ count_dev, int relu,
                                                             float* __restrict__ dxa, int64_t lddxa, float* __restrict__ dxb,
                                                             int64_t lddxb, float* __restrict__ dbeta_a, float* __restrict__ dgamma_a,
-                                                            float* __restrict__ dbeta_b, float* __restrict__ dgamma_b) {
+                                                            float* __restrict__ dbeta_b, float* __restrict__ dgamma_b,
+                                                            const double* __restrict__ psums) {
     const int c4 = c >> 2;
     const float inv_n = (float)(1.0 / (count_dev ? *count_dev : count_host));
     const int nslots = 256 / c4;
@@ -612,11 +603,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const float* __restr
         const int j = cg * 4 + u;
         sg[u] = (float)sums[j] * inv_n; sga[u] = (float)sums[c + j] * inv_n; sgb[u] = (float)sums[2 * c + j] * inv_n;
         ga[u] = (gamma_a ? gamma_a[j] : 1.f) * ia[u]; gb[u] = (gamma_b ? gamma_b[j] : 1.f) * ib[u];
-        if (blockIdx.x == 0 && rs == 0) {        // the parameter gradients (fp32 copies of the global sums)
-            if (dbeta_a) dbeta_a[j] = (float)sums[j];
-            if (dbeta_b) dbeta_b[j] = (float)sums[j];
-            if (dgamma_a) dgamma_a[j] = (float)sums[c + j];
-            if (dgamma_b) dgamma_b[j] = (float)sums[2 * c + j];
+        if (blockIdx.x == 0 && rs == 0) {        // the parameter gradients: fp32 copies of THIS RANK's sums (the gradient
+            // all-reduce averages them over the ranks like every other parameter gradient; torch SyncBatchNorm does the same)
+            if (dbeta_a) dbeta_a[j] = (float)psums[j];
+            if (dbeta_b) dbeta_b[j] = (float)psums[j];
+            if (dgamma_a) dgamma_a[j] = (float)psums[c + j];
+            if (dgamma_b) dgamma_b[j] = (float)psums[2 * c + j];
         }
     }
     for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
@@ -642,7 +634,7 @@ extern "C" int b2m_bn_bwd_apply2(const float* dy, int64_t lddy, const float* y, 
                                  const float* invstd_a, const float* gamma_a, const float* mean_b, const float* invstd_b,
                                  const float* gamma_b, const double* sums, double count, const double* count_dev,
                                  int32_t relu, float* dxa, int64_t lddxa, float* dxb, int64_t lddxb, float* dbeta_a,
-                                 float* dgamma_a, float* dbeta_b, float* dgamma_b, void* stream) {
+                                 float* dgamma_a, float* dbeta_b, float* dgamma_b, const double* local_sums, void* stream) {
     B2M_CHECK_ARG(dy && y && xa && xb && mean_a && invstd_a && mean_b && invstd_b && sums && dxa && dxb, "NULL argument");
     B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldy % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
                       lddxa % 4 == 0 && lddxb % 4 == 0 && (count_dev || count >= 1),
@@ -650,7 +642,7 @@ extern "C" int b2m_bn_bwd_apply2(const float* dy, int64_t lddy, const float* y, 
     if (n == 0) return B2M_OK;
     bn_bwd_apply2_kernel<<<row_grid(n, c / 4), 256, 0, (hipStream_t)stream>>>(dy, lddy, y, ldy, xa, lda, xb, ldb, n, c, mean_a,
         invstd_a, gamma_a, mean_b, invstd_b, gamma_b, sums, count, count_dev, relu, dxa, lddxa, dxb, lddxb, dbeta_a, dgamma_a,
-        dbeta_b, dgamma_b);
+        dbeta_b, dgamma_b, local_sums ? local_sums : sums);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -154,7 +154,7 @@ packed_weights = _PackedWeights()
 
 
 def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: int, out=None, accumulate=False,
-             tile_stats: list | None = None, logical_cin: int | None = None, bn_bwd: tuple | None = None):
+             tile_stats: list | None = None, logical_cin: int | None = None):
     """Y = sum_k [x1|x2][in_k] @ B[k] with B given as a packed image for (K, c1+c2, cout).
     tile_stats: a list; if the kernel of this shape can, it also leaves the per-tile column sums of Y (sum and sum of
     squares over each tile of 64 rows: the statistics of the BatchNorm that follows) and the list receives
@@ -170,20 +170,6 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
     else:
         assert rb.K == K and rb.n_out == n_out
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
-    if bn_bwd is not None and rb is not None and n_out > 0:
-        # data gradient of a convolution whose input was a BatchNorm's output: the kernel also leaves that BatchNorm's
-        # backward reduction per tile (b2m_conv_fwd_bnbwd); bn_bwd = (x, y or None, mean, invstd, result list)
-        bx, by, bmean, binv, res = bn_bwd
-        ntiles = (n_out + 63) // 64
-        ts = torch.empty((ntiles, 2, cout), dtype=torch.float64, device=x1.device)
-        wrote = ctypes.c_int32(0)
-        _call('b2m_conv_fwd_bnbwd', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
-              x1.shape[0], wp.data_ptr(), K, _ptr(bias), rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout,
-              1 if accumulate else 0, bx.data_ptr(), bx.stride(0), _ptr(by), by.stride(0) if by is not None else 0,
-              bmean.data_ptr(), binv.data_ptr(), ts.data_ptr(), ctypes.byref(wrote), meta=meta)
-        if wrote.value:
-            res.append((ts, ntiles))
-        return out
     if tile_stats is not None and rb is not None and n_out > 0:
         ntiles = (n_out + 63) // 64
         ts = torch.empty((ntiles, 2, cout), dtype=torch.float64, device=x1.device)
@@ -250,9 +236,8 @@ class _SparseConv(torch.autograd.Function):
     for the data gradient (same rulebook for stride-1 kernels, whose offsets mirror)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, tile_stats=None, passthrough=False, bn_src=None):
+    def forward(ctx, x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, tile_stats=None, passthrough=False):
         in1, in2 = x1, x2
-        ctx.bn_src = bn_src
         x1 = _f32c(x1)
         x2 = _f32c(x2) if x2 is not None else None
         c1 = x1.shape[1]
@@ -283,7 +268,7 @@ class _SparseConv(torch.autograd.Function):
     def backward(ctx, dy, p1=None, p2=None):
         x1, x2, weight, bias = ctx.saved_tensors
         if dy is None:                         # only the passed-through inputs were used downstream
-            return p1, p2, None, None, None, None, None, None, None, None, None
+            return p1, p2, None, None, None, None, None, None, None, None
         dy = _f32c(dy)
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         w3 = _f32c(w3)
@@ -293,18 +278,10 @@ class _SparseConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = packed_weights.get(weight, True, ctx.mirror, 0, c1)
             acc = _accumulation_target(p1, x1.shape[0], c1)
-            # x1 was the output of a BatchNorm (ctx.bn_src) and this launch leaves its COMPLETE gradient (nothing is added
-            # afterwards): the kernel's epilogue also does that BatchNorm's backward reduction
-            src = ctx.bn_src if (ctx.bn_src is not None and (p1 is None or acc is not None) and bn_bwd_from_conv()) else None
-            req, got = None, []
-            if src is not None and src['x'].shape == (x1.shape[0], c1):
-                req = (src['x'], x1 if src['relu'] else None, src['mean'], src['invstd'], got)
-            dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1, out=acc, accumulate=acc is not None, bn_bwd=req)
+            dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1, out=acc, accumulate=acc is not None)
             if p1 is not None and acc is None:
                 dx1 = dx1 + p1
             _own(dx1)
-            if got:
-                src['holder']['sums'] = (got[0][0], got[0][1], dx1, dx1._version)
         if x2 is not None and ctx.needs_input_grad[1]:
             wt = packed_weights.get(weight, True, ctx.mirror, c1, x2.shape[1])
             acc = _accumulation_target(p2, x2.shape[0], x2.shape[1])
@@ -342,7 +319,7 @@ class _SparseConv(torch.autograd.Function):
                 torch.sum(dy, 0, keepdim=True, out=db)
             else:
                 db = dy.sum(0, keepdim=True).reshape(bias.shape)
-        return dx1, dx2, dw, db, None, None, None, None, None, None, None
+        return dx1, dx2, dw, db, None, None, None, None, None, None
 
 
 def _own(t):
@@ -359,7 +336,9 @@ def _accumulation_target(g, n: int, c: int):
     tensor that owns its memory AND was produced by one of this package's backward operators for this input alone
     (`_own`).  A gradient that comes from a torch operator may be the same TensorImpl another branch still holds
     (AddBackward0 hands one tensor to both inputs): adding in place would corrupt that branch, so those are summed out of
-    place."""
+    place.  Limit of the mark: it is an attribute of the tensor object and survives a torch operator that forwards the SAME
+    tensor (AddBackward0 again): a model that puts a torch elementwise add on FEATURE tensors between two operators of this
+    package must run with B2M_CONV_PASSTHROUGH=0.  SelectionNet has no such add (every add is fused into BatchNorm)."""
     if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n, c) or not g.is_contiguous() or g._base is not None:
         return None
     if not getattr(g, '_b2m_own', False):
@@ -373,20 +352,10 @@ def conv_tile_stats() -> bool:
     return os.environ.get('B2M_CONV_STATS', '1') == '1'
 
 
-def bn_bwd_from_conv() -> bool:
-    """B2M_BN_BWD_FROM_CONV=1: the backward reduction of a BatchNorm (sum g, sum g * xhat) comes from the epilogue of the
-    data-gradient kernel that produced dy (b2m_conv_fwd_bnbwd + b2m_bn_bwd_tilesums) instead of a pass of its own over
-    (dy, x) (b2m_bn_bwd_reduce).  OFF by default: measured on the benchmark step it moves 0.9 ms from the HBM-bound
-    reduction into the MFMA-bound kernel's epilogue (20 launches, +46 us each: a wave's LDS-bound slot waits for the
-    tile's x and y rows) -- the sum of the kernels is unchanged, the step 0.3 ms shorter (inside the noise), and the
-    dominant kernel's roofline fraction 0.010 lower."""
-    return os.environ.get('B2M_BN_BWD_FROM_CONV', '0') == '1' and not deterministic()
-
-
 def bn_small_rows() -> int:
     """B2M_BN_SMALL_ROWS: training-mode BatchNorm of maps with at most this many rows runs as ONE launch each way
     (b2m_bn_small_fwd / _bwd; 0 switches it off).  Not under SyncBN."""
-    return int(os.environ.get('B2M_BN_SMALL_ROWS', '4096'))
+    return min(int(os.environ.get('B2M_BN_SMALL_ROWS', '4096')), 16384)       # (B2M_BN_SMALL_MAX_ROWS of the library)
 
 
 def conv_passthrough() -> bool:
@@ -404,8 +373,7 @@ def sparse_conv(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, collect_stats=F
     holder = [] if (collect_stats and conv_tile_stats()) else None
     alias = bool(passthrough) and torch.is_grad_enabled() and conv_passthrough() and \
         (x1.requires_grad or (x2 is not None and x2.requires_grad))
-    bn_src = getattr(x1, '_b2m_bn_src', None) if (torch.is_grad_enabled() and rb_b is not None) else None
-    out = _SparseConv.apply(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, holder, alias, bn_src)
+    out = _SparseConv.apply(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, holder, alias)
     y = out[0] if alias else out
     if holder:
         y._b2m_tile_stats = holder[0]
@@ -442,7 +410,7 @@ class _BatchNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync,
-                count_key=None, tile_stats=None, src=None):
+                count_key=None, tile_stats=None):
         x = _f32c(x)
         n, c = x.shape
         dev = x.device
@@ -503,12 +471,6 @@ class _BatchNorm(torch.autograd.Function):
                   residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
         ctx.training, ctx.relu, ctx.count, ctx.sync, ctx.count_dev = training, relu, count, sync, count_dev
         ctx.small = small
-        ctx.bsum_holder = None
-        if training and not small and src is not None:
-            # a convolution that consumes y can do this layer's backward reduction in its data-gradient epilogue
-            # (_SparseConv.backward); the sums come back through the holder, keyed by the gradient tensor they belong to
-            ctx.bsum_holder = {}
-            src.update(x=x, mean=mean, invstd=invstd, relu=bool(relu), holder=ctx.bsum_holder)
         ctx.has_res = residual is not None
         if training:
             # without a fused residual the ReLU mask is the sign of fmaf(x, scale, shift): the backward recomputes it
@@ -544,7 +506,7 @@ class _BatchNorm(torch.autograd.Function):
                 invstd = torch.rsqrt(ctx.eval_var + ctx.eval_eps)
                 dgamma = ((g * x).sum(0) - dbeta * ctx.eval_mean) * invstd
             return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                    None, None, None, None, None, _own(gres), None, None, None, None, None)
+                    None, None, None, None, None, _own(gres), None, None, None, None)
         # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned
         dbeta, dgamma = grad_slot(beta), grad_slot(gamma)
         if dbeta is None or dgamma is None:
@@ -556,21 +518,12 @@ class _BatchNorm(torch.autograd.Function):
                   dbeta.data_ptr(), dgamma.data_ptr(), dx.data_ptr(), dx.stride(0), _ptr(dres),
                   dres.stride(0) if dres is not None else 0)
             return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                    None, None, None, None, None, _own(dres), None, None, None, None, None)
+                    None, None, None, None, None, _own(dres), None, None, None, None)
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
-        pre = ctx.bsum_holder.pop('sums', None) if ctx.bsum_holder is not None else None
-        if pre is not None and (pre[2].data_ptr() != dy.data_ptr() or pre[2].shape != dy.shape or pre[2]._version != pre[3] or
-                                pre[0].shape[2] != c or pre[1] != (n + 63) // 64):
-            pre = None          # not the gradient the sums were taken from (autograd added another consumer's gradient)
-        if pre is not None:
-            # the data-gradient kernel that produced dy left this layer's reduction per tile: no pass over (dy, x)
-            _call('b2m_bn_bwd_tilesums', pre[0].data_ptr(), pre[1], c, partial.data_ptr(), sums.data_ptr(), dbeta.data_ptr(),
-                  dgamma.data_ptr())
-        else:
-            _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
-                  x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _ptr(mscale), _ptr(mshift),
-                  partial.data_ptr(), sums.data_ptr(), dbeta.data_ptr(), dgamma.data_ptr())
+        _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
+              x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _ptr(mscale), _ptr(mshift),
+              partial.data_ptr(), sums.data_ptr(), dbeta.data_ptr(), dgamma.data_ptr())
         gsums, count = sums, ctx.count
         group = _sync_group() if ctx.sync else None
         if group is not None:
@@ -581,7 +534,7 @@ class _BatchNorm(torch.autograd.Function):
               count, _ptr(ctx.count_dev), relu, _ptr(mscale), _ptr(mshift), dx.data_ptr(), dx.stride(0), _ptr(dres),
               dres.stride(0) if dres is not None else 0)
         return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, _own(dres), None, None, None, None, None)
+                None, None, None, None, None, _own(dres), None, None, None, None)
 
 
 def bn_pair() -> bool:
@@ -694,12 +647,17 @@ class _BatchNormPair(torch.autograd.Function):
               xb.data_ptr(), xb.stride(0), n, c, mean_a.data_ptr(), inv_a.data_ptr(), mean_b.data_ptr(), inv_b.data_ptr(),
               relu, partial.data_ptr(), sums.data_ptr())
         group = _sync_group() if ctx.sync else None
+        gsums = sums
         if group is not None:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            # dx needs the sums over ALL ranks; the parameter gradients are written from this rank's own sums (they are
+            # averaged over the ranks with every other gradient afterwards)
+            gsums = sums.clone()
+            dist.all_reduce(gsums, op=dist.ReduceOp.SUM, group=group)
         _call('b2m_bn_bwd_apply2', dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), xa.data_ptr(), xa.stride(0),
               xb.data_ptr(), xb.stride(0), n, c, mean_a.data_ptr(), inv_a.data_ptr(), _ptr(ga), mean_b.data_ptr(),
-              inv_b.data_ptr(), _ptr(gb), sums.data_ptr(), ctx.count, _ptr(ctx.count_dev), relu, dxa.data_ptr(),
-              dxa.stride(0), dxb.data_ptr(), dxb.stride(0), dba.data_ptr(), dga.data_ptr(), dbb.data_ptr(), dgb.data_ptr())
+              inv_b.data_ptr(), _ptr(gb), gsums.data_ptr(), ctx.count, _ptr(ctx.count_dev), relu, dxa.data_ptr(),
+              dxa.stride(0), dxb.data_ptr(), dxb.stride(0), dba.data_ptr(), dga.data_ptr(), dbb.data_ptr(), dgb.data_ptr(),
+              sums.data_ptr())
         return (_own(dxa), dga if need[1] else None, dba if need[2] else None, None, None,
                 _own(dxb), dgb if need[6] else None, dbb if need[7] else None, None, None) + (None,) * 9
 
@@ -717,12 +675,8 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1
                relu=False, sync=False, count_key=None):
     # per-tile column sums left by the convolution that produced x (sparse_conv(collect_stats=True))
     tile_stats = getattr(x, '_b2m_tile_stats', None) if training else None
-    src = {} if (training and torch.is_grad_enabled() and x.requires_grad and bn_bwd_from_conv()) else None
-    y = _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync,
-                         count_key, tile_stats, src)
-    if src:
-        y._b2m_bn_src = src          # read by sparse_conv when y becomes a convolution's (first) input
-    return y
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync,
+                            count_key, tile_stats)
 
 
 class _ReLU(torch.autograd.Function):

@@ -178,7 +178,10 @@ def batch_norm_add_relu(norm_a: MinkowskiBatchNorm, feats_a, norm_b: MinkowskiBa
     those take the one-launch kernels of functional._BatchNorm)."""
     if not F_.bn_pair() or norm_a.training != norm_b.training or norm_a.sync != norm_b.sync:
         return None
-    n = feats_a.shape[0]
+    n, c = feats_a.shape
+    # the paired kernels take 16-byte column groups of dense fp32 rows (b2m_bn_apply2 checks the same)
+    if c % 4 != 0 or c > 1024 or feats_b.shape != feats_a.shape:
+        return None
     sync = norm_a.sync and F_._sync_group() is not None
     if norm_a.training and not sync and n <= F_.bn_small_rows():
         return None

@@ -190,24 +190,6 @@ int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const
 
 /* ---------------------------------------------------------------- batch norm / elementwise (fp32, HBM-bound) */
 
-/* b2m_conv_fwd for a DATA-GRADIENT launch whose output Y is the gradient of a BatchNorm's output y = [relu](BN(x))
- * (this convolution's forward input): the kernel also leaves, per tile of 64 rows, the backward reduction of that BatchNorm --
- *   tile_sums[tile][0][col] = sum g,   tile_sums[tile][1][col] = sum g * xhat,   g = Y * (bn_y > 0 if bn_y), xhat = (bn_x - mean) * invstd
- * (fp64, [ceil(n_out / 64)][2][cout]) -- which b2m_bn_bwd_tilesums turns into the sums b2m_bn_bwd_apply needs: the pass of
- * b2m_bn_bwd_reduce over (dy, x) disappears (/root/reference/models/resnet.py:63-82: every BatchNorm is fed by and feeds a
- * convolution).  *wrote (host) = 1 if this shape's kernel provided them (whole 16-channel chunks, a real rulebook, un-split map
- * or exactly 4 slices without accumulate, cout % 4 == 0, 16-byte aligned rows), else 0 and the caller reduces as before.
- * Y must be the COMPLETE gradient when the launch ends (accumulate = 1 onto the other consumers' gradient is fine). */
-int b2m_conv_fwd_bnbwd(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2, int64_t n_in,
-                       const float* wp, int32_t K, const float* bias, const int32_t* rb_in, const uint8_t* rb_out,
-                       const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy, int32_t cout, int32_t accumulate,
-                       const float* bn_x, int64_t ld_bn_x, const float* bn_y, int64_t ld_bn_y, const float* bn_mean,
-                       const float* bn_invstd, double* tile_sums, int32_t* wrote, void* stream);
-/* tile_sums of b2m_conv_fwd_bnbwd -> sums[0:c] = sum g, sums[c:2c] = sum g * xhat (+ fp32 copies dbeta / dgamma, may be NULL):
- * what b2m_bn_bwd_reduce returns.  partial: double[2*c*1280] scratch.  Fixed summation order. */
-int b2m_bn_bwd_tilesums(const double* tile_sums, int64_t ntiles, int32_t c, double* partial, double* sums, float* dbeta_f32,
-                        float* dgamma_f32, void* stream);
-
 /* Column sums for BatchNorm: stats[0:c] = sum x, stats[c:2c] = sum x^2 (double), deterministic
  * two-stage reduction.  partial: double[2*c*nblk_max] scratch with nblk_max = 4096.
  * Replaces the reduction inside torch.nn.BatchNorm1d wrapped by ME.MinkowskiBatchNorm
@@ -265,7 +247,8 @@ int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy,
  * b2m_bn_apply2: both affine maps, the add and the ReLU in one pass (the shortcut's normalised tensor is never stored);
  * b2m_bn_bwd_reduce2: sums[0:c] = sum g, sums[c:2c] = sum g*xhat_a, sums[2c:3c] = sum g*xhat_b with g = dy * (y > 0 if relu)
  *   (partial: double[3*c*1280] scratch) -- under SyncBN ONE all-reduce of 3c doubles for the pair;
- * b2m_bn_bwd_apply2: dx_a, dx_b and the four parameter gradients (fp32 copies of the sums; any may be NULL). */
+ * b2m_bn_bwd_apply2: dx_a, dx_b (from `sums`: under SyncBN the sums over all ranks) and the four parameter gradients
+ * (fp32 copies of `local_sums`, this rank's own sums; NULL: of `sums`; any gradient may be NULL). */
 int b2m_bn_apply2(const float* xa, int64_t lda, const float* xb, int64_t ldb, int64_t n, int32_t c,
                   const float* scale_a, const float* shift_a, const float* scale_b, const float* shift_b,
                   int32_t relu, float* y, int64_t ldy, void* stream);
@@ -278,7 +261,7 @@ int b2m_bn_bwd_apply2(const float* dy, int64_t lddy, const float* y, int64_t ldy
                       const float* gamma_a, const float* mean_b, const float* invstd_b, const float* gamma_b,
                       const double* sums, double count, const double* count_dev, int32_t relu, float* dxa, int64_t lddxa,
                       float* dxb, int64_t lddxb, float* dbeta_a, float* dgamma_a, float* dbeta_b, float* dgamma_b,
-                      void* stream);
+                      const double* local_sums, void* stream);
 
 /* Training-mode BatchNorm of a SMALL map (n <= B2M_BN_SMALL_MAX_ROWS rows: the deep U-Net levels, the heads' segment
  * rows) in ONE launch each way: b2m_bn_small_fwd = statistics (fp64) + finalize (mean / invstd / scale / shift, running

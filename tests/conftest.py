@@ -27,7 +27,7 @@ def _b2m_env_switches(monkeypatch):
     def reload():
         try:
             _lib.reload_env()
-        except (ImportError, OSError):
+        except (ImportError, OSError, AttributeError):      # (no library, or a stale one without b2m_reload_env)
             pass
     set0, del0 = monkeypatch.setenv, monkeypatch.delenv
 

@@ -338,61 +338,3 @@ def test_stem_kernel_and_its_tile_stats(maps, monkeypatch, stem):
         assert torch.equal(y, y_old), 'the two stem kernels differ'
     else:
         assert ts is None
-
-
-@pytest.mark.parametrize('regime', ['unsplit', 'split4', 'many_slices'])
-@pytest.mark.parametrize('cin,cmid,res', [(32, 96, False), (64, 64, True)])
-def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(maps, monkeypatch, regime, cin, cmid, res):
-    """conv -> BatchNorm(+residual)+ReLU -> conv: the second convolution's data-gradient kernel also leaves the BatchNorm's
-    backward reduction per tile (b2m_conv_fwd_bnbwd + b2m_bn_bwd_tilesums); against the pass of b2m_bn_bwd_reduce over (dy, x)
-    (B2M_BN_BWD_FROM_CONV=0): every gradient equal to rounding, and the path is really taken where the kernel can provide the
-    sums (un-split maps, exactly 4 slices) and really falls back where it cannot (more slices: atomic combine)."""
-    from box2mask_amd import functional as F_, _lib
-    env = {'unsplit': {'B2M_CONV_TARGET': '0'}, 'split4': {'B2M_CONV_TARGET': '800', 'B2M_CONV_CHUNKSPLIT': '0'},
-           'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'}}
-    for k, v in env[regime].items():
-        monkeypatch.setenv(k, v)
-    monkeypatch.setenv('B2M_BN_SMALL_ROWS', '0')
-    m, _ = maps
-    rb = m.rulebook_same(0, 3)
-    n = rb.n_out
-    torch.manual_seed(zlib.crc32(repr((regime, cin, cmid)).encode()))
-    x0 = torch.randn(n, cin, device='cuda')
-    r0 = torch.randn(n, cmid, device='cuda')
-    w1_0 = torch.randn(27, cin, cmid, device='cuda') * 0.05
-    w2_0 = torch.randn(27, cmid, 64, device='cuda') * 0.05          # (64: an even number of 16-channel chunks, as every layer of the network has)
-    gy = torch.randn(n, 64, device='cuda')
-
-    def run(flag):
-        monkeypatch.setenv('B2M_BN_BWD_FROM_CONV', flag)
-        calls = []
-        _lib.set_hook(lambda name, a, meta=None: calls.append(name))
-        try:
-            x = x0.clone().requires_grad_(True); r = r0.clone().requires_grad_(True) if res else None
-            w1 = w1_0.clone().requires_grad_(True); w2 = w2_0.clone().requires_grad_(True)
-            gam = torch.linspace(0.5, 1.5, cmid, device='cuda').requires_grad_(True)
-            bet = torch.linspace(-0.3, 0.3, cmid, device='cuda').requires_grad_(True)
-            rm, rv = torch.zeros(cmid, device='cuda'), torch.ones(cmid, device='cuda')
-            h = F_.sparse_conv(x, None, w1, None, rb, rb, True, n, collect_stats=True)
-            h = F_.batch_norm(h, gam, bet, rm, rv, True, residual=r, relu=True)
-            y = F_.sparse_conv(h, None, w2, None, rb, rb, True, n)
-            y.backward(gy)
-            torch.cuda.synchronize()
-        finally:
-            _lib.set_hook(None)
-        g = [x.grad, w1.grad, w2.grad, gam.grad, bet.grad] + ([r.grad] if res else [])
-        return y.detach(), g, calls
-    y1, g1, c1 = run('1')
-    y0, g0, c0 = run('0')
-    assert 'b2m_conv_fwd_bnbwd' not in c0 and 'b2m_bn_bwd_reduce' in c0
-    assert 'b2m_conv_fwd_bnbwd' in c1
-    if regime == 'many_slices':
-        assert 'b2m_bn_bwd_tilesums' not in c1 and 'b2m_bn_bwd_reduce' in c1        # the kernel could not provide the sums
-    else:
-        assert 'b2m_bn_bwd_tilesums' in c1 and 'b2m_bn_bwd_reduce' not in c1
-    if regime == 'many_slices':
-        _close(y1, y0, 'forward', 1e-5)            # (atomic combine: the order of the additions differs from run to run)
-    else:
-        assert torch.equal(y1, y0)
-    for a, b, what in zip(g1, g0, ('dx', 'dw1', 'dw2', 'dgamma', 'dbeta', 'dres')):
-        _close(a, b, '%s (%s)' % (what, regime), 2e-5)
