@@ -252,7 +252,9 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         };
 
         for (;;) {
-            for (int c0 = cb; c0 < ce; c0 += D) {
+            int c0 = cb;
+            do {                              // (bottom-tested, ce - cb >= D: with a zero-trip path hipcc cannot count the loads behind the
+                                              // pair-list fetch and drains the whole queue -- s_waitcnt vmcnt(0) -- at every offset advance)
                 // the D prefetches of this round target one offset: the current one, or -- in its last round -- the next
                 const bool wrap = c0 + D >= ce;
                 const int kT = wrap ? kNc : kC;
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                     }
                     if constexpr (!(DBG & 4)) weights(j, kT, cT + j);
                 }
-            }
+                c0 += D;
+            } while (c0 < ce);
             // ---- add the offset's result into the strip: lane (i,q) holds channels 16t + 4q .. +3 of pair 16g + i;
             // padded pairs (output row 64) take no part
             asm volatile("s_nop 15" ::: "memory");        // MFMA result -> VALU read: >= 11 wait states (8-pass MFMA)

@@ -28,12 +28,14 @@ def timeit(fn, n=4):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 
+CORUN = os.environ.get('CORUN', '0') == '1'
+side = torch.cuda.Stream()
 VARIANTS = [('base', {})]
 for spec in os.environ.get('VARIANTS', 'tw2:B2M_CONV_TW3=0;slow64:B2M_WGRAD_FAST32=0').split(';'):
     if spec:
         name, kvs = spec.split(':')
         VARIANTS.append((name, dict(kv.split('=') for kv in kvs.split(','))))
-SWITCHES = ('B2M_CONV_STEM', 'B2M_XCD_WINDOW', 'B2M_XCD_CLASSES', 'B2M_WGRAD_NARROW', 'B2M_WGRAD_PIPE_IDENT', 'B2M_WGRAD_KPACK', 'B2M_WGRAD_TARGET', 'B2M_WGRAD_MAX_TILES', 'B2M_CONV_1X1', 'B2M_XCD_ORDER', 'B2M_XCD_BALANCE', 'B2M_CONV_FLOW_SPLIT', 'B2M_XCD_TILES', 'B2M_XCD_WG_CHUNKS', 'B2M_CONV_PIPE', 'B2M_CONV_TW3', 'B2M_CONV_NPF', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_WGRAD_BLK64', 'B2M_WGRAD_BLKBIG')
+SWITCHES = ('B2M_CONV_EXP', 'B2M_WGRAD_EXP', 'B2M_CONV_FLOW2', 'B2M_CONV_PERS', 'B2M_CONV_PERS_WAVES', 'B2M_CONV_STEM', 'B2M_XCD_WINDOW', 'B2M_XCD_CLASSES', 'B2M_WGRAD_NARROW', 'B2M_WGRAD_PIPE_IDENT', 'B2M_WGRAD_KPACK', 'B2M_WGRAD_TARGET', 'B2M_WGRAD_MAX_TILES', 'B2M_CONV_1X1', 'B2M_XCD_ORDER', 'B2M_XCD_BALANCE', 'B2M_CONV_FLOW_SPLIT', 'B2M_XCD_TILES', 'B2M_XCD_WG_CHUNKS', 'B2M_CONV_PIPE', 'B2M_CONV_TW3', 'B2M_CONV_NPF', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_WGRAD_BLK64', 'B2M_WGRAD_BLKBIG')
 cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
          ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
          ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64),
@@ -53,7 +55,14 @@ for name, rb, K, c1, c2, co in cases:
     xs = x1 if c2 == 0 else torch.cat([x1, x2], 1)
     f_fwd = lambda: F_.conv_raw(x1, x2, wp, K, None, rb, n_out, co)
     f_wg = lambda: F_.wgrad_raw(xs, dy, rb, K, dw, 0)
-    res = {v: [[], []] for v, _ in VARIANTS}
+
+    def f_both():          # data-gradient-shaped launch and weight gradient side by side on two streams, as in the backward pass
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            f_wg()
+        f_fwd()
+        torch.cuda.current_stream().wait_stream(side)
+    res = {v: [[], [], []] for v, _ in VARIANTS}
     for rnd in range(4):
         for v, env in VARIANTS:
             for k_ in SWITCHES: os.environ.pop(k_, None)
@@ -62,7 +71,11 @@ for name, rb, K, c1, c2, co in cases:
             wp = F_.weight_pack(w)          # the packed layout depends on the strip-width switch
             if rnd == 0: f_fwd(); f_wg(); torch.cuda.synchronize()
             res[v][0].append(timeit(f_fwd)); res[v][1].append(timeit(f_wg))
+            if CORUN:
+                res[v][2].append(timeit(f_both))
     line = '%-22s' % name
     for v, _ in VARIANTS:
         line += ' | %s fwd %6.2f TF wg %6.2f TF' % (v, fl / min(res[v][0]) / 1e9, fl / min(res[v][1]) / 1e9)
+        if CORUN:
+            line += ' both %6.2f TF' % (2 * fl / min(res[v][2]) / 1e9)
     print(line)

@@ -1,0 +1,32 @@
+"""Useful share of the executed MFMAs by tile size, per U-Net level, on one synthetic 150 k-voxel scene (CPU only):
+pairs of a (tile, offset) are rounded up to MFMA row groups of 16.  T = 64: one tile per item (conv_fwd_flow_kernel,
+conv_flow2_kernel<NT = 1>); T = 128: two tiles per item (conv_flow2_kernel<NT = 2>).  Uses the oracle's kernel maps (test
+infrastructure, not the product)."""
+import sys, numpy as np
+sys.path.insert(0,'/root/repo')
+from box2mask_amd import synth
+from oracle import sparse_ref as S
+b = synth.make_batch(1, seed0=0)
+c = b['vox_coords'].numpy().astype(np.int64)
+def morton(c):
+    x,y,z = c[:,1]-c[:,1].min(), c[:,2]-c[:,2].min(), c[:,3]-c[:,3].min()
+    k = np.zeros(len(c), np.uint64)
+    for bit in range(12):
+        k |= ((x>>bit)&1).astype(np.uint64) << np.uint64(3*bit+2)
+        k |= ((y>>bit)&1).astype(np.uint64) << np.uint64(3*bit+1)
+        k |= ((z>>bit)&1).astype(np.uint64) << np.uint64(3*bit)
+    return np.argsort(k, kind='stable')
+c = c[morton(c)]
+for lvl in range(4):
+    ts = 1<<lvl
+    nbr = np.asarray(S.kernel_map_same(c, 3, ts))
+    K, N = nbr.shape
+    for T in (64, 128):
+        nt = (N + T - 1)//T
+        pad = nt*T - N
+        v = np.concatenate([nbr >= 0, np.zeros((K,pad),bool)],1).reshape(K, nt, T).sum(2)
+        act = v > 0
+        g = (v + 15)//16
+        print('level', lvl, 'N', N, 'T', T, 'pairs/row %.1f'%(v.sum()/N), 'avg cnt/active %.1f'%v[act].mean(), 'active/tile %.1f'%act.sum(0).mean(),
+              'useful %.3f'%(v.sum()/ (16*g.sum())), 'G hist', np.round(np.bincount(g[act].ravel(), minlength=T//16+1)/act.sum(),2))
+    c = S.stride_coords(c, ts)[0].astype(np.int64)
