@@ -122,13 +122,14 @@ def main():
     ap.add_argument('--detail', type=int, default=0, help='1 prints a per-layer-shape table of the conv launches to stderr')
     ap.add_argument('--cpu-timeout', type=int, default=240, help='seconds after which the CPU baseline is abandoned')
     ap.add_argument('--votes', type=int, default=1, help='0 skips the votes -> instance masks leg (outside the timed steps)')
+    ap.add_argument('--inference', type=int, default=1, help='0 skips the batch-size-1 inference leg (outside the timed steps)')
     ap.add_argument('--prepare', type=int, default=1, help='0 skips the raw points -> device batch leg (outside the timed steps)')
     ap.add_argument('--workload', default='scannet', choices=['scannet', 's3dis', 'arkit'],
                     help='scannet = BASELINE configs[1] (the headline); s3dis / arkit = configs[4] / [5], own lines under profiles/, '
                          'never the headline')
     args = ap.parse_args()
     if args.workload != 'scannet':       # the side legs and the CPU baseline belong to the headline workload
-        args.votes = args.prepare = args.cpu_baseline = 0
+        args.votes = args.prepare = args.cpu_baseline = args.inference = 0
 
     # `python bench.py --gpus N` without a launcher: start the N rank processes here, BEFORE this process makes any
     # GPU call (children via subprocess; a process that has initialised the GPU must never exec another program).
@@ -462,6 +463,10 @@ def main():
     if args.votes and world == 1:          # N=1 only: the other ranks of a scaling run wait at the final barrier
         result['votes_to_masks'] = votes_leg(model, batch, cfg, cpu=bool(args.cpu_baseline), pmc=pmc, pmc_src=pmc_src)
 
+    # ---- inference as the reference's Evaluater runs it: batch_size 1, eval mode, forward + votes -> masks
+    if args.inference and world == 1:
+        result['inference'] = inference_leg(model, dev, cfg, args.target_voxels, cpu_result, rb_lookup)
+
     # ---- raw scene points -> voxelised, collated device batch (what feeds the step above)
     if args.prepare and world == 1:
         result['prepare'] = prepare_leg(dev, args.target_voxels, cpu=bool(args.cpu_baseline))
@@ -703,6 +708,87 @@ def votes_leg(model, batch, cfg, cpu, pmc=None, pmc_src=None):
     return out
 
 
+def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10):
+    """The reference's evaluation flow (evaluation.py:70-98: batch_size 1, model.eval(), no gradients): one synthetic scene
+    of the metric's size, `Model.get_prediction(batch, with_grad=False)` + `Model.pred2mask(batch, pred, 'eval')`, scenes per
+    second.  Every trunk convolution applies its eval-mode BatchNorm (+ residual) (+ ReLU) on the way out of its kernel
+    (b2m_conv_fwd_affine).  Own roofline: the convolution launches of the forward pass, bracketed by HIP events in an extra
+    pass (small-batch regime: a quarter of the rows per launch of the training benchmark's bs = 8 batches).  Never the
+    headline."""
+    from box2mask_amd import _lib, synth
+    batch = synth.make_batch(1, seed0=100, target_voxels=target_voxels)
+    n_vox = int(batch['vox_coords'].shape[0])
+    for k in ('vox_coords', 'vox_features', 'pooling_ids'):
+        batch[k] = batch[k].to(dev)
+    was_training = model.detection_model.training
+    model.eval()
+
+    def once(masks=True):
+        pred = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=True)
+        return model.pred2mask(batch, pred, 'eval') if masks else pred
+    for _ in range(2):
+        res = once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once(masks=False)
+    torch.cuda.synchronize()
+    dt_fwd = (time.perf_counter() - t0) / reps
+    # roofline of the forward pass's convolutions (own pass: the events serialise the stream)
+    rec, launches = [], {}
+
+    def hook(name, a, meta_in=None):
+        launches[name] = launches.get(name, 0) + 1
+        if name not in ('b2m_conv_fwd_affine', 'b2m_conv_fwd'):
+            return None
+        s_ = torch.cuda.Event(enable_timing=True); e_ = torch.cuda.Event(enable_timing=True)
+        cin = (meta_in or {}).get('cin', a[2] + a[5])
+        # b2m_conv_fwd_affine: x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, ...
+        meta = dict(cin=cin, cout=a[15], K=a[8], n_out=a[12], rb_cnt=a[11]) if name == 'b2m_conv_fwd_affine' else \
+            dict(cin=cin, cout=a[16], K=a[8], n_out=a[13], rb_cnt=a[12])
+        s_.record()
+
+        def done():
+            e_.record()
+            rec.append((s_, e_, meta))
+        return done
+    _lib.set_hook(hook)
+    once(masks=False)
+    torch.cuda.synchronize()
+    _lib.set_hook(None)
+    cache, ms, flops = {}, 0.0, 0.0
+    for s_, e_, meta in rec:
+        ms += s_.elapsed_time(e_)
+        flops += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']
+    tf = flops / max(ms, 1e-9) / 1e9
+    if was_training:
+        model.train()
+    out = {'value': round(1.0 / dt, 3), 'unit': 'scenes/s', 'ms_per_scene': round(dt * 1e3, 3),
+           'ms_forward': round(dt_fwd * 1e3, 3), 'voxels': n_vox, 'instances': int(sum(len(r['conf']) for r in res.values())),
+           'flow': "batch_size 1: Model.get_prediction(batch, with_grad=False) + Model.pred2mask(batch, pred, 'eval') "
+                   '(evaluation.py:70-98); predictions and masks returned to the host',
+           'launches_forward': int(sum(launches.values())),
+           'fused_conv_bn_launches': int(launches.get('b2m_conv_fwd_affine', 0)),
+           'batchnorm_launches': int(launches.get('b2m_bn_apply', 0) + launches.get('b2m_bn_apply2', 0)),
+           'roofline': {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                        'kernel': 'b2m_conv_fwd_affine (conv_fwd_flow_kernel / conv_1x1_kernel / conv_stem_kernel with the '
+                                  'BatchNorm epilogue) + b2m_conv_fwd (heads)',
+                        'launches': len(rec), 'ms': round(ms, 3), 'gflop': round(flops / 1e9, 2)}}
+    if cpu_result is not None and cpu_result.get('inference_s'):
+        out['cpu_baseline'] = {'value': round(1.0 / cpu_result['inference_s'], 4), 'unit': 'scenes/s', 'cores': cpu_result['cores'],
+                               'kind': 'port',
+                               'sample': 'forward of ONE scene of the metric\'s size on the CPU oracle (oracle/unet_ref.py, '
+                                         'coordinate / kernel-map build included): %.1f s; the votes -> masks half on the CPU '
+                                         'is votes_to_masks.cpu_baseline' % cpu_result['inference_s']}
+    return out
+
+
 def prepare_leg(dev, target_voxels, cpu, n_scenes=2):
     """Dataset item incl. weak box supervision + collate (dataloader.py:61-314, 946-995) of `n_scenes` synthetic raw scenes (~1.2 M points,
     ~150 k voxels each) with the points already resident in HBM; with `cpu`, scene 0 also runs on the CPU oracle
@@ -820,6 +906,7 @@ def cpu_baseline(n_scenes, voxels, timeout_s, ref_voxels):
     try:
         out = unet_ref.forward(p, b['vox_coords'].numpy(), b['vox_features'], b['pooling_ids'], cfg, training=True,
                                n_segments=b['input_location'].shape[0], return_trunk=True)
+        dt_fwd = time.perf_counter() - t0
         keep = {'state': {k: v.detach().clone() for k, v in net.state_dict().items()}, 'batch': b,
                 'out': {k: v.detach().clone() for k, v in out.items()}}
         loss = sum(v.abs().mean() for k, v in out.items() if k != '_trunk')
@@ -828,11 +915,12 @@ def cpu_baseline(n_scenes, voxels, timeout_s, ref_voxels):
         value = round(n_scenes / dt, 5)
         note = '%.1f s' % dt
     except _Timeout:
-        value, note, keep = None, 'abandoned after %d s' % timeout_s, None
+        value, note, keep, dt_fwd = None, 'abandoned after %d s' % timeout_s, None, None
     finally:
         signal.alarm(0)
         signal.signal(signal.SIGALRM, old)
     return {'value': value, 'unit': 'scenes/s', 'cores': cores, 'kind': 'port',
+            'inference_s': None if (value is None or dt_fwd is None) else round(dt_fwd / n_scenes, 2),
             'sample': '%d synthetic scene(s) of the metric\'s size (%d voxels in all, seed 0..%d; no scaling): coordinate/'
                       'kernel-map build + forward + backward on the CPU oracle (oracle/unet_ref.py, torch %s, %d threads): '
                       '%s; value = scenes / seconds' % (n_scenes, nvox, n_scenes - 1, torch.__version__, cores, note)}, keep

@@ -36,10 +36,27 @@ struct ConvArgs {
     double* stats;   // != NULL: per-tile column sums of the finished output, [tile][2][cout] (sum, sum of squares): the
                      // BatchNorm statistics of the following layer without another pass over Y (conv_fwd_flow_kernel only)
     unsigned* tickets;   // conv_flow2_kernel<.., PERS = 1>: work counters of the 8 XCD runs + exit counter (ticket_block())
+    // Inference epilogue (b2m_conv_fwd_affine): the strip is written as  [relu]( fmaf(Y, ep_scale[col], ep_shift[col]) [+ ep_res] )
+    // -- the eval-mode BatchNorm (+ residual) (+ ReLU) that follows every trunk convolution, in exactly b2m_bn_apply's
+    // arithmetic, without its launch and without the round trip of Y through HBM.  16-byte column groups only.
+    const float* ep_scale; const float* ep_shift; const float* ep_res; int64_t ld_res; int ep_relu;
 };
 
 // loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
 __device__ float g_zeros[64];
+
+// the inference epilogue on four consecutive columns of output row `grow` (ConvArgs::ep_scale != NULL; col + 3 < cout)
+__device__ __forceinline__ f32x4 conv_epilogue(const ConvArgs& a, f32x4 v, int64_t grow, int col) {
+    const f32x4 s = *(const f32x4*)(a.ep_scale + col), b = *(const f32x4*)(a.ep_shift + col);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_fmaf(v[u], s[u], b[u]);
+    if (a.ep_res) v += *(const f32x4*)(a.ep_res + grow * a.ld_res + col);
+    if (a.ep_relu) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = v[u] > 0.f ? v[u] : 0.f;
+    }
+    return v;
+}
 
 // Diagnostic build only (-DB2M_STAMPS, tools/stamps.py): s_memtime stamps per phase of the offset walk, summed
 // over all waves.  Not compiled into the shipped library.
@@ -426,6 +443,7 @@ __global__ __launch_bounds__(256, (NPF <= 2 && TW == 2) ? 4 : 3) void conv_fwd_k
 // over the tile's ACTIVE offsets is software-pipelined by hand: while offset k multiplies and updates the strip, the rows of
 // the next active offset are in flight and the pair list of the one after is being fetched.
 // One wave per tile (cout <= 32: one strip), 4 tiles per workgroup; single source, 8-channel chunk, un-split maps.
+template <bool EP>      // EP: the inference epilogue (a variant of its own: at 128 VGPRs the extra pointers spilled in the training kernel)
 __global__ __launch_bounds__(256, 4) void conv_stem_kernel(ConvArgs a) {
     constexpr int TW = 2, SW = 32;
     __shared__ float smem[4 * (B2M_TILE + 1) * SW];
@@ -590,10 +608,12 @@ __global__ __launch_bounds__(256, 4) void conv_stem_kernel(ConvArgs a) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
         if (grow >= a.n_out) continue;
-        const f32x4 v = *(const f32x4*)&Cs[cs_index<TW>(row, c4)];
+        f32x4 v = *(const f32x4*)&Cs[cs_index<TW>(row, c4)];
         float* dst = a.y + grow * a.ldy + c4;
-        if (a.vec_store && c4 + 3 < a.cout) *(f32x4*)dst = v;
-        else {
+        if (a.vec_store && c4 + 3 < a.cout) {
+            if constexpr (EP) v = conv_epilogue(a, v, grow, c4);
+            *(f32x4*)dst = v;
+        } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (c4 + u < a.cout) dst[u] = v[u];
         }
@@ -827,12 +847,15 @@ extern "C" int b2m_weight_pack_run(const void* plan_dev, int32_t n, int64_t tota
     return B2M_OK;
 }
 
+struct ConvEpilogue { const float* scale; const float* shift; const float* res; int64_t ld_res; int relu; };
 static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
                          int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
                          const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,
-                         int32_t cout, int32_t accumulate, double* tile_stats, int32_t* wrote_stats, void* stream) {
+                         int32_t cout, int32_t accumulate, double* tile_stats, int32_t* wrote_stats, void* stream,
+                         const ConvEpilogue* ep = nullptr, int32_t* fused = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     if (wrote_stats) *wrote_stats = 0;
+    if (fused) *fused = 0;
     B2M_CHECK_ARG(x1 && wp && y && c1 > 0 && c2 >= 0 && cout > 0 && K >= 1 && K <= 128, "bad pointers/sizes (K<=128)");
     B2M_CHECK_ARG((rb_in == nullptr) == (rb_out == nullptr) && (rb_in == nullptr) == (rb_cnt == nullptr),
                   "rulebook pointers must be all set or all NULL");
@@ -856,10 +879,19 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
     a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
     a.stats = nullptr; a.tickets = nullptr;
+    a.ep_scale = a.ep_shift = a.ep_res = nullptr; a.ld_res = 0; a.ep_relu = 0;
     a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr;
     const int TW = conv_tw(cout, K);
     a.nstrips = (cout + 16 * TW - 1) / (16 * TW);
     a.vec_store = (ldy % 4 == 0 && ((uintptr_t)y % 16) == 0) ? 1 : 0;
+    // the inference epilogue needs whole 16-byte column groups everywhere it touches
+    const bool ep_ok = ep && ep->scale && ep->shift && a.vec_store && cout % 4 == 0 && !accumulate && !bias &&
+                       ((uintptr_t)ep->scale % 16) == 0 && ((uintptr_t)ep->shift % 16) == 0 &&
+                       (!ep->res || (ep->ld_res % 4 == 0 && ep->ld_res >= cout && ((uintptr_t)ep->res % 16) == 0));
+    auto use_epilogue = [&]() {
+        a.ep_scale = ep->scale; a.ep_shift = ep->shift; a.ep_res = ep->res; a.ld_res = ep->ld_res; a.ep_relu = ep->relu;
+        if (fused) *fused = 1;
+    };
     // Small maps (deep U-Net levels: a few hundred rows, 256 channels) have too few (tile, strip) items to
     // fill 1024 SIMDs and each item walks K*cin/16 dependent steps: split the offsets over up to 16 waves.
     const int64_t items0 = a.ntiles * a.nstrips;
@@ -914,6 +946,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
         if (a.ntiles * (a.nstrips / spw) < 2048) spw = 1;       // few rows (the heads on segments): one wave per strip
         const int64_t g1 = a.ntiles * (a.nstrips / spw);
         B2M_CHECK_ARG(g1 < (1ll << 31), "too many workgroups");
+        if (ep_ok) use_epilogue();
         if (spw == 3) conv_1x1_kernel<3><<<(unsigned)g1, 64, 0, st>>>(a);
         else if (spw == 2) conv_1x1_kernel<2><<<(unsigned)g1, 64, 0, st>>>(a);
         else conv_1x1_kernel<1><<<(unsigned)g1, 64, 0, st>>>(a);
@@ -938,6 +971,8 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 a.stats = tile_stats;
                 if (wrote_stats) *wrote_stats = 1;
             }
+            // (the workgroup that writes a (tile, strip) holds its final values: un-split, or exactly 4 slices combined in LDS)
+            if (ep_ok && (nslice == 1 || nslice == 4)) use_epilogue();
             a.nwg = cdiv64(items, wpb);
             XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
             a.xcd_per = fo.chunk;
@@ -952,7 +987,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
             // un-split maps: conv_flow2_kernel (conv_fwd_flow2.h) -- B2M_CONV_FLOW2 = tiles per item (0: the round-2 kernel),
             // B2M_CONV_PERS = persistent grid
             const int f2 = env_flag("B2M_CONV_FLOW2", 0);      // (measured slower than the round-2 kernel in every form: profiles/r04_analysis.md)
-            if (wpb == 1 && !dbg && f2 >= 1 && K <= 64 && a.ntiles < (1ll << 24)) {
+            if (wpb == 1 && !dbg && f2 >= 1 && K <= 64 && a.ntiles < (1ll << 24) && !a.ep_scale) {
                 const int NT = f2 >= 2 ? 2 : 1;
                 const int64_t run_max = a.xcd_start ? B2M_XCD_CAP(a.ntiles) : cdiv64(a.ntiles, 8);
                 const int64_t per_run = cdiv64(run_max, NT) * a.nstrips;            // items of the longest run
@@ -1023,7 +1058,10 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
             a.stats = tile_stats;
             if (wrote_stats) *wrote_stats = 1;
         }
-        conv_stem_kernel<<<grid, 256, 0, st>>>(a);
+        if (ep_ok) {
+            use_epilogue();
+            conv_stem_kernel<true><<<grid, 256, 0, st>>>(a);
+        } else conv_stem_kernel<false><<<grid, 256, 0, st>>>(a);
         B2M_LAUNCH_CHECK();
         return B2M_OK;
     }
@@ -1058,6 +1096,16 @@ extern "C" int b2m_conv_fwd(const float* x1, int64_t ldx1, int32_t c1, const flo
                             int32_t cout, int32_t accumulate, void* stream) {
     return conv_fwd_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, bias, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, accumulate,
                          nullptr, nullptr, stream);
+}
+extern "C" int b2m_conv_fwd_affine(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
+                                   int64_t n_in, const float* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out,
+                                   const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy, int32_t cout,
+                                   const float* scale, const float* shift, const float* res, int64_t ld_res, int32_t relu,
+                                   int32_t* fused, void* stream) {
+    B2M_CHECK_ARG(scale && shift && fused, "scale / shift / fused are NULL");
+    const ConvEpilogue ep = {scale, shift, res, ld_res, relu};
+    return conv_fwd_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, nullptr, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, 0, nullptr,
+                         nullptr, stream, &ep, fused);
 }
 extern "C" int b2m_conv_fwd_stats(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
                                   int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,

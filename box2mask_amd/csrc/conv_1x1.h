@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64, SPW == 3 ? 2 : 3) void conv_1x1_kernel(ConvArgs
                     for (int u = 0; u < 4; ++u) v[u] += a.bias[col + u];
                 }
                 if (a.accumulate) v += *(const f32x4*)dst;
+                if (a.ep_scale) v = conv_epilogue(a, v, grow, col);
                 *(f32x4*)dst = v;
             } else {
 #pragma unroll

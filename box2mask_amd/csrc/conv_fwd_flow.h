@@ -329,6 +329,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             const int col = col0 + c4;
             float* dst = a.y + grow * a.ldy + col;
             if (plain && a.vec_store && col + 3 < a.cout) {
+                if (a.ep_scale) v = conv_epilogue(a, v, grow, col);
                 *(f32x4*)dst = v;
             } else {
 #pragma unroll
@@ -351,10 +352,11 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
         if (grow >= a.n_out) continue;
-        const f32x4 v = *(const f32x4*)&Cs[row * PITCH + c4];
+        f32x4 v = *(const f32x4*)&Cs[row * PITCH + c4];
         const int col = col0 + c4;
         float* dst = a.y + grow * a.ldy + col;
         if (a.vec_store && col + 3 < a.cout) {
+            if (a.ep_scale) v = conv_epilogue(a, v, grow, col);
             *(f32x4*)dst = v;
         } else {
 #pragma unroll

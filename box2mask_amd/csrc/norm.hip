@@ -254,12 +254,68 @@ extern "C" int b2m_bn_tilestats(const double* tile_stats, int64_t ntiles, int32_
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
+// The same in ONE launch for maps of up to a few thousand tiles (every trunk layer below level 0: 85 launches of the forward
+// pass sit on its critical path, each worth its launch gap): a workgroup owns 8 channels -- thread (tile lane tl, column
+// cl) adds up column sum (cl < 8) or sum of squares (cl >= 8) of channel ch0 + cl % 8 over the tiles tl, tl + 16, ... (two
+// 64-byte segments of a tile's row per tile lane), the 16 tile lanes meet in LDS in fixed order, and the channel's finalize
+// math runs in the same workgroup.  Deterministic (another summation grouping than the two-launch form: last bits differ).
+__global__ __launch_bounds__(256) void bn_tilestats_finalize_one_kernel(const double* __restrict__ ts, int64_t ntiles, double count,
+                                                                        int c, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, float eps, float momentum,
+                                                                        float* __restrict__ running_mean,
+                                                                        float* __restrict__ running_var, float* __restrict__ mean,
+                                                                        float* __restrict__ invstd, float* __restrict__ scale,
+                                                                        float* __restrict__ shift, double* __restrict__ stats) {
+    __shared__ double red[16][16];
+    const int tl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int ch = blockIdx.x * 8 + (cl & 7);
+    const int col = (cl < 8 ? 0 : c) + ch;
+    double s[4] = {0., 0., 0., 0.};
+    if (ch < c) {
+        const double* p = ts + col;
+        const int64_t c2 = 2 * (int64_t)c;
+        int64_t t = tl;
+        for (; t + 48 < ntiles; t += 64) {          // four tiles' loads in flight per thread
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += p[(t + 16 * u) * c2];
+        }
+        for (; t < ntiles; t += 16) s[0] += p[t * c2];
+    }
+    red[tl][cl] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (tl != 0 || cl >= 8 || ch >= c) return;
+    double s1 = 0, s2 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1 += red[r][cl]; s2 += red[r][cl + 8]; }
+    const int j = ch;
+    if (stats) { stats[j] = s1; stats[c + j] = s2; }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0) var = 0;
+    if (running_mean) {
+        const double unb = count > 1 ? var * count / (count - 1) : var;
+        running_mean[j] = (float)((1.0 - momentum) * (double)running_mean[j] + momentum * m);
+        running_var[j] = (float)((1.0 - momentum) * (double)running_var[j] + momentum * unb);
+    }
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[j] : 1.0, b = beta ? (double)beta[j] : 0.0;
+    if (mean) mean[j] = (float)m;
+    if (invstd) invstd[j] = (float)is;
+    scale[j] = (float)(g * is);
+    shift[j] = (float)(b - m * g * is);
+}
 extern "C" int b2m_bn_tilestats_finalize(const double* tile_stats, int64_t ntiles, int64_t n, int32_t c, double* partial,
                                          double* stats, const float* gamma, const float* beta, float eps, float momentum,
                                          float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                          float* shift, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(tile_stats && partial && scale && shift && ntiles >= 1 && n >= 1 && c > 0 && c <= 1024, "bad arguments");
+    if (ntiles <= b2m_env_int("B2M_BN_TS_ONE", 8192)) {
+        bn_tilestats_finalize_one_kernel<<<(c + 7) / 8, 256, 0, st>>>(tile_stats, ntiles, (double)n, c, gamma, beta, eps, momentum,
+                                                                      running_mean, running_var, mean, invstd, scale, shift, stats);
+        B2M_LAUNCH_CHECK();
+        return B2M_OK;
+    }
     const int nblk = tilestats_blocks(ntiles);
     bn_tilestats_kernel<<<nblk, 256, 0, st>>>(tile_stats, ntiles, 2 * c, partial);
     bn_final_finalize_kernel<<<c, 64, 0, st>>>(partial, nblk, (double)n, c, gamma, beta, eps, momentum, running_mean,

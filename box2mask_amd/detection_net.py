@@ -124,6 +124,9 @@ class SelectionNet(ResNetBase):
     def _cbr(conv, bn, x, skip=False):
         """conv -> BN -> ReLU.  skip: x has a second consumer later in the network (the decoder's ME.cat); returns
         (result, x') with x' the alias that consumer must take (ME.MinkowskiConvolution.forward(passthrough=True))."""
+        if bn.fusable():                    # inference: one launch (ME.MinkowskiConvolution.forward(fuse=...))
+            out = conv(x, fuse=(bn, None, True))
+            return (out, x) if skip else out
         if skip:
             out, x = conv(x, passthrough=True)
         else:

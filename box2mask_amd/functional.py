@@ -186,6 +186,60 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
     return out
 
 
+def conv_affine(x1, x2, weight, rb: Rulebook | None, n_out: int, scale, shift, residual=None, relu=False):
+    """Inference form of conv -> eval-mode BatchNorm (+ residual) (+ ReLU): y = [relu](fmaf(conv(x), scale, shift) [+ res])
+    in ONE launch where the layer's kernel can transform its strip on the way out (b2m_conv_fwd_affine), else convolution
+    + b2m_bn_apply -- the same bits either way.  No autograd (the caller checks torch.is_grad_enabled()).
+    (/root/reference/models/resnet.py:70-83, detection_net.py:234-337 under model.eval().)"""
+    x1 = _f32c(x1)
+    x2 = _f32c(x2) if x2 is not None else None
+    c1 = x1.shape[1]
+    logical_cin = None
+    if x2 is None and c1 % 4 != 0 and c1 < 16:           # the 6-channel network input (see _SparseConv.forward)
+        xp = torch.nn.functional.pad(x1, (0, 16 - c1))
+        x1 = xp[:, :(c1 + 3) // 4 * 4]
+        logical_cin = c1
+    w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+    K, cin, cout = w3.shape
+    wp = packed_weights.get(weight)
+    c1 = x1.shape[1]
+    c2 = x2.shape[1] if x2 is not None else 0
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=x1.device)
+    if rb is None:
+        rbi = rbo = rbc = None
+    else:
+        assert rb.K == K and rb.n_out == n_out
+        rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
+    if residual is not None:
+        residual = _f32c(residual)
+    if n_out == 0:
+        return out
+    fused = ctypes.c_int32(0)
+    _call('b2m_conv_fwd_affine', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
+          x1.shape[0], wp.data_ptr(), K, rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout, scale.data_ptr(),
+          shift.data_ptr(), _ptr(residual), residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+          ctypes.byref(fused), meta=None if logical_cin is None else {'cin': logical_cin})
+    if not fused.value:
+        _call('b2m_bn_apply', out.data_ptr(), out.stride(0), n_out, cout, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
+              residual.stride(0) if residual is not None else 0, 1 if relu else 0, out.data_ptr(), out.stride(0))
+    return out
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
+    """(scale, shift) of an eval-mode BatchNorm: y = fmaf(x, scale, shift) (b2m_bn_finalize on the running statistics)."""
+    c = running_mean.shape[0]
+    scale = torch.empty(c, dtype=torch.float32, device=running_mean.device)
+    shift = torch.empty(c, dtype=torch.float32, device=running_mean.device)
+    _call('b2m_bn_finalize', None, 1.0, None, c, _ptr(gamma), _ptr(beta), eps, 0.0, running_mean.data_ptr(),
+          running_var.data_ptr(), None, None, scale.data_ptr(), shift.data_ptr())
+    return scale, shift
+
+
+def conv_affine_enabled() -> bool:
+    """B2M_CONV_AFFINE=0: inference runs convolution and BatchNorm as separate launches (the training-mode layering)."""
+    return os.environ.get('B2M_CONV_AFFINE', '1') == '1'
+
+
 def wgrad_raw(x, dy, rb: Rulebook | None, K: int, dw3, ci0: int, cin: int | None = None):
     """dw3[:, ci0:ci0+cin, :] += sum_pairs x[in, :cin]^T dy[out]   (cin defaults to x.shape[1])."""
     cin_total, cout = dw3.shape[1], dw3.shape[2]

@@ -86,12 +86,25 @@ class _ConvBase(nn.Module):
 class MinkowskiConvolution(_ConvBase):
     """[ME-mem] stride 1 (odd kernel, centred) or kernel 2 / stride 2."""
 
-    def forward(self, x: SparseTensor, passthrough: bool = False):
+    def forward(self, x: SparseTensor, passthrough: bool = False, fuse=None):
         """passthrough: returns (y, x') with x' an alias of x for every other consumer of x (a block's residual /
         shortcut branch): this layer's data gradient is then accumulated onto their gradient by the kernel instead of
-        by an add of autograd's (functional._SparseConv)."""
+        by an add of autograd's (functional._SparseConv).
+        fuse = (MinkowskiBatchNorm, residual features or None, relu): inference only (fusable()) -- the layer and the
+        eval-mode BatchNorm (+ residual) (+ ReLU) behind it as one launch (functional.conv_affine)."""
         m, l = x.manager, x.level
         x1, x2 = _sources(x)
+        if fuse is not None:
+            bn, residual, relu = fuse
+            assert self.bias is None and not passthrough
+            scale, shift = bn.eval_affine()
+            if self.kernel_volume == 1:
+                rb, n_out, level = None, x1.shape[0], None
+            elif self.stride == 1:
+                rb = m.rulebook_same(l, self.kernel_size); n_out, level = rb.n_out, None
+            else:
+                rb = m.rulebook_down(l); n_out, level = rb.n_out, l + 1
+            return x.new(F_.conv_affine(x1, x2, self.kernel, rb, n_out, scale, shift, residual, relu), level=level)
 
         def result(out, level=None):
             if not passthrough:
@@ -120,11 +133,16 @@ class MinkowskiConvolutionTranspose(_ConvBase):
     (required by the ME.cat key equality at detection_net.py:286-336)."""
     transposed = True
 
-    def forward(self, x: SparseTensor) -> SparseTensor:
+    def forward(self, x: SparseTensor, fuse=None) -> SparseTensor:
         assert self.stride == 2 and self.kernel_size == 2 and x.level >= 1
         m, l = x.manager, x.level - 1
         x1, x2 = _sources(x)
         rb_f, rb_b = m.rulebook_up(l), m.rulebook_down(l)
+        if fuse is not None:             # inference: see MinkowskiConvolution.forward
+            bn, residual, relu = fuse
+            assert self.bias is None
+            scale, shift = bn.eval_affine()
+            return x.new(F_.conv_affine(x1, x2, self.kernel, rb_f, rb_f.n_out, scale, shift, residual, relu), level=l)
         y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out,
                            collect_stats=self.training and self.bias is None)
         return x.new(y, level=l)
@@ -138,6 +156,25 @@ class MinkowskiBatchNorm(nn.Module):
         super().__init__()
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
         self.sync = False
+
+    def fusable(self) -> bool:
+        """Inference: no gradient is being recorded and the layer normalises with its running statistics -- it is a
+        per-channel affine map that the convolution in front of it can apply on its way out (functional.conv_affine)."""
+        bn = self.bn
+        return (not torch.is_grad_enabled() and not self.training and bn.track_running_stats and bn.running_mean is not None
+                and bn.num_features % 4 == 0 and F_.conv_affine_enabled())
+
+    def eval_affine(self):
+        """(scale, shift) of the eval-mode layer, recomputed only when a parameter or running statistic changed (in-place
+        writes -- load_state_dict, an optimizer step, a training-mode forward -- bump the tensors' version counters)."""
+        bn = self.bn
+        key = tuple((t.data_ptr(), t._version) if t is not None else None
+                    for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        cached = getattr(self, '_affine_cache', None)
+        if cached is None or cached[0] != key:
+            cached = (key, F_.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps))
+            self._affine_cache = cached
+        return cached[1]
 
     def apply_bn(self, feats, residual=None, relu=False, count_key=None, defer_counter=False):
         bn = self.bn

@@ -176,6 +176,21 @@ int b2m_conv_fwd_stats(const float* x1, int64_t ldx1, int32_t c1, const float* x
                        int64_t n_out, float* y, int64_t ldy, int32_t cout, int32_t accumulate,
                        double* tile_stats, int32_t* wrote_stats, void* stream);
 
+/* Inference form of a trunk layer: convolution + the eval-mode BatchNorm that follows it (+ residual) (+ ReLU) in one launch
+ * (/root/reference/models/resnet.py:70-83, detection_net.py:234-337 under model.eval(), evaluation.py:70-98):
+ *   Y[o, c] = [relu]( fmaf(sum_k [x1|x2][in_k(o)] B[k] [., c], scale[c], shift[c]) [+ res[o, c]] )
+ * with scale / shift from b2m_bn_finalize on the running statistics -- the arithmetic of b2m_conv_fwd followed by
+ * b2m_bn_apply, bit for bit, without the second launch and without the round trip of Y through HBM (the strip is
+ * transformed as it is written out).  *fused (host) = 1 if the epilogue was applied; 0 if this shape's kernel cannot
+ * (more than 4 split-K slices, odd column counts, the general fallback kernel): Y then holds the plain convolution
+ * and the caller runs b2m_bn_apply.  No bias, no accumulate; cout % 4 == 0 and 16-byte aligned rows for fused = 1. */
+int b2m_conv_fwd_affine(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
+                        int64_t n_in, const float* wp, int32_t K,
+                        const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                        int64_t n_out, float* y, int64_t ldy, int32_t cout,
+                        const float* scale, const float* shift, const float* res, int64_t ld_res, int32_t relu,
+                        int32_t* fused, void* stream);
+
 /* dW[k][ci][co] += sum over pairs (i,o) of offset k:  X[i, ci] * dY[o, co]     (fp32 atomics)
  * Replaces [ME] ConvolutionBackward (weight part).  x: n_in rows indexed by rb_in (ldx, cin columns used),
  * dy: rows indexed by tile*TILE+rb_out.  dw element (k,ci,co) lives at dw[k*dw_kstride + ci*lddw + co]
@@ -205,7 +220,8 @@ int b2m_bn_stats_finalize(const float* x, int64_t ldx, int64_t n, int32_t c, dou
 
 /* BatchNorm statistics from the per-tile column sums of b2m_conv_fwd_stats instead of a pass over x:
  * b2m_bn_tilestats = b2m_bn_stats, b2m_bn_tilestats_finalize = b2m_bn_stats_finalize with (tile_stats, ntiles) in
- * place of (x, ldx); n = number of rows the sums cover.  partial: double[2*c*1280] scratch. */
+ * place of (x, ldx); n = number of rows the sums cover.  partial: double[2*c*1280] scratch.  Maps of up to 8192 tiles
+ * (B2M_BN_TS_ONE) take ONE launch for the reduction and the finalize math (fixed summation order, other grouping). */
 int b2m_bn_tilestats(const double* tile_stats, int64_t ntiles, int32_t c, double* partial, double* stats, void* stream);
 int b2m_bn_tilestats_finalize(const double* tile_stats, int64_t ntiles, int64_t n, int32_t c, double* partial,
                               double* stats, const float* gamma, const float* beta, float eps, float momentum,

@@ -266,13 +266,18 @@ def test_dense_equivalence_k2s2_and_transpose_random_occupancy(cin, cout):
 
 
 # ------------------------------------------------------------------ 4. BatchNorm statistics from the convolution's epilogue
-@pytest.mark.parametrize('regime', ['unsplit', 'split4', 'many_slices'])
+@pytest.mark.parametrize('regime', ['unsplit', 'split4', 'many_slices', 'unsplit_two_launch_reduction'])
 @pytest.mark.parametrize('cin,cout', [(96, 96), (32, 64), (64, 128)])
 def test_conv_tile_stats_feed_batchnorm(maps, monkeypatch, regime, cin, cout):
     """b2m_conv_fwd_stats: the per-tile column sums the convolution kernel leaves behind equal the sums of its output,
     and BatchNorm fed by them equals BatchNorm that reads the output (b2m_bn_stats) -- forward, running statistics and
-    the gradients.  `many_slices` (atomic combine across workgroups) cannot provide them and must fall back."""
+    the gradients.  `many_slices` (atomic combine across workgroups) cannot provide them and must fall back.  The tile sums
+    are reduced + finalized in one launch (bn_tilestats_finalize_one_kernel; maps of <= 8192 tiles) or in two
+    (B2M_BN_TS_ONE=0: the form the 19 k-tile level-0 maps take)."""
     from box2mask_amd import functional as F_
+    if regime == 'unsplit_two_launch_reduction':
+        monkeypatch.setenv('B2M_BN_TS_ONE', '0')
+        regime = 'unsplit'
     env = {'unsplit': {'B2M_CONV_TARGET': '0'}, 'split4': {'B2M_CONV_TARGET': '800', 'B2M_CONV_CHUNKSPLIT': '0'}, 'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'}}
     for k, v in env[regime].items():
         monkeypatch.setenv(k, v)

@@ -1,4 +1,11 @@
 set -e
 mkdir -p gpurun_out
-CORUN=1 BS=8 CASES="L0 k3 96,L1 k3 96,L1 k3 128,L2 k3 128" VARIANTS="g:B2M_CONV_FLOW2=1,B2M_CONV_PERS=0;prio:B2M_CONV_FLOW2=1,B2M_CONV_PERS=0,B2M_CONV_EXP=1;wg80:B2M_CONV_FLOW2=1,B2M_CONV_PERS=0,B2M_WGRAD_EXP=1;wgprio:B2M_CONV_FLOW2=1,B2M_CONV_PERS=0,B2M_WGRAD_EXP=2;wg80prio:B2M_CONV_FLOW2=1,B2M_CONV_PERS=0,B2M_WGRAD_EXP=3;allprio:B2M_CONV_FLOW2=1,B2M_CONV_PERS=0,B2M_WGRAD_EXP=2,B2M_CONV_EXP=1;nt2g:B2M_CONV_FLOW2=2,B2M_CONV_PERS=0" timeout -k 10 500 python tools/bench_conv.py > gpurun_out/bc4.log 2>&1
-cat gpurun_out/bc4.log
+timeout -k 10 900 python -m pytest tests/test_gpu_inference.py tests/test_gpu_conv_regimes.py -x -q -k "inference or affine or tile_stats or forced_regime" > gpurun_out/t5.log 2>&1 || { tail -40 gpurun_out/t5.log; exit 1; }
+tail -3 gpurun_out/t5.log
+timeout -k 10 600 python bench.py --steps 5 --warmup 2 > gpurun_out/b5.json 2> gpurun_out/b5.err || { tail -30 gpurun_out/b5.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/b5.json').read().strip().splitlines()[-1])
+print('ms/step', d['ms_per_step'], 'value', d['value'], 'roofline', d['roofline']['frac'], 'wgrad', d['roofline_wgrad']['frac'])
+print('inference', json.dumps(d.get('inference'))[:1500])
+PY
