@@ -548,16 +548,25 @@ def gpu_vs_oracle(keep, dev):
         trunk = net._trace['block8']
         if sin.manager.inv_perm is not None:
             trunk = trunk[sin.manager.inv_perm]
-    errs = {}
+    errs, rerrs = {}, {}
     for h, ref in keep['out'].items():
-        got = trunk if h == '_trunk' else out[h].F
-        errs[h] = float((got.detach().cpu().double() - ref.double()).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        got = (trunk if h == '_trunk' else out[h].F).detach().cpu().double()
+        ref = ref.double()
+        tmax = max(float(ref.abs().max()), 1e-30)
+        errs[h] = float((got - ref).abs().max()) / tmax
+        # per-row figure: a row counts with its own magnitude (at least 5 % of the tensor's maximum) -- rows of small
+        # magnitude are invisible to the per-tensor figure
+        den = torch.clamp(ref.abs().max(1).values, min=0.05 * tmax)
+        rerrs[h] = float(((got - ref).abs().max(1).values / den).max())
     del net, out, trunk, sin
     torch.cuda.empty_cache()
     return {'max_rel_err_vs_gpu': float('%.3e' % max(errs.values())),
+            'max_row_rel_err_vs_gpu': float('%.3e' % max(rerrs.values())),
+            'row_rel_err_vs_gpu_by_output': {('vox_feats' if k == '_trunk' else k): float('%.3e' % v) for k, v in rerrs.items()},
             'rel_err_vs_gpu_by_output': {('vox_feats' if k == '_trunk' else k): float('%.3e' % v) for k, v in errs.items()},
             'parity_note': 'device forward (default mode, train-mode BatchNorm) on the same weights and the same full-size '
-                           'scene as this CPU sample; error = max |gpu - cpu| / max |cpu| per output'}
+                           'scene as this CPU sample; error = max |gpu - cpu| / max |cpu| per output; row figure = max over rows of '
+                           '|gpu - cpu|_inf(row) / max(|cpu|_inf(row), 0.05 max |cpu|)'}
 
 
 def spawn_ranks(n):

@@ -2,6 +2,21 @@
 import numpy as np
 import torch
 
+ROW_EPS = 0.05        # a row counts with at least this fraction of the tensor's maximum as its own scale
+ROW_FACTOR = 10.0     # bound on the per-row figure = ROW_FACTOR x the bound on the per-tensor figure
+
+
+def row_rel_err(a, b):
+    """max over rows of |a - b|_inf(row) / max(|b|_inf(row), ROW_EPS * |b|_inf): the per-tensor figure (error over the
+    tensor's maximum) cannot see rows of small magnitude -- deep levels, head outputs near zero; this one can."""
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    if a.dim() < 2 or a.numel() == 0:
+        return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30) if a.numel() else 0.0
+    a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    tmax = max(float(b2.abs().max()), 1e-30)
+    den = torch.clamp(b2.abs().max(1).values, min=ROW_EPS * tmax)
+    return float(((a2 - b2).abs().max(1).values / den).max())
+
 
 class MaskRecorder:
     """ReLU decisions of the device forward, replayed in the CPU oracle.
@@ -60,11 +75,38 @@ class MaskRecorder:
             assert m.shape[0] == (n_seg if level is None else manager.n(level))
             masks.append(m if level is None else m[to_gpu[level]])
         it = iter(masks)
+        self.checks = []                              # per replayed ReLU: (rows, disagreeing fraction, max |x| / rms among them)
 
         def masked(x):
             m = next(it)
             assert m.shape == x.shape
+            # The replay must not MIRROR a wrong device decision: the oracle's own decision x > 0 is taken at every replayed
+            # ReLU and may differ from the device's only on a few elements whose pre-activation is within forward rounding of
+            # zero.  A kernel that got `y > 0` wrong for a channel, a tile or a whole layer fails here, not nowhere.
+            xd = x.detach()
+            own = xd > 0
+            dis = own != m
+            nd = int(dis.sum())
+            rms = float(xd.double().pow(2).mean().sqrt())
+            worst = float(xd[dis].abs().max()) / max(rms, 1e-30) if nd else 0.0
+            frac = nd / max(m.numel(), 1)
+            self.checks.append((m.shape[0], frac, worst))
+            assert frac <= self.max_flip_fraction, \
+                'ReLU %d: device and oracle disagree on %.2e of the elements' % (len(self.checks), frac)
+            assert worst <= self.max_flip_preact, \
+                'ReLU %d: a disagreeing element has |pre-activation| = %.2e x the layer rms' % (len(self.checks), worst)
             return x * m.to(x.dtype)
         monkeypatch.setattr(torch, 'relu', masked)
         self.to_gpu = to_gpu
         return it
+
+    # bounds on the borderline decisions (see `masked`): at most 1e-3 of a layer's elements, each within 1e-4 of the layer's
+    # rms of zero -- the device forward agrees with the fp64 oracle to ~1e-5 of a tensor's maximum (a few 1e-5 of its rms)
+    max_flip_fraction = 1e-3
+    max_flip_preact = 1e-4
+
+    def summary(self):
+        """(largest disagreeing fraction, largest |x| / rms of a disagreeing element) over the replayed ReLUs."""
+        if not getattr(self, 'checks', None):
+            return 0.0, 0.0
+        return max(c[1] for c in self.checks), max(c[2] for c in self.checks)

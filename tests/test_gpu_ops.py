@@ -15,6 +15,9 @@ def _close(a, b, what, tol=TOL):
     scale = max(float(b.abs().max()), 1e-6)
     err = float((a - b).abs().max()) / scale
     assert err < tol, '%s: max rel-to-max error %.3e' % (what, err)
+    from _parity import row_rel_err, ROW_FACTOR
+    rerr = row_rel_err(a, b)              # rows of small magnitude count with their own scale (tests/_parity.py)
+    assert rerr < ROW_FACTOR * tol, '%s: max per-row relative error %.3e' % (what, rerr)
     return err
 
 
