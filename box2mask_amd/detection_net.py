@@ -236,7 +236,14 @@ class SelectionNet(ResNetBase):
         vox_start = 0
         for scene_idx, scene in enumerate(batch['scene']):
             scene_mask = batch_ids == scene_idx
-            seg2vox = torch.as_tensor(batch['seg2vox'][scene_idx]).long()
+            if cfg.do_segment_pooling:
+                seg2vox = torch.as_tensor(batch['seg2vox'][scene_idx]).long()
+            else:
+                # predictions already live on the voxels (detection_net.py:436-445 projects only `if cfg.do_segment_pooling`):
+                # the voxel of vote j IS j.  (The reference's branch then indexes per-voxel arrays with masks that have one
+                # column per FOREGROUND vote, :463 / :470, and fails on the first background voxel; here background votes are
+                # zero-padded exactly as the pooled branch does, which is the same result whenever the reference has one.)
+                seg2vox = torch.arange(int(scene_mask.sum()), dtype=torch.long)
             n_vox = seg2vox.shape[0]
             s2v = seg2vox.to(dev)
             if not self.requires_voxel_outputs:

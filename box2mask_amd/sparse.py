@@ -245,8 +245,21 @@ class SparseTensor:
 
     @property
     def C(self):
-        """Coordinates row-aligned with F (internal row order)."""
+        """Coordinates row-aligned with F, like ME's (C[i] belongs to F[i]).  DEVIATION from MinkowskiEngine: for a tensor
+        built from (features, coordinates) both are in the manager's internal spatial (Morton) row order, not in the order of
+        the coordinates handed in -- ME keeps the input order of unique coordinates.  SelectionNet undoes the order at its
+        boundary (pooling ids in, per-voxel heads out: detection_net.py:347 of the reference relies on input order there);
+        code that uses this module as "ME" directly reads `features_in_input_order()` / `coordinates_in_input_order()`, or
+        sets `sparse.REORDER_DEFAULT = False` (rows then stay in input order; the kernels lose their L2 locality).
+        tests/test_gpu_net.py::test_sparse_tensor_row_order_contract pins all of this."""
         return self.manager.coords[self.level]
+
+    def coordinates_in_input_order(self):
+        """Level-0 coordinates in the row order of the coordinates the tensor was built from (ME's `.C`)."""
+        m = self.manager
+        if self.level == 0 and m is not None and m.inv_perm is not None:
+            return m.coords[0][m.inv_perm]
+        return m.coords[self.level]
 
     def features_in_input_order(self):
         """Level-0 features in the row order of the coordinates the tensor was built from."""

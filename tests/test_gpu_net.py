@@ -301,3 +301,26 @@ def test_training_trajectory_matches_oracle(monkeypatch):
     assert all(x > y for x, y in zip(dev, dev[1:])) and o64[-1] < o64[0]       # it trains, every step
     for a, c in zip(dev, o64):
         assert abs(a - c) <= 0.015 * abs(c), (dev, o32, o64)
+
+
+@pytest.mark.gpu
+def test_sparse_tensor_row_order_contract(monkeypatch):
+    """ME.SparseTensor(features, coordinates): `.F` and `.C` are row-aligned with each other (ME's contract) but, unlike
+    ME's, in the internal Morton order; the input order is available through *_in_input_order(), and
+    sparse.REORDER_DEFAULT = False keeps input order throughout (documented deviation, sparse.SparseTensor.C)."""
+    from box2mask_amd import nn as ME, sparse
+    b = synth.make_batch(2, seed0=7, target_voxels=3000, pts_per_m2=6000.0)
+    coords, feats = b['vox_coords'], b['vox_features']
+    t = ME.SparseTensor(feats, coords)
+    assert t.manager.perm is not None
+    # (C[i], F[i]) pairs are the input's pairs, in another order
+    key = lambda c: (c[:, 0].long() << 48) | (c[:, 1].long() << 32) | (c[:, 2].long() << 16) | c[:, 3].long()
+    order_in = torch.argsort(key(coords)); order_t = torch.argsort(key(t.C.cpu()))
+    assert torch.equal(key(coords)[order_in], key(t.C.cpu())[order_t])
+    assert torch.equal(feats[order_in], t.F.cpu()[order_t])
+    assert not torch.equal(t.C.cpu().int(), coords.int())                      # the deviation: not the input order
+    assert torch.equal(t.coordinates_in_input_order().cpu().int(), coords.int())
+    assert torch.equal(t.features_in_input_order().cpu(), feats)
+    monkeypatch.setattr(sparse, 'REORDER_DEFAULT', False)
+    u = ME.SparseTensor(feats, coords)
+    assert u.manager.perm is None and torch.equal(u.C.cpu().int(), coords.int()) and torch.equal(u.F.cpu(), feats)

@@ -140,6 +140,73 @@ def test_large_n_global_sort_path():
     assert len(reps2) == len(reps)
 
 
+@pytest.mark.parametrize('case', ['a', 'b'])
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_detection2mask_without_segment_pooling_golden(golden_dir, case, mode):
+    """cfg.do_segment_pooling = False (detection_net.py:436-445): per-voxel votes, no seg2vox projection; against the real
+    reference on per-voxel predictions that are foreground everywhere (the inputs its branch can execute on), bit for bit."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.detection_net import SelectionNet
+    d = np.load(os.path.join(golden_dir, 'detection2mask_nopool.npz'))
+    cfg = scannet_config()
+    cfg.do_segment_pooling = False
+    valid, _, _, is_fg = synth.scannet_tables()
+    net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6])
+    names = [str(s) for s in d['np_%s_names' % case]]
+    batch = {'input_location': torch.from_numpy(d['np_%s_input_location' % case]),
+             'batch_ids': torch.from_numpy(d['np_%s_batch_ids' % case]),
+             'scene': [{'name': n} for n in names],
+             'vox2point': [d['np_%s_vox2point%d' % (case, i)] for i in range(len(names))]}      # (no 'seg2vox': it is not read)
+    pred = {h: torch.from_numpy(d['np_%s_pred_%s' % (case, h)]) for h in
+            ('mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics')}
+    res = net.detection2mask(batch, pred, cfg, mode, True, *d['np_%s_ths' % case].tolist())
+    total = 0
+    for si, n in enumerate(names):
+        pre = 'np_%s_%s_s%d_' % (case, mode, si)
+        r = res[n]
+        assert np.array_equal(r['conf'].numpy().view(np.uint32), d[pre + 'conf'].view(np.uint32))
+        assert r['label_id'].dtype == np.int32 and np.array_equal(r['label_id'], d[pre + 'label_id'])
+        assert r['mask'].dtype == torch.bool and tuple(r['mask'].shape) == tuple(d[pre + 'mask_shape'])
+        assert np.array_equal(np.packbits(r['mask'].numpy(), axis=1), d[pre + 'mask'])
+        if mode != 'eval':
+            assert np.array_equal(r['cluster_representatives'].numpy(), d[pre + 'reps'])
+        total += len(r['conf'])
+    assert total > 50
+
+
+def test_detection2mask_without_segment_pooling_pads_background_votes():
+    """Background voxels among per-voxel votes (where the reference's branch stops with a shape mismatch): the result equals
+    the pooled flow with one segment per voxel (seg2vox = identity), which zero-pads the background votes."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.detection_net import SelectionNet
+    valid, _, _, is_fg = synth.scannet_tables()
+    rng = np.random.default_rng(3)
+    n = 3000
+    loc = rng.uniform(0, 3, (n, 3)).astype(np.float32)
+    centres = rng.uniform(0.5, 2.5, (12, 3)).astype(np.float32)
+    obj = rng.integers(0, 12, n)
+    pred = {'mlp_offsets': torch.from_numpy(centres[obj] - loc + rng.normal(0, 0.02, (n, 3)).astype(np.float32)),
+            'mlp_bounds': torch.from_numpy((0.3 + rng.normal(0, 0.02, (n, 3))).astype(np.float32)),
+            'mlp_bb_scores': torch.from_numpy(rng.normal(0.5, 2, (n, 1)).astype(np.float32)),
+            'mlp_semantics': torch.from_numpy(rng.normal(0, 3, (n, len(valid))).astype(np.float32))}     # mixed fore- / background
+    base = {'input_location': torch.from_numpy(loc), 'batch_ids': torch.zeros(n, dtype=torch.long), 'scene': [{'name': 's'}],
+            'vox2point': [rng.integers(0, n, 7000)]}
+    out = []
+    for pooling in (False, True):
+        cfg = scannet_config()
+        cfg.do_segment_pooling = pooling
+        net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6])
+        batch = dict(base)
+        if pooling:
+            batch['seg2vox'] = [np.arange(n)]
+        out.append(net.detection2mask(batch, pred, cfg, 'eval', True, 0.5, 0.05, 0.3, 0.6)['s'])
+    a, b = out
+    assert len(a['conf']) > 3
+    assert torch.equal(a['conf'], b['conf']) and np.array_equal(a['label_id'], b['label_id']) and torch.equal(a['mask'], b['mask'])
+
+
 @pytest.mark.parametrize('mode', ['eval', 'train'])
 def test_detection2mask_s3dis_flow_golden(golden_dir, mode):
     """Per-voxel semantics head (S3DIS config): segment majority vote, no mask NMS (detection_net.py:398-415,449)."""

@@ -1,0 +1,50 @@
+"""Compiler-dependent properties of the hot kernels, pinned on the device assembly hipcc emits for csrc/conv.hip (no GPU
+needed: hipcc cross-compiles gfx950).  The pipelines of conv_fwd_flow_kernel / conv_wgrad_flow_kernel / conv_stem_kernel
+depend on things a toolchain bump can silently undo -- registers under the occupancy steps (168 / 128 / 88), no scratch, and
+counted `s_waitcnt vmcnt(N)` waits inside the MFMA loops (a vmcnt(0) there drains the software pipeline: the round-2 and
+round-3 builds had one at every kernel-offset advance, found in round 4 with tools/isa_check.py).  A regression fails HERE,
+in the CPU suite and in build(), instead of showing up as 20 % in the benchmark."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+
+@pytest.fixture(scope='module')
+def kernels():
+    import isa_check
+    if not os.path.exists(isa_check.HIPCC):
+        pytest.skip('hipcc not available')
+    return isa_check.kernels(isa_check.device_asm())
+
+
+# mangled name -> (max VGPRs, waves per SIMD, needs counted waits in the MFMA loop)
+PINNED = {
+    '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1EEv8ConvArgs': (168, 3, True),       # forward / data gradient, 48-column strips
+    '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1EEv8ConvArgs': (128, 4, True),       # 32-column strips
+    '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi4EEv8ConvArgs': (168, 3, True),       # split maps (4 slices per workgroup)
+    '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi4EEv8ConvArgs': (128, 4, True),
+    '_Z22conv_wgrad_flow_kernelILi3ELi3ELi0EEv9WgradArgs': (88, 5, True),         # weight gradient, 48 x 48 blocks
+    '_Z22conv_wgrad_flow_kernelILi4ELi4ELi0EEv9WgradArgs': (128, 4, True),        # 64 x 64 blocks
+    '_Z22conv_wgrad_flow_kernelILi2ELi2ELi0EEv9WgradArgs': (64, 8, True),
+    '_Z16conv_stem_kernelILb0EEv8ConvArgs': (128, 4, True),                       # the 5x5x5 first layer
+    '_Z15conv_1x1_kernelILi3EEv8ConvArgs': (176, 2, False),                        # 1x1 streaming GEMM (compiler-scheduled waits)
+    '_Z15conv_1x1_kernelILi2EEv8ConvArgs': (168, 3, False),
+}
+
+
+@pytest.mark.parametrize('name', sorted(PINNED))
+def test_hot_kernel_resources(kernels, name):
+    assert name in kernels, 'kernel not found in the device assembly (renamed / template arguments changed?): %s' % name
+    k = kernels[name]
+    max_vgpr, occ, counted = PINNED[name]
+    assert k['vgpr'] <= max_vgpr, (name, k)
+    assert k.get('scratch', 0) == 0, 'register spills to scratch in %s: %s' % (name, k)
+    assert k['occupancy'] >= occ, (name, k)
+    assert k['mfma'] > 0
+    if counted:
+        assert k['loop_waits'], name
+        assert 0 not in k['loop_waits'], 's_waitcnt vmcnt(0) inside the MFMA loop of %s: %s' % (name, k['loop_waits'])

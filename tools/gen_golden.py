@@ -211,6 +211,69 @@ def gen_detection2mask():
     print('detection2mask.npz: %d arrays' % len(out))
 
 
+def gen_detection2mask_nopool():
+    """SelectionNet.detection2mask with cfg.do_segment_pooling = False (detection_net.py:436-445: the heat-maps are NOT
+    projected through seg2vox, the predictions already live on the voxels).  The reference's branch only executes when every
+    voxel of a scene is predicted foreground: it indexes the per-voxel semantics and vox2point with masks that have one
+    column per FOREGROUND vote (:463, :470) -- any background voxel is a shape mismatch.  The fixture therefore predicts a
+    furniture class everywhere; box2mask_amd pads background votes with zeros as the pooled branch does."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import models.detection_net as dn
+    valid, id2idx, _, is_fg = synth.scannet_tables()
+    cfg = SimpleNamespace(mlp_per_vox_semantics='mlp_per_vox_semantics', mlp_semantics='mlp_semantics',
+                          network_heads=['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics'],
+                          do_segment_pooling=False)
+    ns = SimpleNamespace(requires_voxel_outputs=False, semantic_valid_class_ids=valid, is_foreground=is_fg)
+    out = {}
+    for case, seed in (('a', 41), ('b', 47)):
+        batch, _ = _scene_inputs(seed, n_scenes=2, target_voxels=2500)
+        rng = np.random.default_rng(seed)
+        coords = batch['vox_coords'].numpy()
+        n_vox = coords.shape[0]
+        seg_of_vox = batch['pooling_ids'].numpy()                      # segment row of every voxel (batch-wide)
+        loc = (coords[:, 1:].astype(np.float32) * np.float32(0.02))   # vox_world_coords (dataloader.py:98-105)
+        seg_loc = batch['input_location'].numpy()[seg_of_vox]
+        # every voxel votes for its segment's box (furniture segments) or for a small box of its own
+        off = batch['gt_bb_offsets'].numpy()[seg_of_vox] + (seg_loc - loc) + rng.normal(0, 0.03, (n_vox, 3)).astype(np.float32)
+        bnd = np.maximum(batch['gt_bb_bounds'].numpy()[seg_of_vox] + rng.normal(0, 0.03, (n_vox, 3)).astype(np.float32), 0.04)
+        bg_vox = ~batch['fg_instances'].numpy()[seg_of_vox]           # floor / wall segments: one 1 m box around the segment
+        bnd[bg_vox] = (0.5 + rng.normal(0, 0.02, (int(bg_vox.sum()), 3))).astype(np.float32)
+        logits = rng.normal(0.5, 2.0, (n_vox, 1)).astype(np.float32)
+        fg_classes = np.nonzero(is_fg(torch.from_numpy(valid.numpy() if hasattr(valid, 'numpy') else np.asarray(valid)).long()).numpy())[0]
+        sem_logits = rng.normal(0, 1, (n_vox, len(valid))).astype(np.float32)
+        pick = fg_classes[(seg_of_vox * 7) % len(fg_classes)]        # one furniture class per segment: every voxel foreground
+        sem_logits[np.arange(n_vox), pick] += 12.0
+        flip = rng.random(n_vox) < 0.1                                 # some voxels of another (furniture) class
+        sem_logits[flip, fg_classes[rng.integers(0, len(fg_classes), int(flip.sum()))]] += 20.0
+        pred = {'mlp_offsets': torch.from_numpy(off.astype(np.float32)), 'mlp_bounds': torch.from_numpy(bnd.astype(np.float32)),
+                'mlp_bb_scores': torch.from_numpy(logits), 'mlp_semantics': torch.from_numpy(sem_logits)}
+        vbatch = {'input_location': torch.from_numpy(loc), 'batch_ids': torch.from_numpy(coords[:, 0].astype(np.int64)),
+                  'scene': batch['scene'], 'vox2point': batch['vox2point']}
+        ths = [0.5, 0.05, 0.3, 0.6]
+        for mode in ('eval', 'train'):
+            res = dn.SelectionNet.detection2mask(ns, vbatch, {k: v.clone() for k, v in pred.items()}, cfg, mode, True, *ths)
+            for si, sc in enumerate(batch['scene']):
+                r = res[sc['name']]
+                pre = 'np_%s_%s_s%d_' % (case, mode, si)
+                out[pre + 'conf'] = r['conf'].numpy()
+                out[pre + 'label_id'] = np.asarray(r['label_id'])
+                out[pre + 'mask'] = np.packbits(r['mask'].numpy(), axis=1)
+                out[pre + 'mask_shape'] = np.asarray(r['mask'].shape)
+                if mode != 'eval':
+                    out[pre + 'reps'] = r['cluster_representatives'].numpy()
+        for k, v in pred.items():
+            out['np_%s_pred_%s' % (case, k)] = v.numpy()
+        out['np_%s_input_location' % case] = loc
+        out['np_%s_batch_ids' % case] = coords[:, 0].astype(np.int64)
+        for si in range(len(batch['scene'])):
+            out['np_%s_vox2point%d' % (case, si)] = np.asarray(batch['vox2point'][si])
+        out['np_%s_names' % case] = np.asarray([s['name'] for s in batch['scene']])
+        out['np_%s_ths' % case] = np.asarray(ths)
+    np.savez_compressed(os.path.join(OUT, 'detection2mask_nopool.npz'), **out)
+    print('detection2mask_nopool.npz: %d arrays, %s instances' % (len(out), [int(out[k][0]) for k in out if k.endswith('eval_s0_mask_shape')]))
+
+
 def gen_losses():
     Holder = _install_stubs()
     sys.path.insert(0, REF)
@@ -562,11 +625,13 @@ def gen_eval():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ['iou_nms', 'detection2mask', 'losses', 'prepare', 'prepare2', 'eval']
+    which = sys.argv[1:] or ['iou_nms', 'detection2mask', 'detection2mask_nopool', 'losses', 'prepare', 'prepare2', 'eval']
     if 'iou_nms' in which:
         gen_iou_nms()
     if 'detection2mask' in which:
         gen_detection2mask()
+    if 'detection2mask_nopool' in which:
+        gen_detection2mask_nopool()
     if 'losses' in which:
         gen_losses()
     if 'prepare' in which:
