@@ -79,6 +79,34 @@ extern "C" int b2m_debug_stamps(unsigned long long* out8, int reset) {   // out8
 #else
 #define B2M_STAMP(v) do { } while (0)
 #endif
+// Diagnostic build only (-DB2M_CLOCKS, tools/clocks.py): the shader clock a kernel's waves see -- delta s_memtime (shader
+// cycles) over delta s_memrealtime (100 MHz) from the first to the last instruction of every wave, summed per kernel.
+// Two stamps per wave: the timing of the kernel is not disturbed.  [0..2] forward / data gradient, [3..5] weight gradient:
+// cycles, 10 ns ticks, waves.
+#ifdef B2M_CLOCKS
+__device__ unsigned long long g_clocks[8];
+extern "C" int b2m_debug_clocks(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_clocks), sizeof(g_clocks)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_clocks), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define B2M_CLOCK_BEGIN() const unsigned long long ck_c0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime()
+#define B2M_CLOCK_END(slot)                                                                                             \
+    do {                                                                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                     \
+        const unsigned long long ck_c1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();        \
+        if ((threadIdx.x & 63) == 0) {                                                                                  \
+            atomicAdd(&g_clocks[slot], ck_c1 - ck_c0); atomicAdd(&g_clocks[slot + 1], ck_r1 - ck_r0);                   \
+            atomicAdd(&g_clocks[slot + 2], 1ull);                                                                       \
+        }                                                                                                               \
+    } while (0)
+#else
+#define B2M_CLOCK_BEGIN() do { } while (0)
+#define B2M_CLOCK_END(slot) do { } while (0)
+#endif
 
 // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  Consecutive
 // tiles are neighbours in space (Morton row order) and gather largely the same input rows, so an XCD should work on
@@ -1317,6 +1345,7 @@ __global__ __launch_bounds__(256, (EXP & 1) ? 6 : 1) void conv_wgrad_flow_kernel
     int k, blk;
     int64_t chunk, t0, t1;
     if (!wgrad_item(a, wave, k, blk, chunk, t0, t1)) return;
+    B2M_CLOCK_BEGIN();
     const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int nt = (int)(t1 - t0);                       // <= 64 tiles: lane t holds the pair count of tile t0 + t
@@ -1448,6 +1477,7 @@ __global__ __launch_bounds__(256, (EXP & 1) ? 6 : 1) void conv_wgrad_flow_kernel
                     if (v != 0.f) atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)ci * a.lddw + co], v);
                 }
             }
+    B2M_CLOCK_END(3);
 }
 
 // Weight gradient of an identity map (1x1 layer) with FEW output channels -- the last layer of every head (96 -> 3 / 1 /

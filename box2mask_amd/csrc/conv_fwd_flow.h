@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     int64_t tile = item / a.nstrips;
     const int strip = (int)(item % a.nstrips);
     if (tile >= a.ntiles) return;             // the whole workgroup leaves (its waves share the item)
+    B2M_CLOCK_BEGIN();
     if (a.tile_order) tile = a.tile_order[tile];
     const int col0 = strip * SW;
     float* Cs = smem + wave * STRIP;
@@ -363,5 +364,6 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             for (int u = 0; u < 4; ++u) if (col + u < a.cout) dst[u] = v[u];
         }
     }
+    B2M_CLOCK_END(0);
 }
 #undef tile_column_sums

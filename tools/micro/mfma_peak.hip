@@ -35,6 +35,6 @@ void run(int blocks_per_cu, int iters) {
     hipFree(out);
 }
 int main() {
-    for (int w = 1; w <= 4; ++w) { run<2>(w, 20000); run<4>(w, 10000); run<12>(w, 4000); }
+    for (int w = 1; w <= 4; ++w) { run<2>(w, 20000); run<3>(w, 14000); run<4>(w, 10000); run<6>(w, 7000); run<12>(w, 4000); }
     return 0;
 }
