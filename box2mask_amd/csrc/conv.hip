@@ -1042,9 +1042,23 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
 #define B2M_FLOW2_LAUNCH(DV, TWV)                                                                            \
     do { if (NT == 2) B2M_FLOW2_LAUNCH_NT(DV, TWV, 2); else B2M_FLOW2_LAUNCH_NT(DV, TWV, 1); } while (0)
                 const int exp_ = env_flag("B2M_CONV_EXP", 0);
-                if (exp_ == 1 && depth == 2 && NT == 1 && !pers) {
-                    if (TW == 3) conv_flow2_kernel<2, 3, 1, 0, 1><<<(unsigned)g2, 64, 0, st>>>(a);
-                    else conv_flow2_kernel<2, 2, 1, 0, 1><<<(unsigned)g2, 64, 0, st>>>(a);
+                const int wpg = env_flag("B2M_CONV_WPG", 1);
+                if (wpg > 1 && depth == 2 && NT == 1 && !pers && (a.nstrips % 2) == 0) {
+                    const unsigned gw = (unsigned)(8 * cdiv64(per_run, wpg == 4 && a.nstrips % 4 == 0 ? 4 : 2));
+                    if (wpg == 4 && a.nstrips % 4 == 0) {
+                        if (TW == 3) conv_flow2_kernel<2, 3, 1, 0, 0, 4><<<gw, 256, 0, st>>>(a);
+                        else conv_flow2_kernel<2, 2, 1, 0, 0, 4><<<gw, 256, 0, st>>>(a);
+                    } else {
+                        if (TW == 3) conv_flow2_kernel<2, 3, 1, 0, 0, 2><<<gw, 128, 0, st>>>(a);
+                        else conv_flow2_kernel<2, 2, 1, 0, 0, 2><<<gw, 128, 0, st>>>(a);
+                    }
+                } else
+                if (exp_ >= 1 && exp_ <= 4 && depth == 2 && NT == 1 && !pers) {
+#define B2M_EXP_LAUNCH(E) do { if (TW == 3) conv_flow2_kernel<2, 3, 1, 0, E><<<(unsigned)g2, 64, 0, st>>>(a);                  \
+                               else conv_flow2_kernel<2, 2, 1, 0, E><<<(unsigned)g2, 64, 0, st>>>(a); } while (0)
+                    if (exp_ == 1) B2M_EXP_LAUNCH(1); else if (exp_ == 2) B2M_EXP_LAUNCH(2); else if (exp_ == 4) B2M_EXP_LAUNCH(4);
+                    else B2M_EXP_LAUNCH(6);
+#undef B2M_EXP_LAUNCH
                 } else
                 if (depth == 2) { if (TW == 3) B2M_FLOW2_LAUNCH(2, 3); else B2M_FLOW2_LAUNCH(2, 2); }
                 else { if (TW == 3) B2M_FLOW2_LAUNCH(3, 3); else B2M_FLOW2_LAUNCH(3, 2); }

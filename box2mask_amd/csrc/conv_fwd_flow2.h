@@ -19,8 +19,8 @@
 //    (a ninth counter) zeroes them for the next launch on the same stream (one counter block per stream, conv.hip).
 #pragma once
 
-template <int D, int TW, int NT, int PERS, int EXP = 0>
-__global__ __launch_bounds__(64, NT == 2 ? 2 : ((TW == 2 && D == 2) ? 4 : 3)) void conv_flow2_kernel(ConvArgs a) {
+template <int D, int TW, int NT, int PERS, int EXP = 0, int WPG = 1>
+__global__ __launch_bounds__(64 * WPG, NT == 2 ? 2 : ((TW == 2 && D == 2) ? 4 : 3)) void conv_flow2_kernel(ConvArgs a) {
     constexpr int KS = 4;                     // k-steps per 16-channel chunk == floats per lane per gathered row
     constexpr int SW = 16 * TW;               // output channels per strip
     constexpr int LW = 64 * TW * KS;          // floats per packed weight block
@@ -28,8 +28,12 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : ((TW == 2 && D == 2) ? 4 : 3)) vo
     constexpr int ROWS = B2M_TILE * NT;       // output rows per item
     constexpr int NGT = NG * NT;              // row groups per offset, at most
     constexpr uint32_t PADWORD = (uint32_t)ROWS << 24;     // pair slot without a pair: gathers row 0, flushes nowhere
-    __shared__ float Cs[ROWS * PITCH];
-    const int lane = threadIdx.x;
+    // WPG > 1 (plain grid only): the WPG waves of a workgroup are WPG consecutive items -- the strips of ONE tile -- so that
+    // they run on one CU and their gathers of the same rows meet in its L1
+    __shared__ float CsAll[WPG * ROWS * PITCH];
+    const int wave = WPG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const Cs = CsAll + wave * (ROWS * PITCH);
+    const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
     const int nch1 = a.c1 >> 4, NC = (a.c1 + a.c2) >> 4;      // chunks of the first source / in all; NC % D == 0
     const int64_t ldr = a.ntiles * B2M_TILE;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : ((TW == 2 && D == 2) ? 4 : 3)) vo
     int run = blockIdx.x & 7, tries = 0, s0, s1;
     run_bounds(run, s0, s1);
     int nit = ((s1 - s0 + NT - 1) / NT) * nstrips;
-    int j = PERS ? draw(run, nit, 0) : (int)(blockIdx.x >> 3);
+    int j = PERS ? draw(run, nit, 0) : (int)(blockIdx.x >> 3) * WPG + wave;
 
     const uint32_t wlo = (uint32_t)lane * 16u;         // packed block layout [u][lane][4 floats]: pack_pos()
     const uint32_t q16 = (uint32_t)q * 16u;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : ((TW == 2 && D == 2) ? 4 : 3)) vo
             };
             auto gather = [&](int jb, int g, const char* src, uint32_t ld4, uint32_t word) {
                 const uint32_t off = __umul24(word & 0xFFFFFFu, ld4) + q16;
-                const f32x4 v = *(const f32x4*)(src + off);
+                const f32x4 v = (EXP & 4) ? __builtin_nontemporal_load((const f32x4*)(src + off)) : *(const f32x4*)(src + off);
                 av[jb][g][0] = v[0]; av[jb][g][1] = v[1]; av[jb][g][2] = v[2]; av[jb][g][3] = v[3];
             };
             auto weights = [&](int jb, int k, int c) {
@@ -190,7 +194,8 @@ __global__ __launch_bounds__(64, NT == 2 ? 2 : ((TW == 2 && D == 2) ? 4 : 3)) vo
                 float wv[TW * KS];
 #pragma unroll
                 for (int u = 0; u < TW; ++u) {
-                    const f32x4 w4 = *(const f32x4*)(wsrc + (wlo + 1024u * u));
+                    const f32x4 w4 = (EXP & 2) ? __builtin_nontemporal_load((const f32x4*)(wsrc + (wlo + 1024u * u)))
+                                               : *(const f32x4*)(wsrc + (wlo + 1024u * u));
                     wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
                 }
 #pragma unroll
