@@ -35,7 +35,6 @@ struct ConvArgs {
     const int32_t* tile_order; //          tile worked on at position j of that order (heavy tiles of a run's end first)
     double* stats;   // != NULL: per-tile column sums of the finished output, [tile][2][cout] (sum, sum of squares): the
                      // BatchNorm statistics of the following layer without another pass over Y (conv_fwd_flow_kernel only)
-    unsigned* tickets;   // conv_flow2_kernel<.., PERS = 1>: work counters of the 8 XCD runs + exit counter (ticket_block())
     // Inference epilogue (b2m_conv_fwd_affine): the strip is written as  [relu]( fmaf(Y, ep_scale[col], ep_shift[col]) [+ ep_res] )
     // -- the eval-mode BatchNorm (+ residual) (+ ReLU) that follows every trunk convolution, in exactly b2m_bn_apply's
     // arithmetic, without its launch and without the round trip of Y through HBM.  16-byte column groups only.
@@ -649,39 +648,7 @@ __global__ __launch_bounds__(256, 4) void conv_stem_kernel(ConvArgs a) {
 }
 
 #include "conv_fwd_flow.h"
-#include "conv_fwd_flow2.h"
 #include "conv_1x1.h"
-
-// ---- ticket counters of the persistent kernels: one block of 16 words per (device, stream) that launches them.  Launches on
-// one stream run in order and the last wave of a launch leaves the block zeroed, so a block never needs a memset; kernels
-// on different streams may overlap and get different blocks.  (The backward pass runs on autograd's thread: mutex.)
-#include <mutex>
-#define B2M_TICKET_SLOTS 32
-__device__ unsigned g_tickets[B2M_TICKET_SLOTS][16];
-static unsigned* ticket_block(hipStream_t st) {
-    static std::mutex mu;
-    static struct { int dev; hipStream_t st; } slot[B2M_TICKET_SLOTS];
-    static int nslot = 0;
-    static unsigned* base[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
-    for (int i = 0; i < nslot; ++i)
-        if (slot[i].dev == dev && slot[i].st == st) return base[dev] + 16 * i;
-    if (nslot == B2M_TICKET_SLOTS) return nullptr;          // (more streams than blocks: the caller launches the plain grid)
-    slot[nslot].dev = dev; slot[nslot].st = st;
-    return base[dev] + 16 * nslot++;
-}
-static int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        else cus = 256;
-    }
-    return cus;
-}
 
 static int env_flag(const char* name, int dflt);
 static inline int conv_kc(int cin) { return cin >= 16 ? 16 : 8; }
@@ -906,7 +873,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
     a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
-    a.stats = nullptr; a.tickets = nullptr;
+    a.stats = nullptr;
     a.ep_scale = a.ep_shift = a.ep_res = nullptr; a.ld_res = 0; a.ep_relu = 0;
     a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr;
     const int TW = conv_tw(cout, K);
@@ -1012,61 +979,6 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 fo.grid = (unsigned)(8 * B2M_XCD_CAP(a.ntiles) * a.wg_per_tile);
             }
             const int dbg = env_flag("B2M_PIPE_DBG", 0);      // diagnostic builds, wrong results: tools/pipe_breakdown.py
-            // un-split maps: conv_flow2_kernel (conv_fwd_flow2.h) -- B2M_CONV_FLOW2 = tiles per item (0: the round-2 kernel),
-            // B2M_CONV_PERS = persistent grid
-            const int f2 = env_flag("B2M_CONV_FLOW2", 0);      // (measured slower than the round-2 kernel in every form: profiles/r04_analysis.md)
-            if (wpb == 1 && !dbg && f2 >= 1 && K <= 64 && a.ntiles < (1ll << 24) && !a.ep_scale) {
-                const int NT = f2 >= 2 ? 2 : 1;
-                const int64_t run_max = a.xcd_start ? B2M_XCD_CAP(a.ntiles) : cdiv64(a.ntiles, 8);
-                const int64_t per_run = cdiv64(run_max, NT) * a.nstrips;            // items of the longest run
-                int64_t g2 = 8 * per_run;
-                int pers = env_flag("B2M_CONV_PERS", 0);
-                if (pers) {
-                    a.tickets = ticket_block(st);
-                    if (!a.tickets) pers = 0;
-                }
-                if (pers) {
-                    // one wave per wave slot the kernel's LDS strip and registers allow (NT = 2: 6 / 8 per CU, NT = 1: 12 / 16)
-                    const int per_cu = env_flag("B2M_CONV_PERS_WAVES", NT == 2 ? (TW == 3 ? 6 : 8) : (TW == 3 ? 12 : (depth == 2 ? 16 : 12)));
-                    const int64_t slots = (int64_t)per_cu * device_cus();
-                    const int64_t total = cdiv64(a.ntiles, NT) * a.nstrips + 8;
-                    g2 = slots < total ? slots : (total + 7) / 8 * 8;
-                }
-                B2M_CHECK_ARG(g2 < (1ll << 31), "too many workgroups");
-#define B2M_FLOW2_LAUNCH_NT(DV, TWV, NTV)                                                                    \
-    do {                                                                                                     \
-        if (pers >= 2) conv_flow2_kernel<DV, TWV, NTV, 4><<<(unsigned)g2, 64, 0, st>>>(a);                   \
-        else if (pers == 1) conv_flow2_kernel<DV, TWV, NTV, 1><<<(unsigned)g2, 64, 0, st>>>(a);              \
-        else conv_flow2_kernel<DV, TWV, NTV, 0><<<(unsigned)g2, 64, 0, st>>>(a);                             \
-    } while (0)
-#define B2M_FLOW2_LAUNCH(DV, TWV)                                                                            \
-    do { if (NT == 2) B2M_FLOW2_LAUNCH_NT(DV, TWV, 2); else B2M_FLOW2_LAUNCH_NT(DV, TWV, 1); } while (0)
-                const int exp_ = env_flag("B2M_CONV_EXP", 0);
-                const int wpg = env_flag("B2M_CONV_WPG", 1);
-                if (wpg > 1 && depth == 2 && NT == 1 && !pers && (a.nstrips % 2) == 0) {
-                    const unsigned gw = (unsigned)(8 * cdiv64(per_run, wpg == 4 && a.nstrips % 4 == 0 ? 4 : 2));
-                    if (wpg == 4 && a.nstrips % 4 == 0) {
-                        if (TW == 3) conv_flow2_kernel<2, 3, 1, 0, 0, 4><<<gw, 256, 0, st>>>(a);
-                        else conv_flow2_kernel<2, 2, 1, 0, 0, 4><<<gw, 256, 0, st>>>(a);
-                    } else {
-                        if (TW == 3) conv_flow2_kernel<2, 3, 1, 0, 0, 2><<<gw, 128, 0, st>>>(a);
-                        else conv_flow2_kernel<2, 2, 1, 0, 0, 2><<<gw, 128, 0, st>>>(a);
-                    }
-                } else
-                if (exp_ >= 1 && exp_ <= 4 && depth == 2 && NT == 1 && !pers) {
-#define B2M_EXP_LAUNCH(E) do { if (TW == 3) conv_flow2_kernel<2, 3, 1, 0, E><<<(unsigned)g2, 64, 0, st>>>(a);                  \
-                               else conv_flow2_kernel<2, 2, 1, 0, E><<<(unsigned)g2, 64, 0, st>>>(a); } while (0)
-                    if (exp_ == 1) B2M_EXP_LAUNCH(1); else if (exp_ == 2) B2M_EXP_LAUNCH(2); else if (exp_ == 4) B2M_EXP_LAUNCH(4);
-                    else B2M_EXP_LAUNCH(6);
-#undef B2M_EXP_LAUNCH
-                } else
-                if (depth == 2) { if (TW == 3) B2M_FLOW2_LAUNCH(2, 3); else B2M_FLOW2_LAUNCH(2, 2); }
-                else { if (TW == 3) B2M_FLOW2_LAUNCH(3, 3); else B2M_FLOW2_LAUNCH(3, 2); }
-#undef B2M_FLOW2_LAUNCH_NT
-#undef B2M_FLOW2_LAUNCH
-                B2M_LAUNCH_CHECK();
-                return B2M_OK;
-            }
             if (wpb == 4) {
                 if (depth == 2) {
                     if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4><<<fo.grid, 256, 0, st>>>(a);
@@ -1351,8 +1263,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchun
 //    accumulators in AGPRs and copied all of them to VGPRs and back around every slot (108 moves per 36 MFMAs);
 //  * each slot issues the same number of loads (k-steps without pairs gather row 0: L1 hits), so the counted waits
 //    in front of the MFMAs are exact; the loads that refill a k-step's registers follow its MFMAs directly.
-template <int MI, int NJ, int EXP = 0>
-__global__ __launch_bounds__(256, (EXP & 1) ? 6 : 1) void conv_wgrad_flow_kernel(WgradArgs a) {
+template <int MI, int NJ>
+__global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
@@ -1449,7 +1361,6 @@ __global__ __launch_bounds__(256, (EXP & 1) ? 6 : 1) void conv_wgrad_flow_kernel
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < nkC) {                                       // wave-uniform
-                if constexpr (EXP & 2) __builtin_amdgcn_s_setprio(1);
                 float bz[NJ];
 #pragma unroll
                 for (int nn = 0; nn < NJ; ++nn) bz[nn] = (int)wC[s] >= 0 ? bv[s][nn] : 0.f;      // no pair: contributes 0
@@ -1458,7 +1369,6 @@ __global__ __launch_bounds__(256, (EXP & 1) ? 6 : 1) void conv_wgrad_flow_kernel
 #pragma unroll
                     for (int nn = 0; nn < NJ; ++nn)
                         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(av[s][m]), "v"(bz[nn]));
-                if constexpr (EXP & 2) __builtin_amdgcn_s_setprio(0);
             }
             asm volatile("" ::: "memory");                       // the refill stays behind the MFMAs that read the registers
             gather(s, tiN, wN[s]);
@@ -1575,13 +1485,6 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restri
 template <int MI>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
     if (a.pipe) {
-        const int exp_ = env_flag("B2M_WGRAD_EXP", 0);
-        if (exp_ && MI == 3 && NJ == 3) {
-            if (exp_ == 1) conv_wgrad_flow_kernel<3, 3, 1><<<grid, 256, 0, st>>>(a);
-            else if (exp_ == 2) conv_wgrad_flow_kernel<3, 3, 2><<<grid, 256, 0, st>>>(a);
-            else conv_wgrad_flow_kernel<3, 3, 3><<<grid, 256, 0, st>>>(a);
-            return;
-        }
         switch (NJ) {
             case 1: conv_wgrad_flow_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
             case 2: conv_wgrad_flow_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;

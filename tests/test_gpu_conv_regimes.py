@@ -39,11 +39,6 @@ def _close(a, b, what, tol=TOL):
 # ------------------------------------------------------------------ 1. forced dispatch regimes
 REGIMES = {
     'unsplit': {'B2M_CONV_TARGET': '0'},
-    'unsplit_two_tiles_persistent': {'B2M_CONV_TARGET': '0', 'B2M_CONV_FLOW2': '2', 'B2M_CONV_PERS': '4'},
-    'unsplit_two_tiles_plain_grid': {'B2M_CONV_TARGET': '0', 'B2M_CONV_FLOW2': '2'},
-    'unsplit_one_tile_persistent': {'B2M_CONV_TARGET': '0', 'B2M_CONV_FLOW2': '1', 'B2M_CONV_PERS': '1'},
-    'unsplit_one_tile_plain_grid': {'B2M_CONV_TARGET': '0', 'B2M_CONV_FLOW2': '1'},
-    'unsplit_persistent_one_wave_per_cu': {'B2M_CONV_TARGET': '0', 'B2M_CONV_FLOW2': '2', 'B2M_CONV_PERS': '4', 'B2M_CONV_PERS_WAVES': '1'},
     'unsplit_three_steps_in_flight': {'B2M_CONV_TARGET': '0', 'B2M_CONV_PIPE': '3'},
     'unsplit_32_column_strips': {'B2M_CONV_TARGET': '0', 'B2M_CONV_TW3': '0'},
     'atomic_combine': {'B2M_CONV_WGCOMBINE': '0'},

@@ -27,9 +27,9 @@ PINNED = {
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1EEv8ConvArgs': (128, 4, True),       # 32-column strips
     '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi4EEv8ConvArgs': (168, 3, True),       # split maps (4 slices per workgroup)
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi4EEv8ConvArgs': (128, 4, True),
-    '_Z22conv_wgrad_flow_kernelILi3ELi3ELi0EEv9WgradArgs': (88, 5, True),         # weight gradient, 48 x 48 blocks
-    '_Z22conv_wgrad_flow_kernelILi4ELi4ELi0EEv9WgradArgs': (128, 4, True),        # 64 x 64 blocks
-    '_Z22conv_wgrad_flow_kernelILi2ELi2ELi0EEv9WgradArgs': (64, 8, True),
+    '_Z22conv_wgrad_flow_kernelILi3ELi3EEv9WgradArgs': (88, 5, True),         # weight gradient, 48 x 48 blocks
+    '_Z22conv_wgrad_flow_kernelILi4ELi4EEv9WgradArgs': (128, 4, True),        # 64 x 64 blocks
+    '_Z22conv_wgrad_flow_kernelILi2ELi2EEv9WgradArgs': (64, 8, True),
     '_Z16conv_stem_kernelILb0EEv8ConvArgs': (128, 4, True),                       # the 5x5x5 first layer
     '_Z15conv_1x1_kernelILi3EEv8ConvArgs': (176, 2, False),                        # 1x1 streaming GEMM (compiler-scheduled waits)
     '_Z15conv_1x1_kernelILi2EEv8ConvArgs': (168, 3, False),

@@ -5,7 +5,7 @@
 
 per kernel: VGPRs, spills, LDS, waves per SIMD, MFMAs, and every `s_waitcnt vmcnt(N)` BETWEEN the first and the last MFMA
 of the kernel -- a vmcnt(0) there drains the software pipeline (the round-2 / round-3 kernels did, once per kernel
-offset: the pair-list wait of the offset advance; conv_fwd_flow2.h).  tests/test_isa.py pins these numbers."""
+offset: the pair-list wait of the offset advance; conv_fwd_flow.h).  tests/test_isa.py pins these numbers."""
 import os
 import re
 import subprocess
@@ -68,7 +68,7 @@ def _summarise(body):
 
 if __name__ == '__main__':
     ks = kernels(device_asm())
-    pats = sys.argv[1:] or ['conv_flow2_kernel', 'conv_fwd_flow_kernel', 'conv_wgrad_flow_kernel', 'conv_stem_kernel', 'conv_1x1']
+    pats = sys.argv[1:] or ['conv_fwd_flow_kernel', 'conv_wgrad_flow_kernel', 'conv_stem_kernel', 'conv_1x1']
     for n in sorted(ks):
         if any(p in n for p in pats):
             k = ks[n]

@@ -57,48 +57,5 @@ def run():
                  (life - tail - idx - loop - epi) / waves, ini / waves, cnt / waves))
 
 
-def run2():
-    """conv_flow2_kernel (conv_fwd_flow2.h): cycles per item by phase, own-MFMA share of a wave's life.
-    VARIANTS="name:ENV=val,ENV=val;..." as in tools/bench_conv.py."""
-    import torch
-    from box2mask_amd import _lib, synth, functional as F_
-    from box2mask_amd.sparse import CoordinateManager
-    lib = C.CDLL(os.environ['B2M_LIB_PATH'])
-    lib.b2m_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-    b = synth.make_batch(int(os.environ.get('BS', '8')), seed0=0)
-    m = CoordinateManager(b['vox_coords'], reorder=True)
-    rb0 = m.rulebook_same(0, 3); m.ensure_level(2); rb1 = m.rulebook_same(1, 3)
-    cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32), ('L1 k3 96->96', rb1, 27, 96, 0, 96),
-             ('L1 k3 128->128', rb1, 27, 128, 0, 128)]
-    variants = [('plain', {'B2M_CONV_FLOW2': '1', 'B2M_CONV_PERS': '0'})]
-    for spec in os.environ.get('VARIANTS', '').split(';'):
-        if spec:
-            name, kvs = spec.split(':')
-            variants.append((name, dict(kv.split('=') for kv in kvs.split(','))))
-    keys = set(k for _, e in variants for k in e)
-    for name, rb, K, c1, c2, co in cases:
-        n_out, n_in = rb.n_out, rb.n_in
-        x1 = torch.randn(n_in, c1, device='cuda')
-        w = torch.randn(K, c1 + c2, co, device='cuda') * 0.05
-        for vname, env in variants:
-            for k in keys: os.environ.pop(k, None)
-            os.environ.update(env)
-            _lib.reload_env()
-            wp = F_.weight_pack(w)
-            tw = 3 if (co % 48 == 0 and os.environ.get('B2M_CONV_TW3', '1') == '1') else 2
-            for it in range(2):
-                torch.cuda.synchronize(); lib.b2m_debug_stamps(None, 1)
-                s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
-                s.record(); F_.conv_raw(x1, None, wp, K, None, rb, n_out, co); e.record(); torch.cuda.synchronize()
-            v = (C.c_ulonglong * 12)(); lib.b2m_debug_stamps(v, 0)
-            pro, loop, flush, life, noff, items, epi, grp, adv, draw = [float(x) for x in v][:10]
-            own = grp * 4 * tw * 32
-            print('%-16s %-10s %.3f ms items %d | per item: life %.0f = prologue %.0f + loop %.0f + flush %.0f + advance %.0f + '
-                  'write-out %.0f (+ draw %.0f) | offsets/item %.1f groups/offset %.2f | own MFMA cycles %.0f = %.1f %% of life, '
-                  '%.1f %% of loop' % (name, vname, s.elapsed_time(e), items, life / items, pro / items, loop / items,
-                                       flush / items, adv / items, epi / items, draw / items, noff / items,
-                                       grp / max(noff, 1) / ((c1 + c2) / 16), own / items, 100 * own / life, 100 * own / loop))
-
-
 if __name__ == '__main__':
-    {'build': build, 'run2': run2}.get(sys.argv[1] if len(sys.argv) > 1 else '', run)()
+    build() if sys.argv[1:] == ['build'] else run()
