@@ -50,6 +50,9 @@ PROTOTYPES = {
     'b2m_bn_bwd_reduce2': [P, I64, P, I64, P, I64, P, I64, I64, I32, P, P, P, P, I32, P, P, P],
     'b2m_bn_bwd_apply2': [P, I64, P, I64, P, I64, P, I64, I64, I32, P, P, P, P, P, P, P, F64, P, I32, P, I64, P, I64, P, P, P, P, P, P],
     'b2m_bn_small_fwd': [P, I64, I64, I32, P, P, F32, F32, P, P, P, P, P, P, P, I64, I32, P, I64, P],
+    'b2m_bn_small_fwd_stats': [P, I64, I64, I32, P, P],
+    'b2m_bn_small_fwd_apply': [P, P, I64, I64, I32, P, P, F32, F32, P, P, P, P, P, P, P, I64, I32, P, I64, P],
+    'b2m_bn_small_bwd_phase': [I32, P, I64, P, I64, P, I64, I64, I32, P, P, P, I32, P, P, P, P, P, I64, P, I64, P, P, P],
     'b2m_bn_small_bwd': [P, I64, P, I64, P, I64, I64, I32, P, P, P, I32, P, P, P, P, P, I64, P, I64, P],
     'b2m_relu_fwd': [P, I64, P, P],
     'b2m_relu_bwd': [P, P, I64, P, P],

@@ -731,24 +731,36 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* sh /* [4][NV]
 #pragma unroll
     for (int u = 0; u < NV; ++u) v[u] = (sh[u] + sh[NV + u]) + (sh[2 * NV + u] + sh[3 * NV + u]);
 }
+// PHASE 0: the whole layer.  SyncBN (the statistics of all ranks meet between the two halves: b2m_bn_small_fwd_stats ->
+// all-reduce of xchg[2c + 1] -> b2m_bn_small_fwd_apply): PHASE 1 = pass 1 only, this rank's column sums and row count to
+// xchg; PHASE 2 = finalize from the all-reduced xchg + pass 2.
+template <int PHASE>
 __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_fwd_kernel(
         const float* __restrict__ x, int64_t ldx, int n, int c, const float* __restrict__ gamma, const float* __restrict__ beta,
         float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
         float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
-        const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ y, int64_t ldy) {
+        const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ y, int64_t ldy, double* __restrict__ xchg) {
     __shared__ double sh[4 * 8];
     __shared__ float sc[8];
     const int col = blockIdx.x * 4;
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = threadIdx.x; r < n; r += BN_SMALL_THREADS) {
-        const f32x4 v = *(const f32x4*)(x + (int64_t)r * ldx + col);
+    if constexpr (PHASE != 2) {
+        for (int r = threadIdx.x; r < n; r += BN_SMALL_THREADS) {
+            const f32x4 v = *(const f32x4*)(x + (int64_t)r * ldx + col);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const double d = (double)v[u]; s[u] += d; s[4 + u] = fma(d, d, s[4 + u]); }
+            for (int u = 0; u < 4; ++u) { const double d = (double)v[u]; s[u] += d; s[4 + u] = fma(d, d, s[4 + u]); }
+        }
+        block_sum<8>(s, sh);
     }
-    block_sum<8>(s, sh);
+    if constexpr (PHASE == 1) {
+        if (threadIdx.x < 4) { xchg[col + threadIdx.x] = s[threadIdx.x]; xchg[c + col + threadIdx.x] = s[4 + threadIdx.x]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) xchg[2 * c] = (double)n;
+        return;
+    }
     if (threadIdx.x < 4) {
         const int j = col + threadIdx.x, u = threadIdx.x;
-        const double count = (double)n;
+        double count = (double)n;
+        if constexpr (PHASE == 2) { s[u] = xchg[j]; s[4 + u] = xchg[c + j]; count = xchg[2 * c]; }
         const double m = s[u] / count;
         double var = s[4 + u] / count - m * m;
         if (var < 0) var = 0;
@@ -789,19 +801,43 @@ extern "C" int b2m_bn_small_fwd(const float* x, int64_t ldx, int64_t n, int32_t 
                   "c and leading dimensions must be multiples of 4");
     B2M_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)residual % 16) == 0, "16-byte alignment");
     B2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics: both or none");
-    bn_small_fwd_kernel<<<c / 4, BN_SMALL_THREADS, 0, (hipStream_t)stream>>>(x, ldx, (int)n, c, gamma, beta, eps, momentum,
-        running_mean, running_var, mean, invstd, scale, shift, residual, ldr, relu, y, ldy);
+    bn_small_fwd_kernel<0><<<c / 4, BN_SMALL_THREADS, 0, (hipStream_t)stream>>>(x, ldx, (int)n, c, gamma, beta, eps, momentum,
+        running_mean, running_var, mean, invstd, scale, shift, residual, ldr, relu, y, ldy, nullptr);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+extern "C" int b2m_bn_small_fwd_stats(const float* x, int64_t ldx, int64_t n, int32_t c, double* xchg, void* stream) {
+    B2M_CHECK_ARG(x && xchg && n >= 1 && n <= B2M_BN_SMALL_MAX_ROWS, "bad arguments / too many rows");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldx >= c && ((uintptr_t)x % 16) == 0, "c, ldx multiples of 4; 16-byte alignment");
+    bn_small_fwd_kernel<1><<<c / 4, BN_SMALL_THREADS, 0, (hipStream_t)stream>>>(x, ldx, (int)n, c, nullptr, nullptr, 0.f, 0.f, nullptr,
+        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, xchg);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+extern "C" int b2m_bn_small_fwd_apply(const double* xchg, const float* x, int64_t ldx, int64_t n, int32_t c, const float* gamma,
+                                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                      float* mean, float* invstd, float* scale, float* shift, const float* residual, int64_t ldr,
+                                      int32_t relu, float* y, int64_t ldy, void* stream) {
+    B2M_CHECK_ARG(xchg && x && y && mean && invstd && scale && shift && n >= 1 && n <= B2M_BN_SMALL_MAX_ROWS, "bad arguments / too many rows");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) && ldx >= c && ldy >= c,
+                  "c and leading dimensions must be multiples of 4");
+    B2M_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)residual % 16) == 0, "16-byte alignment");
+    B2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics: both or none");
+    bn_small_fwd_kernel<2><<<c / 4, BN_SMALL_THREADS, 0, (hipStream_t)stream>>>(x, ldx, (int)n, c, gamma, beta, eps, momentum,
+        running_mean, running_var, mean, invstd, scale, shift, residual, ldr, relu, y, ldy, (double*)xchg);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
 
-template <bool RELU, bool HASY>
+// PHASE as in bn_small_fwd_kernel: 1 = reduction only (this rank's sums to xchg[2c], dbeta / dgamma from them), 2 = apply from
+// the all-reduced xchg[2c] with the global row count *count_dev.
+template <bool RELU, bool HASY, int PHASE = 0>
 __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_bwd_kernel(
         const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy, const float* __restrict__ x,
         int64_t ldx, int n, int c, const float* __restrict__ mean, const float* __restrict__ invstd,
         const float* __restrict__ gamma, const float* __restrict__ mscale, const float* __restrict__ mshift,
         float* __restrict__ dbeta, float* __restrict__ dgamma, float* __restrict__ dx, int64_t lddx,
-        float* __restrict__ dres, int64_t lddres) {
+        float* __restrict__ dres, int64_t lddres, double* __restrict__ xchg = nullptr, const double* __restrict__ count_dev = nullptr) {
     __shared__ double sh[4 * 8];
     const int col = blockIdx.x * 4;
     const f32x4 m = *(const f32x4*)(mean + col), is = *(const f32x4*)(invstd + col);
@@ -822,18 +858,28 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_small_bwd_kernel(
         }
     };
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = threadIdx.x; r < n; r += BN_SMALL_THREADS) {
-        f32x4 g, xx;
-        masked(r, g, xx);
+    if constexpr (PHASE != 2) {
+        for (int r = threadIdx.x; r < n; r += BN_SMALL_THREADS) {
+            f32x4 g, xx;
+            masked(r, g, xx);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s[u] += (double)g[u]; s[4 + u] += (double)(g[u] * ((xx[u] - m[u]) * is[u])); }
+            for (int u = 0; u < 4; ++u) { s[u] += (double)g[u]; s[4 + u] += (double)(g[u] * ((xx[u] - m[u]) * is[u])); }
+        }
+        block_sum<8>(s, sh);
+        if (threadIdx.x < 4) {           // (the parameter gradients: THIS rank's sums; the gradient all-reduce averages them)
+            if (dbeta) dbeta[col + threadIdx.x] = (float)s[threadIdx.x];
+            if (dgamma) dgamma[col + threadIdx.x] = (float)s[4 + threadIdx.x];
+        }
     }
-    block_sum<8>(s, sh);
-    if (threadIdx.x < 4) {
-        if (dbeta) dbeta[col + threadIdx.x] = (float)s[threadIdx.x];
-        if (dgamma) dgamma[col + threadIdx.x] = (float)s[4 + threadIdx.x];
+    if constexpr (PHASE == 1) {
+        if (threadIdx.x < 4) { xchg[col + threadIdx.x] = s[threadIdx.x]; xchg[c + col + threadIdx.x] = s[4 + threadIdx.x]; }
+        return;
     }
-    const float inv_n = (float)(1.0 / (double)n);
+    if constexpr (PHASE == 2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[u] = xchg[col + u]; s[4 + u] = xchg[c + col + u]; }
+    }
+    const float inv_n = (float)(1.0 / (PHASE == 2 ? *count_dev : (double)n));
     f32x4 sg, sgx, ga;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -867,6 +913,34 @@ extern "C" int b2m_bn_small_bwd(const float* dy, int64_t lddy, const float* y, i
     if (!relu) bn_small_bwd_kernel<false, false><<<grid, BN_SMALL_THREADS, 0, st>>>(dy, lddy, nullptr, 0, x, ldx, (int)n, c, mean, invstd, gamma, nullptr, nullptr, dbeta_f32, dgamma_f32, dx, lddx, dres, lddres);
     else if (y) bn_small_bwd_kernel<true, true><<<grid, BN_SMALL_THREADS, 0, st>>>(dy, lddy, y, ldy, x, ldx, (int)n, c, mean, invstd, gamma, nullptr, nullptr, dbeta_f32, dgamma_f32, dx, lddx, dres, lddres);
     else bn_small_bwd_kernel<true, false><<<grid, BN_SMALL_THREADS, 0, st>>>(dy, lddy, nullptr, 0, x, ldx, (int)n, c, mean, invstd, gamma, mask_scale, mask_shift, dbeta_f32, dgamma_f32, dx, lddx, dres, lddres);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+// SyncBN halves of b2m_bn_small_bwd: phase 1 leaves this rank's (sum g, sum g * xhat) in xchg[2c] (and dbeta / dgamma from
+// them), the caller all-reduces xchg, phase 2 applies with the global row count *count_dev.
+extern "C" int b2m_bn_small_bwd_phase(int32_t phase, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
+                                      int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd, const float* gamma,
+                                      int32_t relu, const float* mask_scale, const float* mask_shift, float* dbeta_f32,
+                                      float* dgamma_f32, float* dx, int64_t lddx, float* dres, int64_t lddres, double* xchg,
+                                      const double* count_dev, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG((phase == 1 || phase == 2) && xchg && (phase == 1 || (count_dev && dx)), "phase is 1 or 2; xchg / count_dev / dx");
+    B2M_CHECK_ARG(dy && x && mean && invstd && (!relu || y || (mask_scale && mask_shift)) && n >= 1 &&
+                      n <= B2M_BN_SMALL_MAX_ROWS, "NULL argument / too many rows");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && (phase == 1 || lddx % 4 == 0) && (!(relu && y) || ldy % 4 == 0) &&
+                      (!dres || lddres % 4 == 0), "c and leading dimensions must be multiples of 4");
+    B2M_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
+                      ((uintptr_t)y % 16) == 0 && ((uintptr_t)dres % 16) == 0, "16-byte alignment");
+    const dim3 grid(c / 4);
+#define B2M_SMALL_BWD(R, H, P) bn_small_bwd_kernel<R, H, P><<<grid, BN_SMALL_THREADS, 0, st>>>(dy, lddy, (H) ? y : nullptr, (H) ? ldy : 0, x, ldx, \
+        (int)n, c, mean, invstd, gamma, (R) && !(H) ? mask_scale : nullptr, (R) && !(H) ? mask_shift : nullptr, dbeta_f32, dgamma_f32, dx, lddx,   \
+        dres, lddres, xchg, count_dev)
+    if (phase == 1) {
+        if (!relu) B2M_SMALL_BWD(false, false, 1); else if (y) B2M_SMALL_BWD(true, true, 1); else B2M_SMALL_BWD(true, false, 1);
+    } else {
+        if (!relu) B2M_SMALL_BWD(false, false, 2); else if (y) B2M_SMALL_BWD(true, true, 2); else B2M_SMALL_BWD(true, false, 2);
+    }
+#undef B2M_SMALL_BWD
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

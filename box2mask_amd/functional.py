@@ -408,7 +408,7 @@ def conv_tile_stats() -> bool:
 
 def bn_small_rows() -> int:
     """B2M_BN_SMALL_ROWS: training-mode BatchNorm of maps with at most this many rows runs as ONE launch each way
-    (b2m_bn_small_fwd / _bwd; 0 switches it off).  Not under SyncBN."""
+    (b2m_bn_small_fwd / _bwd; 0 switches it off); under SyncBN as two half-kernels around the statistics exchange."""
     return min(int(os.environ.get('B2M_BN_SMALL_ROWS', '4096')), 16384)       # (B2M_BN_SMALL_MAX_ROWS of the library)
 
 
@@ -477,8 +477,22 @@ class _BatchNorm(torch.autograd.Function):
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             invstd = torch.empty(c, dtype=torch.float32, device=dev)
             group = _sync_group() if sync else None
-            small = group is None and n <= bn_small_rows() and c % 4 == 0 and x.stride(0) % 4 == 0
-        if small:
+            small = n <= bn_small_rows() and c % 4 == 0 and x.stride(0) % 4 == 0
+        if small and group is not None:
+            # SyncBN on a small map: the one-launch kernel cut in two, the ranks' column sums and row counts meet in between
+            # (statistics -> ONE packed all-reduce -> finalize + apply): 2 launches + the collective instead of 5 + it
+            if residual is not None:
+                residual = _f32c(residual)
+            y = torch.empty_like(x)
+            stats = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+            _call('b2m_bn_small_fwd_stats', x.data_ptr(), x.stride(0), n, c, stats.data_ptr())
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+            count_dev = stats[2 * c:]
+            _call('b2m_bn_small_fwd_apply', stats.data_ptr(), x.data_ptr(), x.stride(0), n, c, _ptr(gamma), _ptr(beta), eps,
+                  momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                  shift.data_ptr(), _ptr(residual), residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                  y.data_ptr(), y.stride(0))
+        elif small:
             # few rows (deep levels, the heads): statistics + finalize + apply in ONE launch (b2m_bn_small_fwd)
             if residual is not None:
                 residual = _f32c(residual)
@@ -566,7 +580,19 @@ class _BatchNorm(torch.autograd.Function):
         if dbeta is None or dgamma is None:
             dbeta = torch.empty(c, dtype=torch.float32, device=dev)
             dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-        if ctx.small and dy.stride(0) % 4 == 0:
+        group = _sync_group() if ctx.sync else None
+        if ctx.small and dy.stride(0) % 4 == 0 and group is not None and ctx.count_dev is not None:
+            # SyncBN on a small map: reduce (this rank's sums, parameter gradients from them) -> all-reduce -> apply
+            xchg = torch.empty(2 * c, dtype=torch.float64, device=dev)
+            args = (dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(), x.stride(0), n, c,
+                    mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), relu, _ptr(mscale), _ptr(mshift))
+            _call('b2m_bn_small_bwd_phase', 1, *args, dbeta.data_ptr(), dgamma.data_ptr(), None, 0, None, 0, xchg.data_ptr(), None)
+            dist.all_reduce(xchg, op=dist.ReduceOp.SUM, group=group)
+            _call('b2m_bn_small_bwd_phase', 2, *args, None, None, dx.data_ptr(), dx.stride(0), _ptr(dres),
+                  dres.stride(0) if dres is not None else 0, xchg.data_ptr(), ctx.count_dev.data_ptr())
+            return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                    None, None, None, None, None, _own(dres), None, None, None, None)
+        if ctx.small and dy.stride(0) % 4 == 0 and group is None:
             _call('b2m_bn_small_bwd', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
                   x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), relu, _ptr(mscale), _ptr(mshift),
                   dbeta.data_ptr(), dgamma.data_ptr(), dx.data_ptr(), dx.stride(0), _ptr(dres),

@@ -60,7 +60,8 @@ class Model:
             # gradient all-reduce (box2mask_amd/parallel.py) instead of torch DDP's hook machinery.
             from .parallel import GradAllReduce
             ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(self.detection_model)
-            self._dp = GradAllReduce(list(self.detection_model.parameters()), arena=self._arena)
+            self._dp = GradAllReduce(list(self.detection_model.parameters()), arena=self._arena,
+                                     buffers=list(self.detection_model.buffers()))
             self._dp.broadcast_parameters()
         self.BCEWithLogitsLoss = torch.nn.BCEWithLogitsLoss().to(device)
         self.semantics_loss = torch.nn.CrossEntropyLoss(ignore_index=-100).to(device)

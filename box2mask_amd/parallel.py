@@ -52,8 +52,9 @@ def shard_scenes(n_scenes: int, rank: int, world: int):
 
 
 class GradAllReduce:
-    def __init__(self, params, bucket_bytes: int = 64 << 20, group=None, overlap: bool = True, arena=None):
+    def __init__(self, params, bucket_bytes: int = 64 << 20, group=None, overlap: bool = True, arena=None, buffers=None):
         self.params = [p for p in params if p.requires_grad]
+        self.buffers = list(buffers) if buffers is not None else []      # BatchNorm running statistics / counters
         self.group = group
         self.arena = arena
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -141,6 +142,10 @@ class GradAllReduce:
             return
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.group)
+        # the BatchNorm running statistics as well: equal at a fresh init, NOT after a rank-local load_state_dict (the
+        # reference's DDP broadcasts module buffers too, torch's `broadcast_buffers=True` default; model.py:24)
+        for b in self.buffers:
+            dist.broadcast(b.data, src=src, group=self.group)
 
     def all_reduce_mean(self):
         """Explicit form for callers without hooks (overlap=False): all-reduce now.  With hooks the work was done

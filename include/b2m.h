@@ -292,6 +292,24 @@ int b2m_bn_small_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy,
                      int64_t n, int32_t c, const float* mean, const float* invstd, const float* gamma, int32_t relu,
                      const float* mask_scale, const float* mask_shift, float* dbeta_f32, float* dgamma_f32,
                      float* dx, int64_t lddx, float* dres, int64_t lddres, void* stream);
+/* SyncBN forms of the two (the statistics of all ranks meet between two launches instead of inside one):
+ *   b2m_bn_small_fwd_stats  -> xchg[0:c] = sum x, xchg[c:2c] = sum x^2, xchg[2c] = n of THIS rank (fp64);
+ *   the caller all-reduces xchg[2c + 1];
+ *   b2m_bn_small_fwd_apply  = finalize from xchg (global count xchg[2c]) + apply (+residual)(+ReLU).
+ *   b2m_bn_small_bwd_phase(1, ...) -> xchg[0:c] = sum g, xchg[c:2c] = sum g * xhat of this rank, dbeta / dgamma from them
+ *   (the gradient all-reduce averages parameter gradients over the ranks); all-reduce of xchg[2c];
+ *   b2m_bn_small_bwd_phase(2, ...) = dx (and dres) from xchg with the global row count *count_dev.
+ * Replaces torch.nn.SyncBatchNorm's exchanges for the small maps (/root/reference/models/model.py:25). */
+int b2m_bn_small_fwd_stats(const float* x, int64_t ldx, int64_t n, int32_t c, double* xchg, void* stream);
+int b2m_bn_small_fwd_apply(const double* xchg, const float* x, int64_t ldx, int64_t n, int32_t c, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* invstd, float* scale, float* shift, const float* residual, int64_t ldr,
+                           int32_t relu, float* y, int64_t ldy, void* stream);
+int b2m_bn_small_bwd_phase(int32_t phase, const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* x,
+                           int64_t ldx, int64_t n, int32_t c, const float* mean, const float* invstd, const float* gamma,
+                           int32_t relu, const float* mask_scale, const float* mask_shift, float* dbeta_f32,
+                           float* dgamma_f32, float* dx, int64_t lddx, float* dres, int64_t lddres, double* xchg,
+                           const double* count_dev, void* stream);
 
 /* out = relu(a) (b == NULL) or a + b, optional relu; grad helper: dx = dy * (y > 0). */
 int b2m_relu_fwd(const float* x, int64_t n_elem, float* y, void* stream);

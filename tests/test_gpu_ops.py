@@ -191,6 +191,62 @@ def test_batch_norm_small_and_two_stage_kernels_agree(monkeypatch):
             _close(a, b, 'n=%d %s' % (n, what), 2e-5)
 
 
+@pytest.mark.parametrize('n,c,res,relu', [(3214, 256, True, True), (109, 256, False, True), (9752, 96, False, False), (2, 32, True, True)])
+def test_batch_norm_small_syncbn_halves_equal_one_launch(n, c, res, relu):
+    """SyncBN on a small map runs the one-launch kernels cut in two around the statistics exchange (b2m_bn_small_fwd_stats ->
+    all-reduce -> b2m_bn_small_fwd_apply; b2m_bn_small_bwd_phase 1 -> all-reduce -> 2).  With one rank the exchange is the
+    identity, so both halves together must give the bits of the one-launch kernel."""
+    from box2mask_amd import functional as F_
+    call, ptr = F_._call, F_._ptr
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c, device='cuda') * 1.3 + 0.2
+    r = torch.randn(n, c, device='cuda') if res else None
+    gam = torch.rand(c, device='cuda') + 0.5; bet = torch.randn(c, device='cuda')
+    dy = torch.randn(n, c, device='cuda')
+    f32 = lambda: torch.empty(c, device='cuda')
+
+    def forward(halves):
+        rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+        mean, inv, sc, sh = f32(), f32(), f32(), f32()
+        y = torch.empty_like(x)
+        tail = (ptr(gam), ptr(bet), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), mean.data_ptr(), inv.data_ptr(), sc.data_ptr(),
+                sh.data_ptr(), ptr(r), r.stride(0) if r is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
+        xchg = None
+        if halves:
+            xchg = torch.empty(2 * c + 1, dtype=torch.float64, device='cuda')
+            call('b2m_bn_small_fwd_stats', x.data_ptr(), x.stride(0), n, c, xchg.data_ptr())
+            call('b2m_bn_small_fwd_apply', xchg.data_ptr(), x.data_ptr(), x.stride(0), n, c, *tail)
+        else:
+            call('b2m_bn_small_fwd', x.data_ptr(), x.stride(0), n, c, *tail)
+        return y, rm, rv, mean, inv, sc, sh, xchg
+    a, b = forward(True), forward(False)
+    for u, v, what in zip(a[:7], b[:7], ('y', 'running_mean', 'running_var', 'mean', 'invstd', 'scale', 'shift')):
+        assert torch.equal(u, v), what
+    assert float(a[7][2 * c]) == n
+    y, mean, inv, sc, sh = b[0], b[3], b[4], b[5], b[6]
+    use_y = relu and res                   # (without a residual the mask is recomputed from x)
+
+    def backward(halves):
+        dx, dres = torch.empty_like(x), (torch.empty_like(x) if res else None)
+        dbeta, dgamma = f32(), f32()
+        head = (dy.data_ptr(), dy.stride(0), y.data_ptr() if use_y else None, y.stride(0) if use_y else 0, x.data_ptr(), x.stride(0), n, c,
+                mean.data_ptr(), inv.data_ptr(), ptr(gam), 1 if relu else 0, None if use_y or not relu else sc.data_ptr(),
+                None if use_y or not relu else sh.data_ptr())
+        if halves:
+            xchg = torch.empty(2 * c, dtype=torch.float64, device='cuda')
+            cnt = torch.full((1,), float(n), dtype=torch.float64, device='cuda')
+            call('b2m_bn_small_bwd_phase', 1, *head, dbeta.data_ptr(), dgamma.data_ptr(), None, 0, None, 0, xchg.data_ptr(), None)
+            call('b2m_bn_small_bwd_phase', 2, *head, None, None, dx.data_ptr(), dx.stride(0), ptr(dres),
+                 dres.stride(0) if dres is not None else 0, xchg.data_ptr(), cnt.data_ptr())
+        else:
+            call('b2m_bn_small_bwd', *head, dbeta.data_ptr(), dgamma.data_ptr(), dx.data_ptr(), dx.stride(0), ptr(dres),
+                 dres.stride(0) if dres is not None else 0)
+        return dx, dres, dbeta, dgamma
+    ga, gb = backward(True), backward(False)
+    for u, v, what in zip(ga, gb, ('dx', 'dres', 'dbeta', 'dgamma')):
+        assert (u is None and v is None) or torch.equal(u, v), what
+
+
 @pytest.mark.parametrize('mode', ['avg', 'max'])
 def test_segment_pool(mode):
     from box2mask_amd import functional as F_

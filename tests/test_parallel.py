@@ -93,6 +93,14 @@ def _worker(rank, world, port, q):
     net2(x).pow(2).sum().backward()
     dp2.all_reduce_mean()
     out['grads2'] = [p.grad.clone() for p in net2.parameters()]
+    # --- broadcast_parameters also carries the module buffers (BatchNorm running statistics, step counters): a rank-local
+    # load_state_dict before the wrapper is built must not leave the ranks with different normalisation in eval mode
+    bnm = torch.nn.BatchNorm1d(4)
+    with torch.no_grad():
+        bnm.running_mean.fill_(float(rank + 1)); bnm.running_var.fill_(float(2 * rank + 3)); bnm.num_batches_tracked.fill_(7 + rank)
+        bnm.weight.fill_(float(rank))
+    GradAllReduce(list(bnm.parameters()), buffers=list(bnm.buffers())).broadcast_parameters()
+    out['bn_buffers'] = [bnm.running_mean.clone(), bnm.running_var.clone(), bnm.num_batches_tracked.clone().double(), bnm.weight.detach().clone()]
     # --- SyncBN statistics merge == statistics of the concatenated rows
     torch.manual_seed(7 + rank)
     feats = torch.randn(30 + 10 * rank, 6, dtype=torch.float64)
@@ -161,6 +169,9 @@ def test_world_size_2_gloo():
             assert torch.allclose(r['arena_g1'][i], ref, atol=1e-6)
             assert torch.allclose(r['arena_g2'][i], 2 * ref, atol=1e-6)
             assert torch.allclose(r['arena_g3'][i], ref, atol=1e-6)
+    for r in (a, b):                                     # rank 0's values everywhere
+        assert torch.equal(r['bn_buffers'][0], torch.full((4,), 1.0)) and torch.equal(r['bn_buffers'][1], torch.full((4,), 3.0))
+        assert float(r['bn_buffers'][2]) == 7.0 and torch.equal(r['bn_buffers'][3], torch.zeros(4))
     feats = torch.cat([a['bn'][2], b['bn'][2]])
     for r in (a, b):
         s, cnt, _ = r['bn']
