@@ -615,6 +615,123 @@ __global__ void morton_keys_kernel(const int32_t* __restrict__ coords, int64_t n
                  (spread3((uint32_t)c.w) << 2);
     keys[i] = (int64_t)k;
 }
+// ------------------------------------------------------------------ radix argsort of 64-bit keys (Morton row order)
+// LSD radix sort of (key, row) pairs, 8 bits per pass, stable, only over the digits a caller-supplied bit mask says can
+// differ (Morton keys of a batch: 3 x bitlength(max coordinate) low bits + the batch bits at 48: 4-5 passes instead of 8).
+// Per pass: (1) one 256-bin histogram per block of RS_TILE keys (LDS atomics), stored digit-major; (2) ONE workgroup scans the
+// 256 x nblk counts (exclusive; digit-major order = the global order of the pass); (3) every block ranks its keys again --
+// in input order, wave by wave: lanes with equal digits find each other with eight ballots, the lowest of them owns the
+// digit's running counter in LDS -- and scatters key and row.  The last pass also writes the permutation and its inverse
+// as int64 (torch index tensors), so nothing of the sort is left to torch (round 3: torch.argsort = rocprim onesweep).
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift, int nblk,
+                                                             int32_t* __restrict__ hist) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const int64_t i = base + it * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+// exclusive scan of m ints in place by ONE workgroup of 1024 threads (m = 256 x nblk: a few 10^4 .. 10^5)
+__global__ __launch_bounds__(1024) void rs_scan_kernel(int32_t* __restrict__ a, int64_t m) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (m + 1023) / 1024;
+    const int64_t lo = tid * per < m ? tid * per : m, hi = lo + per < m ? lo + per : m;
+    int s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += a[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int64_t i = lo; i < hi; ++i) { const int v = a[i]; a[i] = run; run += v; }
+}
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                                int64_t n, int shift, int nblk, const int32_t* __restrict__ hist,
+                                                                uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out,
+                                                                int64_t* __restrict__ perm64, int64_t* __restrict__ inv64) {
+    __shared__ int base[256];                       // next output position of every digit for this block
+    __shared__ int wcnt[RS_THREADS / 64][256];      // keys of the round with that digit, per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    base[tid] = hist[(int64_t)tid * nblk + blockIdx.x];
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    for (int it = 0; it < RS_ITEMS; ++it) {
+#pragma unroll
+        for (int w = 0; w < RS_THREADS / 64; ++w) wcnt[w][tid] = 0;
+        __syncthreads();
+        const int64_t i = tile0 + it * RS_THREADS + tid;
+        const bool live = i < n;
+        const uint64_t k = live ? keys[i] : 0;
+        const int d = (int)((k >> shift) & 255);
+        // lanes of this wave with the same digit
+        uint64_t same = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1);
+            same &= ((d >> b) & 1) ? m : ~m;
+        }
+        const int below = __builtin_popcountll(same & ((1ull << lane) - 1));
+        if (live && below == 0) wcnt[wave][d] = __builtin_popcountll(same);
+        __syncthreads();
+        if (live) {
+            int pos = base[d] + below;
+            for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
+            const int v = vals ? vals[i] : (int)i;
+            keys_out[pos] = k; vals_out[pos] = v;
+            if (perm64) { perm64[pos] = v; inv64[v] = pos; }
+        }
+        __syncthreads();
+        int add = 0;
+#pragma unroll
+        for (int w = 0; w < RS_THREADS / 64; ++w) add += wcnt[w][tid];
+        base[tid] += add;
+        // (the zeroing of wcnt at the top of the next round is behind the barrier above)
+    }
+}
+extern "C" int64_t b2m_radix_argsort_scratch(int64_t n) {
+    const int64_t nblk = cdiv64(n > 0 ? n : 1, RS_TILE);
+    return 2 * n * 8 + 2 * n * 4 + 256 * nblk * 4 + 64;          // two key buffers, two row buffers, the histograms
+}
+extern "C" int b2m_radix_argsort(const uint64_t* keys, int64_t n, uint64_t bit_mask, int64_t* perm, int64_t* inv_perm,
+                                 void* scratch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(n >= 0 && n < (1ll << 31) && (n == 0 || (keys && perm && inv_perm && scratch)), "bad arguments");
+    if (n == 0) return B2M_OK;
+    const int nblk = (int)cdiv64(n, RS_TILE);
+    uint64_t* kbuf[2] = {(uint64_t*)scratch, (uint64_t*)scratch + n};
+    int32_t* vbuf[2] = {(int32_t*)((uint64_t*)scratch + 2 * n), (int32_t*)((uint64_t*)scratch + 2 * n) + n};
+    int32_t* hist = vbuf[1] + n;
+    int shifts[8], np = 0;
+    for (int sft = 0; sft < 64; sft += 8)
+        if ((bit_mask >> sft) & 255ull) shifts[np++] = sft;
+    if (np == 0) shifts[np++] = 0;                   // (all keys equal: one pass writes the identity permutation)
+    const uint64_t* kin = keys;
+    const int32_t* vin = nullptr;
+    for (int p = 0; p < np; ++p) {
+        const bool last = p == np - 1;
+        rs_hist_kernel<<<nblk, RS_THREADS, 0, st>>>(kin, n, shifts[p], nblk, hist);
+        rs_scan_kernel<<<1, 1024, 0, st>>>(hist, (int64_t)256 * nblk);
+        rs_scatter_kernel<<<nblk, RS_THREADS, 0, st>>>(kin, vin, n, shifts[p], nblk, hist, kbuf[p & 1], vbuf[p & 1],
+                                                       last ? perm : nullptr, last ? inv_perm : nullptr);
+        kin = kbuf[p & 1]; vin = vbuf[p & 1];
+    }
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 extern "C" int b2m_morton_keys(const int32_t* coords, int64_t n, int64_t* keys, void* stream) {
     B2M_CHECK_ARG(n >= 0 && (n == 0 || (coords && keys)), "bad arguments");
     if (n == 0) return B2M_OK;

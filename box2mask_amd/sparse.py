@@ -76,11 +76,18 @@ class CoordinateManager:
         # optional spatial row order: level-0 rows sorted by Morton key; perm[i] = input row held by internal row i
         self.perm = self.inv_perm = None
         if reorder and c0.shape[0] > 1:
-            keys = torch.empty(c0.shape[0], dtype=torch.int64, device=dev)
-            _lib.call('b2m_morton_keys', c0.data_ptr(), c0.shape[0], keys.data_ptr())
-            self.perm = torch.argsort(keys)
-            self.inv_perm = torch.empty_like(self.perm)
-            self.inv_perm[self.perm] = torch.arange(c0.shape[0], device=dev)
+            n0 = c0.shape[0]
+            keys = torch.empty(n0, dtype=torch.int64, device=dev)
+            _lib.call('b2m_morton_keys', c0.data_ptr(), n0, keys.data_ptr())
+            # radix argsort over the key bits that can differ: 3 x bitlength(largest coordinate) interleaved bits + the
+            # batch index at bit 48 (the bounds check above read the maximum; without it all 64 bits)
+            bits = max(int(mx).bit_length(), 1) if (check and coords.numel()) else 16
+            mask = ((1 << (3 * bits)) - 1) | (((1 << bits) - 1) << 48)
+            self.perm = torch.empty(n0, dtype=torch.int64, device=dev)
+            self.inv_perm = torch.empty(n0, dtype=torch.int64, device=dev)
+            scratch = torch.empty((_lib.load().b2m_radix_argsort_scratch(n0) + 7) // 8, dtype=torch.int64, device=dev)
+            _lib.call('b2m_radix_argsort', keys.data_ptr(), n0, mask & 0xFFFFFFFFFFFFFFFF, self.perm.data_ptr(),
+                      self.inv_perm.data_ptr(), scratch.data_ptr())
             c0 = c0[self.perm].contiguous()
         self.device = dev
         self.serial = next(_serial)

@@ -53,6 +53,14 @@ int b2m_coords_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* 
  * order guarantee beyond input order, which the host restores at the boundary).  Requires b < 32768. */
 int b2m_morton_keys(const int32_t* coords, int64_t n, int64_t* keys, void* stream);
 
+/* Stable argsort of n 64-bit keys (LSD radix sort, 8 bits per pass, only over the bytes in which `bit_mask` has a bit: the bits
+ * that can differ between keys; ~0 = all eight): perm[j] = index of the j-th smallest key, inv_perm[perm[j]] = j (int64, ready
+ * to index torch tensors).  scratch: b2m_radix_argsort_scratch(n) bytes.  Orders the rows of a batch by Morton key
+ * (CoordinateManager(reorder=True)); replaces torch.argsort (rocprim) on the product path. */
+int64_t b2m_radix_argsort_scratch(int64_t n);
+int b2m_radix_argsort(const uint64_t* keys, int64_t n, uint64_t bit_mask, int64_t* perm, int64_t* inv_perm, void* scratch,
+                      void* stream);
+
 /* Strided (kernel 2, stride 2) coordinate generation: out = floor(c / 2ts) * 2ts, unique, rows in
  * order of first occurrence.  Replaces [ME] stride() reached from the seven k=2,s=2 convolutions,
  * models/detection_net.py:42,48,54,61,68,74,81.

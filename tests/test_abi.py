@@ -28,13 +28,13 @@ def _kind(arg):
     if '*' in arg:
         return 'p'
     t = arg.split()[0] if not arg.startswith('const') else arg.split()[1]
-    return {'int64_t': 'i64', 'int32_t': 'i32', 'float': 'f32', 'double': 'f64', 'int': 'i32'}[t]
+    return {'int64_t': 'i64', 'uint64_t': 'u64', 'int32_t': 'i32', 'float': 'f32', 'double': 'f64', 'int': 'i32'}[t]
 
 
 def _ckind(t):
     if t in (_lib.P,) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
         return 'p'
-    return {_lib.I64: 'i64', _lib.I32: 'i32', _lib.F32: 'f32', _lib.F64: 'f64'}[t]
+    return {_lib.I64: 'i64', ctypes.c_uint64: 'u64', _lib.I32: 'i32', _lib.F32: 'f32', _lib.F64: 'f64'}[t]
 
 
 def test_library_is_built_and_loads():

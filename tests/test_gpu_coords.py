@@ -223,3 +223,26 @@ def test_conv_on_skewed_runs_matches_equal_counts(monkeypatch):
     y0, dw0 = run()
     assert torch.equal(y1, y0)                           # the same wave code per tile: the same bits
     assert float((dw1 - dw0).abs().max()) / float(dw0.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 4095, 4096, 4097, 100_003, 1_300_000])
+def test_radix_argsort_matches_stable_sort(n):
+    """b2m_radix_argsort (the Morton row order of CoordinateManager(reorder=True)): permutation and inverse equal a stable
+    sort's, for key sets with few distinct values (long runs of equal digits), full 64-bit keys and masked passes."""
+    from box2mask_amd import _lib
+    g = torch.Generator().manual_seed(n)
+    cases = {
+        'few values': (torch.randint(0, 7, (n,), generator=g), 0xFF),
+        'morton-like': ((torch.randint(0, 8, (n,), generator=g) << 48) | torch.randint(0, 1 << 30, (n,), generator=g),
+                        ((1 << 30) - 1) | (0x3FF << 48)),
+        'all 63 bits': (torch.randint(0, (1 << 62), (n,), generator=g), 0xFFFFFFFFFFFFFFFF),
+        'all equal': (torch.full((n,), 12345), 0),
+    }
+    for what, (keys, mask) in cases.items():
+        k = keys.to(torch.int64).cuda()
+        perm = torch.empty(n, dtype=torch.int64, device='cuda'); inv = torch.empty_like(perm)
+        scratch = torch.empty((_lib.load().b2m_radix_argsort_scratch(n) + 7) // 8, dtype=torch.int64, device='cuda')
+        _lib.call('b2m_radix_argsort', k.data_ptr(), n, mask, perm.data_ptr(), inv.data_ptr(), scratch.data_ptr())
+        ref = torch.sort(keys.to(torch.int64), stable=True).indices
+        assert torch.equal(perm.cpu(), ref), what
+        assert torch.equal(inv.cpu()[ref], torch.arange(n)), what
