@@ -32,6 +32,7 @@ PROTOTYPES = {
     'b2m_stride_tables': [P, P, I64, I64, P, I64, P, I64, P],
     'b2m_rulebook': [P, I64, I32, I64, P, P, P, P, P],
     'b2m_rulebook_balance': [P, I32, I64, P],
+    'b2m_detection_loss': [P, I64, P, I64, P, I64, P, I64, I32, P, P, P, P, P, I64, F64, P, F32, F32, F32, F32, F32, P, P, P, P, P, P, P, P],
     'b2m_radix_argsort': [P, I64, C.c_uint64, P, P, P, P],
     'b2m_conv_fwd': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],
     'b2m_conv_fwd_affine': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, I64, P, I64, I32, P, P, P, I64, I32, P, P],

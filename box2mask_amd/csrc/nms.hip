@@ -40,6 +40,144 @@ extern "C" int b2m_set_ious(const float* a, const float* b, int64_t n, float* ou
     return B2M_OK;
 }
 
+// ------------------------------------------------------------------ detection losses, forward + gradients in one launch
+// The box and semantics terms of Model.compute_loss_detection in the ScanNet configuration
+// (/root/reference/models/model.py:62-88 L1 offset / bounds, :133-176 IoU-target score loss, :194-210 semantics): torch
+// evaluates them as ~75 elementwise launches forward and as many backward, all on the critical path between the forward and
+// the backward pass of the network.  Here one thread owns one prediction row: the L1 terms, the box IoU against the ground
+// truth (set_IOUs' arithmetic), BCE-with-logits against it, the Pearson sums of the logging correlation, cross entropy over
+// the class logits and its argmax -- and, in the same pass, the gradient of the weighted total with respect to every head
+// output (each is an elementwise function of the row once the normalisers F = foreground rows and n_valid are known).
+// Sums in fp64 (block tree, then one atomic per block and value).  out[16] doubles:
+//   0 sum |d off|   1 sum |d bounds|   2 sum BCE   3 sum iou   4 sum logit   5 sum iou^2   6 sum logit^2   7 sum iou*logit
+//   8 sum CE        9 correct class   10 (unused)
+struct LossArgs {
+    const float* off; int64_t ld_off; const float* bnd; int64_t ld_bnd; const float* sc; int64_t ld_sc;
+    const float* sem; int64_t ld_sem; int C;
+    const float* gt_off; const float* gt_bnd; const float* loc;            // (S, 3) dense
+    const uint8_t* fg; const int64_t* gt_sem; int64_t S;
+    float w_off, w_bnd, w_sc, w_sem, min_bb; double F; const double* n_valid;
+    float* d_off; float* d_bnd; float* d_sc; float* d_sem; int64_t* argmax; double* out;
+};
+__global__ __launch_bounds__(256) void detection_loss_kernel(LossArgs a) {
+    __shared__ double red[4][10];
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (s < a.S) {
+        const bool fg = a.fg == nullptr || a.fg[s] != 0;
+        const float inv_f = (float)(1.0 / a.F);
+        float po[3], pb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { po[j] = a.off[s * a.ld_off + j]; pb[j] = a.bnd[s * a.ld_bnd + j]; }
+        if (fg) {
+            float l_off = 0.f, l_bnd = 0.f, pbox[6], gbox[6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float go = a.gt_off[s * 3 + j], gb = a.gt_bnd[s * 3 + j], lc = a.loc[s * 3 + j];
+                const float d0 = po[j] - go, d1 = pb[j] - gb;
+                l_off += fabsf(d0); l_bnd += fabsf(d1);
+                a.d_off[s * 3 + j] = d0 > 0.f ? a.w_off * inv_f : (d0 < 0.f ? -a.w_off * inv_f : 0.f);
+                a.d_bnd[s * 3 + j] = d1 > 0.f ? a.w_bnd * inv_f : (d1 < 0.f ? -a.w_bnd * inv_f : 0.f);
+                const float pc = po[j] + lc, gc = go + lc;                  // voted / true centre (model.py:147-150)
+                const float pbc = pb[j] < a.min_bb ? a.min_bb : pb[j];      // torch.clamp(pred_bounds, min=min_bb_size)
+                pbox[j] = pc - pbc; pbox[3 + j] = pc + pbc;
+                gbox[j] = gc - gb; gbox[3 + j] = gc + gb;
+            }
+            v[0] = l_off; v[1] = l_bnd;
+            if (a.sc) {
+                const float iou = box_iou(gbox, pbox);                      // set_IOUs(gt_bbs, pred_bbs)
+                const double x = (double)a.sc[s * a.ld_sc], y = (double)iou;
+                v[2] = (x > 0 ? x : 0) - x * y + log1p(exp(-fabs(x)));      // BCEWithLogitsLoss
+                v[3] = y; v[4] = x; v[5] = y * y; v[6] = x * x; v[7] = x * y;
+                a.d_sc[s] = (float)((double)a.w_sc * (1.0 / (1.0 + exp(-x)) - y) / a.F);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { a.d_off[s * 3 + j] = 0.f; a.d_bnd[s * 3 + j] = 0.f; }
+            if (a.sc) a.d_sc[s] = 0.f;
+        }
+        if (a.sem) {
+            const float* z = a.sem + s * a.ld_sem;
+            const int64_t t = a.gt_sem[s];
+            float mx = z[0]; int am = 0;
+            for (int c = 1; c < a.C; ++c) if (z[c] > mx) { mx = z[c]; am = c; }        // first maximum, like torch.argmax
+            double den = 0;
+            for (int c = 0; c < a.C; ++c) den += exp((double)z[c] - (double)mx);
+            a.argmax[s] = am;
+            v[9] = (t == am) ? 1.0 : 0.0;
+            const bool valid = t >= 0 && t < a.C;                                       // ignore_index = -100
+            const double inv_n = 1.0 / *a.n_valid;
+            if (valid) v[8] = log(den) - ((double)z[t] - (double)mx);
+            for (int c = 0; c < a.C; ++c) {
+                const double p = exp((double)z[c] - (double)mx) / den;
+                a.d_sem[s * a.C + c] = valid ? (float)((double)a.w_sem * (p - (c == t ? 1.0 : 0.0)) * inv_n) : 0.f;
+            }
+        }
+    }
+    // block sum in a fixed tree, one atomic per value and block
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+        double t = v[u];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d, 64);
+        v[u] = t;
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int u = 0; u < 10; ++u) red[threadIdx.x >> 6][u] = v[u];
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const double t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (t != 0.0) atomicAdd(a.out + threadIdx.x, t);
+    }
+}
+// res[0] total, 1 offset_loss, 2 bounds_loss, 3 bb_score_loss, 4 bb_target_scores, 5 bb_scores_correlation, 6 semantics_loss,
+// 7 semantics_acc
+__global__ void detection_loss_final_kernel(const double* __restrict__ o, double F, const double* __restrict__ n_valid, int64_t S,
+                                            float w_off, float w_bnd, float w_sc, float w_sem, int has_sc, int has_sem,
+                                            float* __restrict__ res) {
+    const double l_off = o[0] / F, l_bnd = o[1] / F;
+    double total = (double)w_off * l_off + (double)w_bnd * l_bnd;
+    res[1] = (float)l_off; res[2] = (float)l_bnd;
+    res[3] = res[4] = res[5] = res[6] = res[7] = 0.f;
+    if (has_sc) {
+        const double bce = o[2] / F;
+        total += (double)w_sc * bce;
+        res[3] = (float)bce; res[4] = (float)(o[3] / F);
+        const double ca = o[5] - o[3] * o[3] / F, cb = o[6] - o[4] * o[4] / F, cab = o[7] - o[3] * o[4] / F;
+        const double den = sqrt(ca * cb);
+        res[5] = (float)(cab / (den > 1e-300 ? den : 1e-300));
+    }
+    if (has_sem) {
+        const double ce = o[8] / *n_valid;
+        total += (double)w_sem * ce;
+        res[6] = (float)ce; res[7] = (float)(o[9] / (double)S);
+    }
+    res[0] = (float)total;
+}
+extern "C" int b2m_detection_loss(const float* off, int64_t ld_off, const float* bnd, int64_t ld_bnd, const float* sc, int64_t ld_sc,
+                                  const float* sem, int64_t ld_sem, int32_t n_class, const float* gt_off, const float* gt_bnd,
+                                  const float* loc, const uint8_t* fg, const int64_t* gt_sem, int64_t S, double n_fg,
+                                  const double* n_valid, float w_off, float w_bnd, float w_sc, float w_sem, float min_bb_size,
+                                  float* d_off, float* d_bnd, float* d_sc, float* d_sem, int64_t* argmax, double* sums,
+                                  float* result, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(off && bnd && gt_off && gt_bnd && loc && d_off && d_bnd && sums && result && S >= 1 && n_fg >= 1, "bad arguments");
+    B2M_CHECK_ARG(ld_off >= 3 && ld_bnd >= 3 && (!sc || (d_sc && ld_sc >= 1)), "leading dimensions / score gradient");
+    B2M_CHECK_ARG(!sem || (d_sem && argmax && gt_sem && n_valid && n_class >= 1 && ld_sem >= n_class), "semantics arguments");
+    LossArgs a;
+    a.off = off; a.ld_off = ld_off; a.bnd = bnd; a.ld_bnd = ld_bnd; a.sc = sc; a.ld_sc = ld_sc; a.sem = sem; a.ld_sem = ld_sem;
+    a.C = n_class; a.gt_off = gt_off; a.gt_bnd = gt_bnd; a.loc = loc; a.fg = fg; a.gt_sem = gt_sem; a.S = S;
+    a.w_off = w_off; a.w_bnd = w_bnd; a.w_sc = w_sc; a.w_sem = w_sem; a.min_bb = min_bb_size; a.F = n_fg; a.n_valid = n_valid;
+    a.d_off = d_off; a.d_bnd = d_bnd; a.d_sc = d_sc; a.d_sem = d_sem; a.argmax = argmax; a.out = sums;
+    B2M_HIP(hipMemsetAsync(sums, 0, 16 * sizeof(double), st));
+    detection_loss_kernel<<<(unsigned)cdiv64(S, 256), 256, 0, st>>>(a);
+    detection_loss_final_kernel<<<1, 1, 0, st>>>(sums, n_fg, n_valid, S, w_off, w_bnd, w_sc, w_sem, sc ? 1 : 0, sem ? 1 : 0, result);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 // ------------------------------------------------------------------ non-maximum clustering
 #define NMC_THREADS 1024
 #define NMC_LDS_SORT 4096

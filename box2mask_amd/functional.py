@@ -820,5 +820,57 @@ class _SegmentPool(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _DetectionLoss(torch.autograd.Function):
+    """Box + semantics terms of the training loss, values and gradients in ONE pass over the prediction rows
+    (b2m_detection_loss; /root/reference/models/model.py:62-88, 133-176, 194-210).  Returns the 8 result floats
+    (include/b2m.h); element 0 is the weighted total and the only one gradients flow through."""
+
+    @staticmethod
+    def forward(ctx, off, bnd, sc, sem, gt_off, gt_bnd, loc, fg_u8, gt_sem, n_fg, n_valid, weights, min_bb):
+        off, bnd = _f32c(off), _f32c(bnd)
+        sc = _f32c(sc) if sc is not None else None
+        sem = _f32c(sem) if sem is not None else None
+        S, dev = off.shape[0], off.device
+        d_off, d_bnd = torch.empty((S, 3), device=dev), torch.empty((S, 3), device=dev)
+        d_sc = torch.empty((S, 1), device=dev) if sc is not None else None
+        C = sem.shape[1] if sem is not None else 0
+        d_sem = torch.empty((S, C), device=dev) if sem is not None else None
+        argmax = torch.empty(S, dtype=torch.int64, device=dev) if sem is not None else None
+        sums = torch.empty(16, dtype=torch.float64, device=dev)
+        result = torch.empty(8, dtype=torch.float32, device=dev)
+        _call('b2m_detection_loss', off.data_ptr(), off.stride(0), bnd.data_ptr(), bnd.stride(0), _ptr(sc),
+              sc.stride(0) if sc is not None else 0, _ptr(sem), sem.stride(0) if sem is not None else 0, C,
+              gt_off.data_ptr(), gt_bnd.data_ptr(), loc.data_ptr(), _ptr(fg_u8), _ptr(gt_sem), S, float(n_fg), _ptr(n_valid),
+              weights[0], weights[1], weights[2], weights[3], min_bb, d_off.data_ptr(), d_bnd.data_ptr(), _ptr(d_sc),
+              _ptr(d_sem), _ptr(argmax), sums.data_ptr(), result.data_ptr())
+        ctx.grads = (d_off, d_bnd, d_sc, d_sem)
+        ctx.argmax = argmax
+        return result
+
+    @staticmethod
+    def backward(ctx, g):
+        g0 = g[0]
+        out = [None if d is None else d * g0 for d in ctx.grads]
+        return (out[0], out[1], out[2], out[3]) + (None,) * 9
+
+
+def detection_loss(off, bnd, sc, sem, gt_off, gt_bnd, loc, fg_u8, gt_sem, n_fg, n_valid, weights, min_bb):
+    """-> (result (8,) float tensor: total, offset_loss, bounds_loss, bb_score_loss, bb_target_scores, bb_scores_correlation,
+    semantics_loss, semantics_acc;  predicted class per row or None)."""
+    fn = _DetectionLoss
+    res = fn.apply(off, bnd, sc, sem, gt_off, gt_bnd, loc, fg_u8, gt_sem, n_fg, n_valid, weights, min_bb)
+    node = res.grad_fn
+    argmax = None
+    if sem is not None:
+        # (the argmax rides on the context of the node that made `res`; without autograd the kernel's buffer is re-made)
+        argmax = node.argmax if node is not None and hasattr(node, 'argmax') else torch.argmax(sem.detach(), 1)
+    return res, argmax
+
+
+def fused_loss_enabled() -> bool:
+    """B2M_FUSED_LOSS=0: the loss terms are evaluated term by term with torch (the reference's formulas as written)."""
+    return os.environ.get('B2M_FUSED_LOSS', '1') == '1'
+
+
 def segment_pool(x, ids, n_seg, mode='avg'):
     return _SegmentPool.apply(x, ids, n_seg, 0 if mode == 'avg' else 1)

@@ -151,6 +151,10 @@ class Model:
             pred[mlp_head] = sparse_tensor.F
         losses_dict = {'optimization_loss': 0}
 
+        fused = self._fused_losses(batch, pred, epoch, fg, fg_rows, on_fg)
+        if fused is not None:
+            return fused, pred
+
         if cfg.mlp_offsets in cfg.network_heads:                     # model.py:62-73
             gt_offsets, pred_offsets = batch['gt_bb_offsets'].to(device), pred[cfg.mlp_offsets]
             if on_fg:
@@ -234,6 +238,50 @@ class Model:
             losses_dict['per_vox_semantics_loss'] = per_vox_semantics_loss.detach()
             losses_dict['per_vox_semantics_acc'] = per_vox_semantics_acc.detach()
         return losses_dict, pred
+
+    def _fused_losses(self, batch, pred, epoch, fg, fg_rows, on_fg):
+        """The ScanNet loss configuration (offsets + bounds [+ IoU-target scores] [+ semantics] on the foreground segments)
+        as ONE launch for values and gradients (functional.detection_loss) instead of ~150 elementwise torch launches between
+        the forward and the backward pass; None for every other configuration (IoU loss, centre scores, per-voxel semantics:
+        the term-by-term code below).  Same keys, same values (tests/test_gpu_net.py::test_losses_match_reference_golden)."""
+        from . import functional as F_
+        cfg, device = self.cfg, self.device
+        heads = cfg.network_heads
+        if not F_.fused_loss_enabled() or cfg.use_bb_iou_loss or cfg.mlp_center_scores in heads or \
+                cfg.mlp_per_vox_semantics in heads or cfg.mlp_offsets not in heads or cfg.mlp_bounds not in heads:
+            return None
+        if on_fg and (fg is None or fg_rows is None):
+            return None
+        S = pred[cfg.mlp_offsets].shape[0]
+        n_fg = int(fg_rows.shape[0]) if on_fg else S
+        if S == 0 or n_fg == 0:
+            return None
+        f32 = lambda t: t.to(device=device, dtype=torch.float32).contiguous()
+        has_sc, has_sem = cfg.mlp_bb_scores in heads, cfg.mlp_semantics in heads
+        w_sc = 0.0
+        if has_sc:
+            w_sc = float(cfg.loss_weight_bb_scores) if epoch >= cfg.mlp_bb_scores_start_epoch else 0.0
+        gt_sem = n_valid = None
+        if has_sem:
+            gt_sem = self._sem_lut()[batch['gt_semantics'].to(device)].contiguous()
+            n_valid = (gt_sem >= 0).sum(dtype=torch.float64).reshape(1)
+        res, argmax = F_.detection_loss(
+            pred[cfg.mlp_offsets], pred[cfg.mlp_bounds], pred[cfg.mlp_bb_scores] if has_sc else None,
+            pred[cfg.mlp_semantics] if has_sem else None, f32(batch['gt_bb_offsets']), f32(batch['gt_bb_bounds']),
+            f32(batch['input_location']), fg.to(torch.uint8).contiguous() if on_fg else None, gt_sem, n_fg, n_valid,
+            (float(cfg.loss_weight_bb_offsets), float(cfg.loss_weight_bb_bounds), w_sc, float(cfg.loss_weight_semantics)),
+            float(cfg.min_bb_size))
+        d = res.detach()
+        out = {'optimization_loss': res[0], 'offset_loss': d[1], 'bounds_loss': d[2]}
+        if has_sc:
+            out['bb_scores_correlation'] = d[5]
+            out['bb_score_loss'] = d[3]
+            out['bb_target_scores'] = d[4]
+        if has_sem:
+            out['semantics_loss'] = d[6]
+            out['semantics_acc'] = d[7]
+            out['semantics_mIoU'] = _LazyMean(argmax, gt_sem)
+        return out
 
     def sync_gradients(self):
         """Kept for callers of the first release: the data-parallel gradient mean (DDP's job in the reference,

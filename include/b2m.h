@@ -129,6 +129,23 @@ int b2m_rulebook_balance(int32_t* rb_cnt, int32_t K, int64_t n_out, void* stream
 int b2m_rulebook(const int32_t* nbr, int64_t ld, int32_t K, int64_t n_out,
                  int32_t* rb_in, uint8_t* rb_out, int32_t* rb_cnt, int32_t* pair_total, void* stream);
 
+/* Detection losses of the ScanNet configuration, values AND gradients in one pass over the prediction rows
+ * (/root/reference/models/model.py:62-88, 133-176, 194-210; replaces ~150 elementwise torch launches per step):
+ *   offset_loss = mean_fg sum_j |off - gt_off|, bounds_loss likewise, bb_score_loss = BCEWithLogits(score, IoU(gt box, predicted
+ *   box with bounds clamped at min_bb_size)) over the foreground rows, semantics_loss = CrossEntropy(sem, gt_sem; ignore < 0 or
+ *   >= n_class) over the n_valid rows, total = sum of weight * loss.
+ * off / bnd / sc: (S,3) / (S,3) / (S,1) head outputs with row pitches ld_*; sem (S, n_class) or NULL; sc NULL = no score term.
+ * fg: uint8 (S) foreground flags or NULL (all rows), n_fg = their count; n_valid: device scalar = rows with a valid class.
+ * d_*: gradient of `total` w.r.t. the head outputs, dense (S,3) / (S,3) / (S) / (S, n_class); argmax (S) = predicted class.
+ * sums: double[16] scratch; result: float[8] = total, offset_loss, bounds_loss, bb_score_loss, bb_target_scores (mean IoU),
+ * bb_scores_correlation (Pearson of IoU and score logit), semantics_loss, semantics_acc. */
+int b2m_detection_loss(const float* off, int64_t ld_off, const float* bnd, int64_t ld_bnd, const float* sc, int64_t ld_sc,
+                       const float* sem, int64_t ld_sem, int32_t n_class, const float* gt_off, const float* gt_bnd,
+                       const float* loc, const uint8_t* fg, const int64_t* gt_sem, int64_t S, double n_fg,
+                       const double* n_valid, float w_off, float w_bnd, float w_sc, float w_sem, float min_bb_size,
+                       float* d_off, float* d_bnd, float* d_sc, float* d_sem, int64_t* argmax, double* sums,
+                       float* result, void* stream);
+
 /* ---------------------------------------------------------------- sparse convolution (fp32, MFMA) */
 
 /* Packed weight image read by b2m_conv_fwd.  The logical operand is B[k][ci][co]:
