@@ -988,10 +988,15 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                     else conv_fwd_flow_kernel<3, 2, 0, 4><<<fo.grid, 256, 0, st>>>(a);
                 }
             } else if (dbg && TW == 3 && depth == 2) {
+                // (diagnostic: B2M_PIPE_LDS extra bytes of dynamic LDS per workgroup cap the waves resident per CU)
+                const size_t xl = (size_t)env_flag("B2M_PIPE_LDS", 0);
+                if (dbg == 16) { conv_fwd_flow_kernel<2, 3><<<fo.grid, 64, xl, st>>>(a); B2M_LAUNCH_CHECK(); return B2M_OK; }
+                if (dbg == 22) { conv_fwd_flow_kernel<2, 3, 6><<<fo.grid, 64, xl, st>>>(a); B2M_LAUNCH_CHECK(); return B2M_OK; }
                 switch (dbg) {
                     case 1: conv_fwd_flow_kernel<2, 3, 1><<<fo.grid, 64, 0, st>>>(a); break;
                     case 2: conv_fwd_flow_kernel<2, 3, 2><<<fo.grid, 64, 0, st>>>(a); break;
                     case 4: conv_fwd_flow_kernel<2, 3, 4><<<fo.grid, 64, 0, st>>>(a); break;
+                    case 8: conv_fwd_flow_kernel<2, 3, 8><<<fo.grid, 64, 0, st>>>(a); break;
                     default: conv_fwd_flow_kernel<2, 3, 6><<<fo.grid, 64, 0, st>>>(a); break;
                 }
             } else if (depth == 2) {

@@ -59,7 +59,7 @@ __device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float
 #define tile_column_sums(a, strip, tile, row0, col0, lane) strip_column_sums<SW>(a, strip, tile, row0, col0, lane)
 
 // DBG (diagnostic builds of tools/pipe_breakdown.py only, results are WRONG): 1 = no strip flush, 2 = no gathers inside
-// the loop, 4 = no weight loads inside the loop -- each removes one component so that its cost shows in the launch time
+// the loop, 4 = no weight loads inside the loop, 8 = no MFMAs (everything else: the floor a faster multiply would leave) -- each removes one component so that its cost shows in the launch time
 // WPB = 4: split maps (deep U-Net levels).  The four waves of a workgroup are four slices of ONE (tile, strip): the
 // tile's active offsets are dealt round-robin to nslice / ncs slices and the input-channel chunks to ncs parts; the
 // waves add their strips up in LDS behind one barrier and wave 0 writes (plain stores for exactly 4 slices, else fp32
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                     const char* src = src_of(cT + j, ld4);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        if (g < GC) mfma_group(j, g);                        // wave-uniform
+                        if constexpr (!(DBG & 8)) { if (g < GC) mfma_group(j, g); }   // wave-uniform
                         if constexpr (!(DBG & 2)) gather(j, g, src, ld4, wT[g]);
                     }
                     if constexpr (!(DBG & 4)) weights(j, kT, cT + j);
