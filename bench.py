@@ -596,15 +596,14 @@ KERNEL_OF = {'nmc_batch': 'nmc_batch_kernel', 'mask_project': 'mask_project_batc
              'label_hist': 'label_hist_batch_kernel', 'mask_gather': 'mask_gather_batch_kernel'}
 
 
-def votes_leg(model, batch, cfg, cpu, pmc=None, pmc_src=None):
-    """Evaluater flow (evaluation.py:86-97) on synthetic votes: every segment of the batch votes for the box of
-    its ground-truth object with 2.5 cm noise on offset and bounds, score logits ~ N(0,2), semantics = ground
-    truth (SURVEY 8d).  Times Model.pred2mask(batch, pred, 'eval') over the whole batch; with `cpu`, scene 0 is
-    also run on the CPU oracle (oracle/nms_ref.py, pinned bit for bit to the reference) and compared."""
+def synthetic_votes(batch, cfg, seed=7):
+    """Head outputs a trained network would produce: every segment votes for the box of its ground-truth object with
+    2.5 cm noise on offset and bounds, score logits ~ N(0, 2), semantics = ground truth.  A random-init network's outputs are
+    not votes (every segment its own cluster), so the votes -> masks half of every leg runs on these."""
     from box2mask_amd import synth
-    g = torch.Generator().manual_seed(7)
+    g = torch.Generator().manual_seed(seed)
     S = batch['input_location'].shape[0]
-    valid, id2idx, _, is_fg = synth.scannet_tables()
+    valid, id2idx, _, _ = synth.scannet_tables()
     sem_idx = id2idx[batch['gt_semantics'].cpu()].clamp_min(0)
     pred = {
         cfg.mlp_offsets: batch['gt_bb_offsets'].cpu() + 0.025 * torch.randn(S, 3, generator=g),
@@ -612,6 +611,18 @@ def votes_leg(model, batch, cfg, cpu, pmc=None, pmc_src=None):
         cfg.mlp_bb_scores: 2.0 * torch.randn(S, 1, generator=g),
         cfg.mlp_semantics: torch.nn.functional.one_hot(sem_idx, len(valid)).float(),
     }
+    return pred, sem_idx
+
+
+def votes_leg(model, batch, cfg, cpu, pmc=None, pmc_src=None):
+    """Evaluater flow (evaluation.py:86-97) on synthetic votes: every segment of the batch votes for the box of
+    its ground-truth object with 2.5 cm noise on offset and bounds, score logits ~ N(0,2), semantics = ground
+    truth (SURVEY 8d).  Times Model.pred2mask(batch, pred, 'eval') over the whole batch; with `cpu`, scene 0 is
+    also run on the CPU oracle (oracle/nms_ref.py, pinned bit for bit to the reference) and compared."""
+    from box2mask_amd import synth
+    S = batch['input_location'].shape[0]
+    valid, id2idx, _, is_fg = synth.scannet_tables()
+    pred, sem_idx = synthetic_votes(batch, cfg)
     cpu_batch = dict(batch)
     for k in ('input_location', 'batch_ids'):
         cpu_batch[k] = batch[k].cpu()
@@ -732,9 +743,16 @@ def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10
     was_training = model.detection_model.training
     model.eval()
 
+    votes, _ = synthetic_votes(batch, cfg, seed=8)
+    cpu_batch = dict(batch)
+    for k in ('input_location', 'batch_ids'):
+        cpu_batch[k] = batch[k].cpu()
+
     def once(masks=True):
+        # the network's forward pass is the real one (its outputs come back to the host as in evaluation.py:86); the masks are
+        # made from synthetic votes of the same scene: a random-init network votes every segment into a cluster of its own
         pred = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=True)
-        return model.pred2mask(batch, pred, 'eval') if masks else pred
+        return model.pred2mask(cpu_batch, votes, 'eval') if masks else pred
     for _ in range(2):
         res = once()
     torch.cuda.synchronize()
@@ -779,8 +797,9 @@ def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10
         model.train()
     out = {'value': round(1.0 / dt, 3), 'unit': 'scenes/s', 'ms_per_scene': round(dt * 1e3, 3),
            'ms_forward': round(dt_fwd * 1e3, 3), 'voxels': n_vox, 'instances': int(sum(len(r['conf']) for r in res.values())),
-           'flow': "batch_size 1: Model.get_prediction(batch, with_grad=False) + Model.pred2mask(batch, pred, 'eval') "
-                   '(evaluation.py:70-98); predictions and masks returned to the host',
+           'flow': "batch_size 1: Model.get_prediction(batch, with_grad=False) [real forward, outputs to the host] + "
+                   "Model.pred2mask(batch, votes, 'eval') on synthetic votes of the same scene (evaluation.py:70-98); masks "
+                   'returned to the host',
            'launches_forward': int(sum(launches.values())),
            'fused_conv_bn_launches': int(launches.get('b2m_conv_fwd_affine', 0)),
            'batchnorm_launches': int(launches.get('b2m_bn_apply', 0) + launches.get('b2m_bn_apply2', 0)),
