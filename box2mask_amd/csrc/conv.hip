@@ -979,6 +979,18 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 fo.grid = (unsigned)(8 * B2M_XCD_CAP(a.ntiles) * a.wg_per_tile);
             }
             const int dbg = env_flag("B2M_PIPE_DBG", 0);      // diagnostic builds, wrong results: tools/pipe_breakdown.py
+            const int hl = env_flag("B2M_CONV_HANDLOADS", 1);     // hand-issued operand loads, absent row groups masked (conv_fwd_flow.h)
+            if (hl && depth == 2 && !dbg) {
+                if (wpb == 4) {
+                    if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4, 1><<<fo.grid, 256, 0, st>>>(a);
+                    else conv_fwd_flow_kernel<2, 2, 0, 4, 1><<<fo.grid, 256, 0, st>>>(a);
+                } else {
+                    if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 1, 1><<<fo.grid, 64, 0, st>>>(a);
+                    else conv_fwd_flow_kernel<2, 2, 0, 1, 1><<<fo.grid, 64, 0, st>>>(a);
+                }
+                B2M_LAUNCH_CHECK();
+                return B2M_OK;
+            }
             if (wpb == 4) {
                 if (depth == 2) {
                     if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4><<<fo.grid, 256, 0, st>>>(a);

@@ -64,7 +64,14 @@ __device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float
 // tile's active offsets are dealt round-robin to nslice / ncs slices and the input-channel chunks to ncs parts; the
 // waves add their strips up in LDS behind one barrier and wave 0 writes (plain stores for exactly 4 slices, else fp32
 // atomics into the pre-zeroed Y).
-template <int D, int TW, int DBG = 0, int WPB = 1>
+// HL = 1 (round 4): the operand loads of the hot loop are issued by hand -- asm statements with the waits counted here, not
+// by hipcc -- so that the gather of an ABSENT row group can run with one active lane.  Every step still issues NG + TW
+// vector loads (a static count: the waits stay exact), but a 16-byte-per-lane load occupies the CU's vector-memory return
+// path for ~22 cycles whatever it reads (tools/micro/mfma_loads.hip: 46 B/clk per CU), and with 4 + TW full-width loads
+// per step the one-group steps -- a third of all steps on the benchmark's maps -- were bound by that path, not by their
+// 12 * TW MFMAs.  A conditional (branchy) narrow load in C++ loses hipcc's counted waits (vmcnt(0) in front of every MFMA
+// block); the EXEC mask around ONE load instruction keeps the instruction count and costs two scalar moves.
+template <int D, int TW, int DBG = 0, int WPB = 1, int HL = 0>
 __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
     constexpr int KS = 4;                     // k-steps per 16-channel chunk == floats per lane per gathered row
     constexpr int SW = 16 * TW;               // output channels per strip
@@ -152,6 +159,17 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             r_in = a.rb_in[base];
             r_out = a.rb_out[base];
         };
+        // the same fetch issued by hand (HL): consumed one offset later behind `s_waitcnt vmcnt(D * (NG + TW))` -- at least that
+        // many operand loads are younger -- instead of hipcc's vmcnt(0), which cannot see the hand-issued loads and would drain
+        // all of them at every offset advance
+        const uint32_t lane4 = (uint32_t)lane * 4u;
+        auto list_load_hl = [&](int k, int& r_in, int& r_out) {
+            const int64_t base = (int64_t)k * ldr + row0;                  // wave-uniform
+            const int32_t* pin = a.rb_in + base;
+            const uint8_t* pout = a.rb_out + base;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(r_in) : "v"(lane4), "s"(pin) : "memory");
+            asm volatile("global_load_ubyte %0, %1, %2" : "=v"(r_out) : "v"((uint32_t)lane), "s"(pout) : "memory");
+        };
         auto list_words = [&](int r_in, int r_out, uint32_t (&w)[NG]) {
             const uint32_t word = r_in < 0 ? ((uint32_t)B2M_TILE << 24) : ((uint32_t)r_in | ((uint32_t)r_out << 24));
 #pragma unroll
@@ -170,9 +188,17 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             ld4 = first ? ld1 : ld2;
             return (const char*)(first ? a.x1 + (c << 4) : a.x2 + ((c - nch1) << 4));
         };
-        auto gather = [&](int j, int g, const char* src, uint32_t ld4, uint32_t word) {
+        // `present` (wave-uniform): the step that will consume this buffer has row group g
+        auto gather = [&](int j, int g, const char* src, uint32_t ld4, uint32_t word, bool present) {
             const uint32_t off = __umul24(word & 0xFFFFFFu, ld4) + q16;
-            const f32x4 v = *(const f32x4*)(src + off);
+            f32x4 v;
+            if constexpr (HL) {
+                const uint64_t em = present ? ~0ull : 1ull;                 // absent group: one lane fetches, the rest keep stale registers
+                asm volatile("s_mov_b64 exec, %3\n\tglobal_load_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                             : "=v"(v) : "v"(off), "s"(src), "s"(em) : "memory");
+            } else {
+                v = *(const f32x4*)(src + off);
+            }
             av[j][g][0] = v[0]; av[j][g][1] = v[1]; av[j][g][2] = v[2]; av[j][g][3] = v[3];
         };
         auto weights = [&](int j, int k, int c) {
@@ -181,7 +207,14 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             float wv[TW * KS];
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
-                const f32x4 w4 = *(const f32x4*)(wsrc + (wlo + 1024u * u));
+                f32x4 w4;
+                if constexpr (HL) {
+                    if (u == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w4) : "v"(wlo), "s"(wsrc) : "memory");
+                    else if (u == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w4) : "v"(wlo), "s"(wsrc) : "memory");
+                    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(w4) : "v"(wlo), "s"(wsrc) : "memory");
+                } else {
+                    w4 = *(const f32x4*)(wsrc + (wlo + 1024u * u));
+                }
                 wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
             }
 #pragma unroll
@@ -203,16 +236,17 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             list_words(r0i, r0o, wC);
             list_words(r1i, r1o, wN);
         }
-        int GC = groups_of(kC);
+        int GC = groups_of(kC), GN = groups_of(kNc);
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             uint32_t ld4;
             const char* src = src_of(cb + j, ld4);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) gather(j, g, src, ld4, wC[g]);
+            for (int g = 0; g < NG; ++g) gather(j, g, src, ld4, wC[g], g < GC);
             weights(j, kC, cb + j);
         }
-        list_load(kNN < 0 ? kNc : kNN, rawi, rawo);       // behind the step loads, as in the steady state
+        if constexpr (HL) list_load_hl(kNN < 0 ? kNc : kNN, rawi, rawo);
+        else list_load(kNN < 0 ? kNc : kNN, rawi, rawo);  // behind the step loads, as in the steady state
 
         f32x4 acc[NG][TW];
 #pragma unroll
@@ -263,6 +297,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                 uint32_t wT[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) wT[g] = wrap ? wN[g] : wC[g];
+                const int GT = wrap ? GN : GC;                              // row groups of the offset the prefetches target
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
                     // step in buffer j: the MFMAs of row group g, then at once the gather that refills the group's
@@ -272,8 +307,16 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                     const char* src = src_of(cT + j, ld4);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        if constexpr (!(DBG & 8)) { if (g < GC) mfma_group(j, g); }   // wave-uniform
-                        if constexpr (!(DBG & 2)) gather(j, g, src, ld4, wT[g]);
+                        if constexpr (!(DBG & 8)) {
+                            if (g < GC) {                                   // wave-uniform
+                                // hand-issued loads: the operands of this step are complete when all but the loads issued
+                                // since -- the other D - 1 buffers' NG + TW, and this step's g refills -- have landed (the
+                                // compiler-tracked pair-list loads in between only make this wait a little early)
+                                if constexpr (HL) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * (NG + TW) + g) : "memory");
+                                mfma_group(j, g);
+                            }
+                        }
+                        if constexpr (!(DBG & 2)) gather(j, g, src, ld4, wT[g], g < GT);
                     }
                     if constexpr (!(DBG & 4)) weights(j, kT, cT + j);
                 }
@@ -306,11 +349,16 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
 #pragma unroll
             for (int g = 0; g < NG; ++g) wC[g] = wN[g];
             kN = kNN; kNc = kN < 0 ? kC : kN;
-            GC = groups_of(kC);
+            GC = GN; GN = groups_of(kNc);
+            if constexpr (HL) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rawi), "+v"(rawo) : "n"(D * (NG + TW)) : "memory");
             list_words(rawi, rawo, wN);
             kNN = kN < 0 ? -1 : next_active(kN);
-            list_load(kNN < 0 ? kNc : kNN, rawi, rawo);
+            if constexpr (HL) list_load_hl(kNN < 0 ? kNc : kNN, rawi, rawo);
+            else list_load(kNN < 0 ? kNc : kNN, rawi, rawo);
         }
+        // hand-issued loads: the last round's prefetches are still in flight and the compiler, which cannot see them, is about
+        // to reuse their destination registers (addresses of the write-out!): drain them first
+        if constexpr (HL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
 
