@@ -40,6 +40,8 @@ def _close(a, b, what, tol=TOL):
 REGIMES = {
     'unsplit': {'B2M_CONV_TARGET': '0'},
     'unsplit_three_steps_in_flight': {'B2M_CONV_TARGET': '0', 'B2M_CONV_PIPE': '3'},
+    'unsplit_compiler_tracked_loads': {'B2M_CONV_TARGET': '0', 'B2M_CONV_HANDLOADS': '0'},
+    'split_compiler_tracked_loads': {'B2M_CONV_HANDLOADS': '0'},
     'unsplit_32_column_strips': {'B2M_CONV_TARGET': '0', 'B2M_CONV_TW3': '0'},
     'atomic_combine': {'B2M_CONV_WGCOMBINE': '0'},
     'no_chunk_slices': {'B2M_CONV_CHUNKSPLIT': '0'},

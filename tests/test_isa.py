@@ -23,10 +23,14 @@ def kernels():
 
 # mangled name -> (max VGPRs, waves per SIMD, needs counted waits in the MFMA loop)
 PINNED = {
-    '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1EEv8ConvArgs': (168, 3, True),       # forward / data gradient, 48-column strips
-    '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1EEv8ConvArgs': (128, 4, True),       # 32-column strips
-    '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi4EEv8ConvArgs': (168, 3, True),       # split maps (4 slices per workgroup)
-    '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi4EEv8ConvArgs': (128, 4, True),
+    # forward / data gradient, hand-issued loads (the shipped variants): 48- and 32-column strips, un-split and 4 slices per workgroup
+    '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1ELi1EEv8ConvArgs': (168, 3, True),
+    '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi1EEv8ConvArgs': (128, 4, True),
+    '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi4ELi1EEv8ConvArgs': (168, 3, True),
+    '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi4ELi1EEv8ConvArgs': (128, 4, True),
+    # ... and with hipcc-tracked loads (B2M_CONV_HANDLOADS=0, three steps in flight, diagnostics)
+    '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1ELi0EEv8ConvArgs': (168, 3, True),
+    '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi0EEv8ConvArgs': (128, 4, True),
     '_Z22conv_wgrad_flow_kernelILi3ELi3EEv9WgradArgs': (88, 5, True),         # weight gradient, 48 x 48 blocks
     '_Z22conv_wgrad_flow_kernelILi4ELi4EEv9WgradArgs': (128, 4, True),        # 64 x 64 blocks
     '_Z22conv_wgrad_flow_kernelILi2ELi2EEv9WgradArgs': (64, 8, True),
@@ -48,3 +52,25 @@ def test_hot_kernel_resources(kernels, name):
     if counted:
         assert k['loop_waits'], name
         assert 0 not in k['loop_waits'], 's_waitcnt vmcnt(0) inside the MFMA loop of %s: %s' % (name, k['loop_waits'])
+
+
+def test_hand_issued_loads_of_the_flow_kernel(kernels):
+    """conv_fwd_flow_kernel<.., HL = 1> issues its operand loads as asm statements hipcc cannot see: (i) every load of an
+    absent row group sits between an EXEC write and its restore, (ii) the waits in front of the MFMA blocks are the counted
+    ones of conv_fwd_flow.h -- (D - 1) * (NG + TW) + g -- and the pair-list wait is D * (NG + TW), (iii) the loads still in
+    flight when the offset loop ends are drained (vmcnt(0)) before the registers are reused for the write-out."""
+    import isa_check
+    text = open(isa_check.device_asm()).read()
+    for tw, name in ((3, '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1ELi1EEv8ConvArgs'), (2, '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi1EEv8ConvArgs')):
+        body = text[text.index(name + ':'):]
+        body = body[:body.index('.end_amdhsa_kernel')].split('\n')
+        mf = [i for i, l in enumerate(body) if 'v_mfma' in l]
+        masked = [i for i, l in enumerate(body) if 's_mov_b64 exec, s[' in l]
+        assert len(masked) >= 16                                  # 4 gathers x 2 buffers, prologue + loop
+        for i in masked:
+            assert 'global_load_dwordx4' in body[i + 1] and 's_mov_b64 exec, -1' in body[i + 2], body[i:i + 3]
+        waits = kernels[name]['loop_waits']
+        base = 4 + tw
+        assert set(waits) <= {base, base + 1, base + 2, base + 3, 2 * base}, waits
+        after = body[mf[-1]:]
+        assert any('s_waitcnt vmcnt(0)' in l for l in after[:400]), 'no drain of the in-flight loads behind the offset loop'
