@@ -113,7 +113,7 @@ extern "C" int b2m_debug_clocks(unsigned long long* out8, int reset) {
 // traffic 3.6x the algorithmic bytes of conv_fwd).  The work is cut into chunks of `chunk` workgroups and XCD x takes
 // chunks x, x+8, x+16, ...: hardware workgroup b = 8*j + x does work item ((j / chunk) * 8 + x) * chunk + j % chunk.
 // Default: one chunk per XCD (contiguous eighths).  Work per tile varies over a scene, so the eighths differ in total
-// work (up to 8 % on 4 scenes, 5 % on the 8 scenes of the benchmark); finer chunks (B2M_XCD_TILES=32) even that out
+// work (up to 8 % on 4 scenes, 5 % on the 8 scenes of the benchmark); finer chunks (32 tiles) even that out
 // but measured 0-2 % SLOWER in the training step -- L2 locality is worth more than the balance
 // (profiles/r02_conv_analysis.md).
 struct XcdOrder { int64_t chunk; unsigned grid; };
@@ -929,8 +929,8 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
         B2M_HIP(hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)cout * sizeof(float), (size_t)n_out, st));
     const int64_t items = items0 * nslice;
     a.nwg = cdiv64(items, 4);
-    // XCD chunks of B2M_XCD_TILES tiles (default: contiguous eighths): a workgroup holds 4 (tile, strip, slice) items
-    const int64_t xcd_tiles = env_flag("B2M_XCD", 1) ? env_flag("B2M_XCD_TILES", 1 << 30) : 0;
+    // XCD-aware order: contiguous eighths; a workgroup holds 4 (tile, strip, slice) items
+    const int64_t xcd_tiles = env_flag("B2M_XCD", 1) ? (1 << 30) : 0;        // (finer chunks measured equal or slower: one run per XCD)
     const XcdOrder xo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / 4);
     a.xcd_per = xo.chunk;
     const unsigned grid = xo.grid;
@@ -1039,7 +1039,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     const int variant = (KC == 16 ? 4 : 0) | (ident ? 2 : 0) | (fast ? 0 : 1);
     // chunks of loads in flight per wave: 2 pays on the 48-column-strip layers with >= 4 chunks (+7 % in the A/B of
     // tools/bench_conv.py), 1 elsewhere (narrow / 1x1 layers lose occupancy with 2)
-    const int npf = env_flag("B2M_CONV_NPF", (TW == 3 && cin >= 64) ? 2 : 1);
+    const int npf = (TW == 3 && cin >= 64) ? 2 : 1;
 #define B2M_CONV_LAUNCH(KCV, ID, AS, NPFV)                                                                 \
     do {                                                                                                   \
         if (TW == 3) conv_fwd_kernel<KCV, ID, AS, NPFV, 3><<<grid, 256, 0, st>>>(a);                       \
@@ -1530,8 +1530,8 @@ static int env_flag(const char* name, int dflt) { return b2m_env_int(name, dflt)
 static int pick_blk(int c) {      // 16-column sub-tiles per wave block
     // 64 channels: four 32x32 blocks keep all 4 waves of a workgroup busy and fit the pipelined kernel at full
     // occupancy (+27..35 % over one 64x64 block)
-    if (c == 64) return env_flag("B2M_WGRAD_BLK64", 2);
-    if (c % 64 == 0) return env_flag("B2M_WGRAD_BLKBIG", 4);
+    if (c == 64) return 2;
+    if (c % 64 == 0) return 4;
     if (c % 48 == 0) return 3;
     if (c % 32 == 0) return 2;
     if (c <= 16) return 1;
@@ -1585,7 +1585,7 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     // the same cut on the 1 k-tile level-2 maps LOSES 20 %: there the atomics of twice as many waves weigh more).
     const int64_t blocks_per_chunk = (int64_t)K * a.nmb * a.nnb;
     const bool large = a.ntiles >= 2048;
-    int64_t want_chunks = cdiv64(env_flag("B2M_WGRAD_TARGET", large ? 32768 : 16384), blocks_per_chunk);
+    int64_t want_chunks = cdiv64(large ? 32768 : 16384, blocks_per_chunk);
     if (want_chunks < 1) want_chunks = 1;
     int64_t tpc = cdiv64(a.ntiles, want_chunks);
     // (floor 8 from 32 tiles up: level-3 128->128 58 -> 66, level-4 256->256 58 -> 67 TFLOP/s; the 11-tile level-5 maps lose
@@ -1594,7 +1594,7 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     // on 256 CUs, 40 us per launch; one block's atomics per 2 tiles are nothing against that)
     const int min_tiles = env_flag("B2M_WGRAD_MIN_TILES", (rb_in == nullptr && a.ntiles <= 1024) ? 2 : a.ntiles >= 32 ? 8 : 4);
     if (tpc < min_tiles) tpc = min_tiles;
-    { int mx = env_flag("B2M_WGRAD_MAX_TILES", large ? 32 : 64); if (mx < 1) mx = 1; if (mx > 64) mx = 64; if (tpc > mx) tpc = mx; }
+    { const int mx = large ? 32 : 64; if (tpc > mx) tpc = mx; }
     // Deterministic mode (workspace given): at most B2M_WGRAD_DET_CHUNKS tile chunks, every chunk stores its partial
     // blocks plainly and a second kernel adds them up in chunk order -- no atomics, the same bits on every run.
     a.partial = workspace;
@@ -1608,8 +1608,8 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     a.nwg = (int64_t)a.kgroups * cdiv64(a.ntiles, tpc) * a.nz;
     B2M_CHECK_ARG(a.nwg < (1ll << 31) - 8, "too many workgroups");
     // work item = (k fastest, block group, tile chunk): a chunk of the XCD order = all offsets and blocks of
-    // B2M_XCD_WG_CHUNKS tile chunks (default: contiguous eighths)
-    const XcdOrder xo = xcd_order(a.nwg, env_flag("B2M_XCD", 1) ? (int64_t)env_flag("B2M_XCD_WG_CHUNKS", 1 << 20) * a.kgroups * a.nz : 0);
+    // tile chunks of one eighth (contiguous)
+    const XcdOrder xo = xcd_order(a.nwg, env_flag("B2M_XCD", 1) ? (int64_t)(1 << 20) * a.kgroups * a.nz : 0);
     a.xcd_per = xo.chunk;
     dim3 grid(xo.grid);
     // XCD runs of equal work (the tail of rb_cnt, b2m_rulebook_balance), each cut into tile chunks from its own start

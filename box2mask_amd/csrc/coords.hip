@@ -390,7 +390,7 @@ __device__ __forceinline__ void rulebook_runs(const int32_t* __restrict__ cost, 
 // conv_fwd_flow wave owns a tile for all of its offsets, and tiles differ 10x in cost (interior tiles: 27 offsets x 4 row
 // groups; surface tiles a third of that): in plain row order the launch ends with a few waves still inside heavy tiles
 // they took last -- up to 0.3 ms of a 2.3 ms launch with most SIMDs idle.  The last `window` positions of every run are
-// therefore ordered by cost class, heaviest first (B2M_XCD_CLASSES classes of equal width below the run's largest cost,
+// therefore ordered by cost class, heaviest first (8 classes of equal width below the run's largest cost,
 // stable: row order inside a class, so neighbouring tiles of a class still run together); the positions before the
 // window keep the row order and with it all of the L2 locality.
 #define ORDER_MAX_CLASSES 8
@@ -473,10 +473,10 @@ extern "C" int b2m_rulebook_balance(int32_t* rb_cnt, int32_t K, int64_t n_out, v
     const int64_t ntiles = cdiv64(n_out, B2M_TILE);
     if (ntiles < B2M_BALANCE_MIN_TILES) return B2M_OK;     // (the convolutions use the tail from that many tiles on)
     rulebook_cost_kernel<<<(unsigned)cdiv64(ntiles, 256), 256, 0, st>>>(rb_cnt, K, ntiles);
-    int ncls = coords_env("B2M_XCD_CLASSES", 8);
+    int ncls = 8;                      // cost classes and window: 4 .. 16 classes, 256 .. 2048 positions measured equal
     if (ncls < 1) ncls = 1;
     if (ncls > ORDER_MAX_CLASSES) ncls = ORDER_MAX_CLASSES;
-    rulebook_order_kernel<<<8, 1024, 0, st>>>(rb_cnt, K, ntiles, coords_env("B2M_XCD_WINDOW", 768), ncls);
+    rulebook_order_kernel<<<8, 1024, 0, st>>>(rb_cnt, K, ntiles, 768, ncls);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

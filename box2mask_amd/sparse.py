@@ -163,7 +163,7 @@ class CoordinateManager:
             K = ksize ** 3
             occ = self._occupancy() if (level == 0 and ksize > 1) else None
             occ_args = (occ[0].data_ptr(), occ[1], occ[2], occ[3]) if occ else (None, 0, 0, 0)
-            if self.keep_tables or os.environ.get('B2M_FUSED_MAP', '1') == '0':        # tests compare the neighbour table itself
+            if self.keep_tables:        # tests compare the neighbour table itself
                 nbr = torch.empty((K, max(n, 1)), dtype=torch.int32, device=self.device)
                 _lib.call('b2m_kernel_map', c.data_ptr(), n, ksize, 1 << level, keys.data_ptr(), vals.data_ptr(), cap,
                           *occ_args, nbr.data_ptr(), nbr.shape[1])

@@ -2,10 +2,10 @@
 tuning switches inside one process (same device, same clocks).
 
     python tools/bench_conv.py                       # base vs the variants below
-    VARIANTS="tw2:B2M_CONV_TW3=0;npf2:B2M_CONV_NPF=2" python tools/bench_conv.py
+    VARIANTS="tw2:B2M_CONV_TW3=0;old:B2M_CONV_HANDLOADS=0" python tools/bench_conv.py
 
-Switches read by csrc/conv.hip at every call: B2M_CONV_TW3 (48-column strips), B2M_CONV_NPF (chunks of loads in
-flight), B2M_CONV_FAST32 / B2M_WGRAD_FAST32 (24-bit multiply addressing)."""
+Switches are re-read by the library per variant (b2m_reload_env): B2M_CONV_TW3 (48-column strips), B2M_CONV_HANDLOADS
+(hand-issued loads), B2M_CONV_FAST32 / B2M_WGRAD_FAST32 (24-bit multiply addressing), ...."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -35,7 +35,7 @@ for spec in os.environ.get('VARIANTS', 'tw2:B2M_CONV_TW3=0;slow64:B2M_WGRAD_FAST
     if spec:
         name, kvs = spec.split(':')
         VARIANTS.append((name, dict(kv.split('=') for kv in kvs.split(','))))
-SWITCHES = ('B2M_CONV_HANDLOADS', 'B2M_PIPE_LDS', 'B2M_PIPE_DBG', 'B2M_CONV_STEM', 'B2M_XCD_WINDOW', 'B2M_XCD_CLASSES', 'B2M_WGRAD_NARROW', 'B2M_WGRAD_PIPE_IDENT', 'B2M_WGRAD_KPACK', 'B2M_WGRAD_TARGET', 'B2M_WGRAD_MAX_TILES', 'B2M_CONV_1X1', 'B2M_XCD_ORDER', 'B2M_XCD_BALANCE', 'B2M_CONV_FLOW_SPLIT', 'B2M_XCD_TILES', 'B2M_XCD_WG_CHUNKS', 'B2M_CONV_PIPE', 'B2M_CONV_TW3', 'B2M_CONV_NPF', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_WGRAD_BLK64', 'B2M_WGRAD_BLKBIG')
+SWITCHES = ('B2M_CONV_HANDLOADS', 'B2M_PIPE_LDS', 'B2M_PIPE_DBG', 'B2M_CONV_STEM', 'B2M_WGRAD_NARROW', 'B2M_WGRAD_PIPE_IDENT', 'B2M_WGRAD_KPACK', 'B2M_CONV_1X1', 'B2M_XCD_ORDER', 'B2M_XCD_BALANCE', 'B2M_CONV_FLOW_SPLIT', 'B2M_CONV_PIPE', 'B2M_CONV_TW3', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_CONV_MAXSLICE')
 cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
          ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
          ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64),
