@@ -1,7 +1,8 @@
 #!/bin/bash
 # All profile artefacts of a round in one go (run on the GPU box from the repository root):
 #   tools/final_profiles.sh <outdir>
-# 1. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` (the driver's command) -> kernel_stats.csv, summary.md
+# 1. rocprofv3 --kernel-trace --stats of `python3 bench.py --inference 0` (the driver's command without the batch-size-1
+#    inference leg, whose launches would be averaged into the per-step table) -> kernel_stats.csv, summary.md
 # 2. the same with B2M_WGRAD_STREAM=0 B2M_BENCH_PREFETCH=0 (one stream: a kernel's duration is its own) -> *_one_stream.*
 # 3. two PMC passes (FETCH_SIZE / WRITE_SIZE, kernel-trace only) of one bench step, one stream  -> traffic.json
 # 4. PMC passes of the conv micro-benchmark (tools/pmc_passes.sh)                               -> pmc/summary.txt
@@ -12,7 +13,7 @@ root=$(pwd)
 stats() {   # $1 = tag, rest = env assignments
   tag=$1; shift
   (cd /tmp; for kv in "$@"; do export "$kv"; done; \
-   rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_$tag -- python3 $root/bench.py > $root/$out/bench_$tag.log 2>&1)
+   rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_$tag -- python3 $root/bench.py --inference 0 > $root/$out/bench_$tag.log 2>&1)
   f=$(find $out/prof_$tag -name "*kernel_stats.csv" | head -1)
   cp $f $out/kernel_stats_$tag.csv
   python3 tools/profile_summary.py $out/kernel_stats_$tag.csv $out/bench_$tag.log > $out/summary_$tag.md
@@ -23,7 +24,7 @@ stats default
 stats one_stream B2M_WGRAD_STREAM=0 B2M_BENCH_PREFETCH=0
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && export B2M_WGRAD_STREAM=0 B2M_BENCH_PREFETCH=0 && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/$out/pmc_$c -- \
-     python3 $root/bench.py --steps 1 --warmup 1 --cpu-baseline 0 --votes 1 --prepare 0 > $root/$out/pmc_$c.log 2>&1)
+     python3 $root/bench.py --steps 1 --warmup 1 --cpu-baseline 0 --votes 1 --prepare 0 --inference 0 > $root/$out/pmc_$c.log 2>&1)
 done
 python3 tools/pmc_traffic.py $(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
     $(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) > $out/traffic.json
