@@ -1109,6 +1109,7 @@ struct WgradArgs {
     int kpack;                // offsets per workgroup: 1, or -- layers with only 1 or 2 (ci, co) blocks -- 4 or 2: the waves
                               // a single block would leave idle take the neighbouring offsets of the same tile chunk
     int kgroups;              // ceil(K / kpack)
+    int handloads;            // conv_wgrad_flow_kernel<.., HL = 1> (B2M_WGRAD_HANDLOADS)
 };
 // work item of a wave -> (offset k, block blk, tile range [t0, t1)); false: nothing to do.  A workgroup is (offset group,
 // block group, tile chunk); its 4 waves are 4 blocks of one offset (kpack = 1) or 4 / kpack blocks of kpack consecutive
@@ -1280,8 +1281,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchun
 //    accumulators in AGPRs and copied all of them to VGPRs and back around every slot (108 moves per 36 MFMAs);
 //  * each slot issues the same number of loads (k-steps without pairs gather row 0: L1 hits), so the counted waits
 //    in front of the MFMAs are exact; the loads that refill a k-step's registers follow its MFMAs directly.
-template <int MI, int NJ>
+// HL = 1 (real rulebook) / 2 (identity map) -- round 4, 48 x 48 and 64 x 64 blocks: the operand and pair-list loads are issued
+// by hand, as in conv_fwd_flow_kernel -- a k-step's MI + NJ loads sit in ONE EXEC window that holds the lanes whose pair exists
+// (a slot's missing pairs and empty k-steps fetch nothing: 14 % of the loads on the benchmark's maps), the waits are counted
+// here: the operands of k-step s are complete when all but the 3 (MI + NJ) refills (+ the 2 list loads of a real rulebook)
+// issued since have landed.  Every register such a load writes is read ONLY by the asm statement that waits for it (hipcc
+// knows nothing of the load in flight: handed the register any earlier -- as the in/out operand of a bare wait, say -- it is
+// free to copy it first, and did: tests/test_isa.py follows the registers through the assembly).
+template <int MI, int NJ, int HL = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
+    static_assert(!HL || (MI == NJ && (MI == 3 || MI == 4)), "hand-issued loads: 48 x 48 and 64 x 64 blocks");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
@@ -1292,7 +1301,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int nt = (int)(t1 - t0);                       // <= 64 tiles: lane t holds the pair count of tile t0 + t
-    const bool ident = a.rb_in == nullptr;               // identity map (1x1 layers): pair j of a tile is (row j, row j)
+    // identity map (1x1 layers): pair j of a tile is (row j, row j).  (Hand-issued loads: a compile-time property -- an identity
+    // map has no list loads, and the counted waits differ by those two.)
+    const bool ident = HL ? HL == 2 : a.rb_in == nullptr;
     int cnt = 0;
     if (lane < nt) {
         if (ident) { const int64_t rem = a.n_out - (t0 + lane) * B2M_TILE; cnt = rem < B2M_TILE ? (int)rem : B2M_TILE; }
@@ -1323,6 +1334,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
         r_in = a.rb_in[base];
         r_out = a.rb_out[base];
     };
+    auto load_list_hl = [&](int ti, int g, int& r_in, int& r_out) {      // (real rulebooks: HL == 1)
+        const int64_t base = kbase + (int64_t)ti * B2M_TILE + 16 * g;      // wave-uniform
+        const int32_t* pin = a.rb_in + base;
+        const uint8_t* pout = a.rb_out + base;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(r_in) : "v"((uint32_t)i * 4u), "s"(pin) : "memory");
+        asm volatile("global_load_ubyte %0, %1, %2" : "=v"(r_out) : "v"((uint32_t)i), "s"(pout) : "memory");
+    };
     // the word of pair 4s + q for k-step s
     auto words = [&](int r_in, int r_out, uint32_t (&w)[4]) {
         const uint32_t word = r_in < 0 ? 0x80000000u : ((uint32_t)r_in | ((uint32_t)r_out << 24));
@@ -1332,6 +1350,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     const uint32_t ldx4 = (uint32_t)a.ldx * 4u, lddy4 = (uint32_t)a.lddy * 4u;
     const uint32_t cxb = (uint32_t)(ci0 + i) * 4u, cyb = (uint32_t)(co0 + i) * 4u;
     float av[4][MI], bv[4][NJ];
+    if constexpr (HL != 0) {
+        // hand-issued loads take their destination as an IN/OUT operand: the previous content stays alive, in that register, up to
+        // the load.  (As a plain output the register is dead to hipcc from its last use on -- and the last use, the wait of a
+        // k-step without pairs, may have been skipped with the load still in flight: the next address computation landed there.)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int m = 0; m < MI; ++m) av[s][m] = 0.f;
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) bv[s][n] = 0.f;
+        }
+    }
     // operands of k-step s of the slot in tile ti (MI + NJ loads, always)
     auto gather = [&](int s, int ti, uint32_t word) {
         const uint32_t row0 = (uint32_t)((t0 + ti) * B2M_TILE);
@@ -1339,10 +1369,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
         const uint32_t by = __umul24(row0 + ((word >> 24) & 63u), lddy4) + cyb;
         const char* px = (const char*)a.x + bx;
         const char* py = (const char*)a.dy + by;
+        if constexpr (HL) {
+            // lanes whose pair exists (bit 31 of the word clear); at least lane 0, so that the loads are always issued
+            const uint64_t em = __ballot((int)word >= 0) | 1ull;
+            if constexpr (MI == 3) {
+                asm volatile("s_mov_b64 exec, %10\n\t"
+                             "global_load_dword %0, %6, %8\n\tglobal_load_dword %1, %6, %8 offset:64\n\tglobal_load_dword %2, %6, %8 offset:128\n\t"
+                             "global_load_dword %3, %7, %9\n\tglobal_load_dword %4, %7, %9 offset:64\n\tglobal_load_dword %5, %7, %9 offset:128\n\t"
+                             "s_mov_b64 exec, -1"
+                             : "+v"(av[s][0]), "+v"(av[s][1]), "+v"(av[s][2]), "+v"(bv[s][0]), "+v"(bv[s][1]), "+v"(bv[s][2])
+                             : "v"(bx), "v"(by), "s"(a.x), "s"(a.dy), "s"(em) : "memory");
+            } else {
+                asm volatile("s_mov_b64 exec, %12\n\t"
+                             "global_load_dword %0, %8, %10\n\tglobal_load_dword %1, %8, %10 offset:64\n\t"
+                             "global_load_dword %2, %8, %10 offset:128\n\tglobal_load_dword %3, %8, %10 offset:192\n\t"
+                             "global_load_dword %4, %9, %11\n\tglobal_load_dword %5, %9, %11 offset:64\n\t"
+                             "global_load_dword %6, %9, %11 offset:128\n\tglobal_load_dword %7, %9, %11 offset:192\n\t"
+                             "s_mov_b64 exec, -1"
+                             : "+v"(av[s][0]), "+v"(av[s][1]), "+v"(av[s][2]), "+v"(av[s][MI - 1]), "+v"(bv[s][0]), "+v"(bv[s][1]),
+                               "+v"(bv[s][2]), "+v"(bv[s][NJ - 1])
+                             : "v"(bx), "v"(by), "s"(a.x), "s"(a.dy), "s"(em) : "memory");
+            }
+        } else {
 #pragma unroll
-        for (int m = 0; m < MI; ++m) av[s][m] = *(const float*)(px + 64 * m);
+            for (int m = 0; m < MI; ++m) av[s][m] = *(const float*)(px + 64 * m);
 #pragma unroll
-        for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = *(const float*)(py + 64 * nn);
+            for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = *(const float*)(py + 64 * nn);
+        }
     };
     f32x4 acc[MI][NJ];
 #pragma unroll
@@ -1367,7 +1420,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     for (int s = 0; s < 4; ++s) gather(s, tiC, wC[s]);
     int tiNN = tiN, gNN = gN;
     bool hasNN = hasN && advance(tiNN, gNN);
-    load_list(hasNN ? tiNN : tiN, hasNN ? gNN : gN, rawi, rawo);
+    if (HL == 1) load_list_hl(hasNN ? tiNN : tiN, hasNN ? gNN : gN, rawi, rawo);
+    else load_list(hasNN ? tiNN : tiN, hasNN ? gNN : gN, rawi, rawo);
     if (!hasN) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) wN[s] = 0x80000000u;       // no next slot: the refills gather row 0 and are never used
@@ -1378,14 +1432,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < nkC) {                                       // wave-uniform
-                float bz[NJ];
+                float bz[NJ], az[MI];
+                if constexpr (HL) {
+                    // ONE statement waits for the k-step's operands and moves them (0 for a missing pair: the masked lanes'
+                    // registers are stale, possibly NaN) into the MFMA operands.  The loaded registers are plain INPUTS of
+                    // it: as in/out operands of a bare wait, hipcc copied them to fresh registers IN FRONT of the wait.
+                    const uint64_t pm = __ballot((int)wC[s] >= 0);
+                    if constexpr (MI == 3) {
+                        asm volatile("s_waitcnt vmcnt(%13)\n\t"
+                                     "v_cndmask_b32_e64 %0, 0, %6, %12\n\tv_cndmask_b32_e64 %1, 0, %7, %12\n\tv_cndmask_b32_e64 %2, 0, %8, %12\n\t"
+                                     "v_cndmask_b32_e64 %3, 0, %9, %12\n\tv_cndmask_b32_e64 %4, 0, %10, %12\n\tv_cndmask_b32_e64 %5, 0, %11, %12"
+                                     : "=&v"(az[0]), "=&v"(az[1]), "=&v"(az[2]), "=&v"(bz[0]), "=&v"(bz[1]), "=&v"(bz[2])
+                                     : "v"(av[s][0]), "v"(av[s][1]), "v"(av[s][2]), "v"(bv[s][0]), "v"(bv[s][1]), "v"(bv[s][2]), "s"(pm),
+                                       "n"(3 * (MI + NJ) + (HL == 1 ? 2 : 0)) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(%17)\n\t"
+                                     "v_cndmask_b32_e64 %0, 0, %8, %16\n\tv_cndmask_b32_e64 %1, 0, %9, %16\n\tv_cndmask_b32_e64 %2, 0, %10, %16\n\t"
+                                     "v_cndmask_b32_e64 %3, 0, %11, %16\n\tv_cndmask_b32_e64 %4, 0, %12, %16\n\tv_cndmask_b32_e64 %5, 0, %13, %16\n\t"
+                                     "v_cndmask_b32_e64 %6, 0, %14, %16\n\tv_cndmask_b32_e64 %7, 0, %15, %16"
+                                     : "=&v"(az[0]), "=&v"(az[1]), "=&v"(az[2]), "=&v"(az[MI - 1]), "=&v"(bz[0]), "=&v"(bz[1]), "=&v"(bz[2]),
+                                       "=&v"(bz[NJ - 1])
+                                     : "v"(av[s][0]), "v"(av[s][1]), "v"(av[s][2]), "v"(av[s][MI - 1]), "v"(bv[s][0]), "v"(bv[s][1]),
+                                       "v"(bv[s][2]), "v"(bv[s][NJ - 1]), "s"(pm), "n"(3 * (MI + NJ) + (HL == 1 ? 2 : 0)) : "memory");
+                    }
+                } else {
 #pragma unroll
-                for (int nn = 0; nn < NJ; ++nn) bz[nn] = (int)wC[s] >= 0 ? bv[s][nn] : 0.f;      // no pair: contributes 0
+                    for (int nn = 0; nn < NJ; ++nn) bz[nn] = (int)wC[s] >= 0 ? bv[s][nn] : 0.f;      // no pair: contributes 0
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) az[m] = av[s][m];
+                }
 #pragma unroll
                 for (int m = 0; m < MI; ++m)
 #pragma unroll
                     for (int nn = 0; nn < NJ; ++nn)
-                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(av[s][m]), "v"(bz[nn]));
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
             }
             asm volatile("" ::: "memory");                       // the refill stays behind the MFMAs that read the registers
             gather(s, tiN, wN[s]);
@@ -1397,14 +1477,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) wC[s] = wN[s];
         hasN = hasNN; tiN = tiNN; gN = gNN;
-        words(rawi, rawo, wN);
+        // (hand-issued list loads: one slot old, the 4 k-steps' refills are younger)
+        if constexpr (HL == 1) {   // (the loaded registers are inputs of the statement that waits for them, see above)
+            int li, lo;
+            asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(li), "=&v"(lo) : "v"(rawi), "v"(rawo),
+                         "n"(4 * (MI + NJ)) : "memory");
+            words(li, lo, wN);
+        } else words(rawi, rawo, wN);
         if (!hasN) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) wN[s] = 0x80000000u;
         }
         hasNN = hasN && advance(tiNN, gNN);
-        load_list(hasNN ? tiNN : tiN, hasNN ? gNN : gN, rawi, rawo);
+        if (HL == 1) load_list_hl(hasNN ? tiNN : tiN, hasNN ? gNN : gN, rawi, rawo);
+        else load_list(hasNN ? tiNN : tiN, hasNN ? gNN : gN, rawi, rawo);
     }
+    // hand-issued loads: the last refills are still in flight and hipcc is about to reuse their registers
+    if constexpr (HL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_nop 15" ::: "memory");          // MFMA result -> VALU / memory read: >= 12 wait states
 #pragma unroll
     for (int m = 0; m < MI; ++m)
@@ -1502,6 +1591,16 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restri
 template <int MI>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
     if (a.pipe) {
+        if (MI == NJ && (MI == 3 || MI == 4) && a.handloads) {
+            if constexpr (MI == 3) {
+                if (a.rb_in) conv_wgrad_flow_kernel<3, 3, 1><<<grid, 256, 0, st>>>(a);
+                else conv_wgrad_flow_kernel<3, 3, 2><<<grid, 256, 0, st>>>(a);
+            } else if constexpr (MI == 4) {
+                if (a.rb_in) conv_wgrad_flow_kernel<4, 4, 1><<<grid, 256, 0, st>>>(a);
+                else conv_wgrad_flow_kernel<4, 4, 2><<<grid, 256, 0, st>>>(a);
+            }
+            return;
+        }
         switch (NJ) {
             case 1: conv_wgrad_flow_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
             case 2: conv_wgrad_flow_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
@@ -1629,6 +1728,7 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     // same registers) stays on the plain kernel, where the builtin lets hipcc place whatever the dependence needs.
     a.pipe = (a.fast32 && (rb_in != nullptr || (n_in >= n_out && env_flag("B2M_WGRAD_PIPE_IDENT", 1))) && MI * NJ >= 2 &&
               !workspace && env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
+    a.handloads = env_flag("B2M_WGRAD_HANDLOADS", 1);
     launch_wgrad(MI, NJ, grid, st, a);
     if (workspace) {
         const int nchunks = (int)cdiv64(a.ntiles, tpc);

@@ -181,7 +181,22 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         const uint32_t ld1 = (uint32_t)a.ldx1 * 4u, ld2 = (uint32_t)a.ldx2 * 4u;
         const uint32_t wstrip = (uint32_t)strip * (uint32_t)NC;
         const uint32_t wkstride = (uint32_t)a.nstrips * (uint32_t)NC;
-        float av[D][NG][KS], bv[D][KS][TW];
+        // operand registers: buffer j holds row group g's four k-steps (one 16-byte gather) and the TW weight pieces; MFMA operand
+        // (k-step s, column tile t) of the weights is float TW * s + t of the buffer's TW pieces.  With hand-issued loads every
+        // load statement takes its destination as an IN/OUT operand: the previous content stays alive, in that very register, up
+        // to the load -- hipcc, which does not know that a skipped group's load may still be in flight, would otherwise hand the
+        // "dead" register to the next address computation (tests/test_isa.py traces this).
+        f32x4 av[D][NG], bw[D][TW];
+        if constexpr (HL) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) av[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < TW; ++u) bw[j][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#define B2M_BV(j, s, t) bw[j][(TW * (s) + (t)) >> 2][(TW * (s) + (t)) & 3]
         // loads of step (offset k, chunk c) into register buffer j: NG gathers + TW weight pieces, always
         auto src_of = [&](int c, uint32_t& ld4) -> const char* {
             const bool first = c < nch1;                                        // wave-uniform source select
@@ -191,36 +206,27 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         // `present` (wave-uniform): the step that will consume this buffer has row group g
         auto gather = [&](int j, int g, const char* src, uint32_t ld4, uint32_t word, bool present) {
             const uint32_t off = __umul24(word & 0xFFFFFFu, ld4) + q16;
-            f32x4 v;
             if constexpr (HL) {
                 const uint64_t em = present ? ~0ull : 1ull;                 // absent group: one lane fetches, the rest keep stale registers
                 asm volatile("s_mov_b64 exec, %3\n\tglobal_load_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, -1"
-                             : "=v"(v) : "v"(off), "s"(src), "s"(em) : "memory");
+                             : "+v"(av[j][g]) : "v"(off), "s"(src), "s"(em) : "memory");
             } else {
-                v = *(const f32x4*)(src + off);
+                av[j][g] = *(const f32x4*)(src + off);
             }
-            av[j][g][0] = v[0]; av[j][g][1] = v[1]; av[j][g][2] = v[2]; av[j][g][3] = v[3];
         };
         auto weights = [&](int j, int k, int c) {
             const uint32_t blk = (uint32_t)k * wkstride + wstrip + (uint32_t)c;     // wave-uniform
             const char* wsrc = (const char*)a.wp + (size_t)blk * (size_t)(LW * 4);
-            float wv[TW * KS];
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
-                f32x4 w4;
                 if constexpr (HL) {
-                    if (u == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w4) : "v"(wlo), "s"(wsrc) : "memory");
-                    else if (u == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w4) : "v"(wlo), "s"(wsrc) : "memory");
-                    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(w4) : "v"(wlo), "s"(wsrc) : "memory");
+                    if (u == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                    else if (u == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
                 } else {
-                    w4 = *(const f32x4*)(wsrc + (wlo + 1024u * u));
+                    bw[j][u] = *(const f32x4*)(wsrc + (wlo + 1024u * u));
                 }
-                wv[4 * u] = w4[0]; wv[4 * u + 1] = w4[1]; wv[4 * u + 2] = w4[2]; wv[4 * u + 3] = w4[3];
             }
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int t = 0; t < TW; ++t) bv[j][s][t] = wv[TW * s + t];
         };
 
         // ---- prologue: lists of the first three offsets, operands of the first D steps
@@ -269,8 +275,8 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                     "v_mfma_f32_16x16x4_f32 %0, %16, %6, %0\n\tv_mfma_f32_16x16x4_f32 %1, %17, %6, %1\n\tv_mfma_f32_16x16x4_f32 %2, %18, %6, %2"
                     : "+v"(acc[g][0]), "+v"(acc[g][1]), "+v"(acc[g][2])
                     : "v"(av[j][g][0]), "v"(av[j][g][1]), "v"(av[j][g][2]), "v"(av[j][g][3]),
-                      "v"(bv[j][0][0]), "v"(bv[j][0][1]), "v"(bv[j][0][2]), "v"(bv[j][1][0]), "v"(bv[j][1][1]), "v"(bv[j][1][2]),
-                      "v"(bv[j][2][0]), "v"(bv[j][2][1]), "v"(bv[j][2][2]), "v"(bv[j][3][0]), "v"(bv[j][3][1]), "v"(bv[j][3][2])
+                      "v"(B2M_BV(j, 0, 0)), "v"(B2M_BV(j, 0, 1)), "v"(B2M_BV(j, 0, 2)), "v"(B2M_BV(j, 1, 0)), "v"(B2M_BV(j, 1, 1)), "v"(B2M_BV(j, 1, 2)),
+                      "v"(B2M_BV(j, 2, 0)), "v"(B2M_BV(j, 2, 1)), "v"(B2M_BV(j, 2, 2)), "v"(B2M_BV(j, 3, 0)), "v"(B2M_BV(j, 3, 1)), "v"(B2M_BV(j, 3, 2))
                     : "memory");
             } else {
                 asm volatile(
@@ -280,8 +286,8 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                     "v_mfma_f32_16x16x4_f32 %0, %12, %5, %0\n\tv_mfma_f32_16x16x4_f32 %1, %13, %5, %1"
                     : "+v"(acc[g][0]), "+v"(acc[g][1])
                     : "v"(av[j][g][0]), "v"(av[j][g][1]), "v"(av[j][g][2]), "v"(av[j][g][3]),
-                      "v"(bv[j][0][0]), "v"(bv[j][0][1]), "v"(bv[j][1][0]), "v"(bv[j][1][1]),
-                      "v"(bv[j][2][0]), "v"(bv[j][2][1]), "v"(bv[j][3][0]), "v"(bv[j][3][1])
+                      "v"(B2M_BV(j, 0, 0)), "v"(B2M_BV(j, 0, 1)), "v"(B2M_BV(j, 1, 0)), "v"(B2M_BV(j, 1, 1)),
+                      "v"(B2M_BV(j, 2, 0)), "v"(B2M_BV(j, 2, 1)), "v"(B2M_BV(j, 3, 0)), "v"(B2M_BV(j, 3, 1))
                     : "memory");
             }
         };
@@ -350,8 +356,14 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             for (int g = 0; g < NG; ++g) wC[g] = wN[g];
             kN = kNN; kNc = kN < 0 ? kC : kN;
             GC = GN; GN = groups_of(kNc);
-            if constexpr (HL) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rawi), "+v"(rawo) : "n"(D * (NG + TW)) : "memory");
-            list_words(rawi, rawo, wN);
+            if constexpr (HL) {
+                // the statement that waits for the list is the only reader of the two loaded registers (as in/out operands of a
+                // bare wait hipcc may copy them IN FRONT of it: conv_wgrad_flow_kernel, round 4)
+                int li, lo;
+                asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(li), "=&v"(lo) : "v"(rawi), "v"(rawo),
+                             "n"(D * (NG + TW)) : "memory");
+                list_words(li, lo, wN);
+            } else list_words(rawi, rawo, wN);
             kNN = kN < 0 ? -1 : next_active(kN);
             if constexpr (HL) list_load_hl(kNN < 0 ? kNc : kNN, rawi, rawo);
             else list_load(kNN < 0 ? kNc : kNN, rawi, rawo);
@@ -415,3 +427,4 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     B2M_CLOCK_END(0);
 }
 #undef tile_column_sums
+#undef B2M_BV

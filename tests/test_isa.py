@@ -31,9 +31,15 @@ PINNED = {
     # ... and with hipcc-tracked loads (B2M_CONV_HANDLOADS=0, three steps in flight, diagnostics)
     '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1ELi0EEv8ConvArgs': (168, 3, True),
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi0EEv8ConvArgs': (128, 4, True),
-    '_Z22conv_wgrad_flow_kernelILi3ELi3EEv9WgradArgs': (88, 5, True),         # weight gradient, 48 x 48 blocks
-    '_Z22conv_wgrad_flow_kernelILi4ELi4EEv9WgradArgs': (128, 4, True),        # 64 x 64 blocks
-    '_Z22conv_wgrad_flow_kernelILi2ELi2EEv9WgradArgs': (64, 8, True),
+    # weight gradient: 48 x 48 and 64 x 64 blocks with hand-issued loads (real rulebook / identity map), the shipped variants
+    '_Z22conv_wgrad_flow_kernelILi3ELi3ELi1EEv9WgradArgs': (88, 5, True),
+    '_Z22conv_wgrad_flow_kernelILi3ELi3ELi2EEv9WgradArgs': (88, 5, True),
+    '_Z22conv_wgrad_flow_kernelILi4ELi4ELi1EEv9WgradArgs': (128, 4, True),
+    '_Z22conv_wgrad_flow_kernelILi4ELi4ELi2EEv9WgradArgs': (128, 4, True),
+    # ... hipcc-tracked loads (B2M_WGRAD_HANDLOADS=0; the other block shapes always)
+    '_Z22conv_wgrad_flow_kernelILi3ELi3ELi0EEv9WgradArgs': (88, 5, True),
+    '_Z22conv_wgrad_flow_kernelILi4ELi4ELi0EEv9WgradArgs': (128, 4, True),
+    '_Z22conv_wgrad_flow_kernelILi2ELi2ELi0EEv9WgradArgs': (64, 8, True),
     '_Z16conv_stem_kernelILb0EEv8ConvArgs': (128, 4, True),                       # the 5x5x5 first layer
     '_Z15conv_1x1_kernelILi3EEv8ConvArgs': (176, 2, False),                        # 1x1 streaming GEMM (compiler-scheduled waits)
     '_Z15conv_1x1_kernelILi2EEv8ConvArgs': (168, 3, False),
@@ -74,3 +80,81 @@ def test_hand_issued_loads_of_the_flow_kernel(kernels):
         assert set(waits) <= {base, base + 1, base + 2, base + 3, 2 * base}, waits
         after = body[mf[-1]:]
         assert any('s_waitcnt vmcnt(0)' in l for l in after[:400]), 'no drain of the in-flight loads behind the offset loop'
+
+
+HAND_ISSUED = [n for n in sorted(PINNED) if n.endswith(('Li1ELi1EEv8ConvArgs', 'Li4ELi1EEv8ConvArgs', 'Li1EEv9WgradArgs', 'Li2EEv9WgradArgs'))]
+
+
+@pytest.mark.parametrize('name', HAND_ISSUED)
+def test_nothing_touches_a_register_of_a_load_in_flight(kernels, name):
+    """A hand-issued load fills its registers some hundred cycles after hipcc thinks they are written.  Between the load and
+    the counted wait that covers it nothing may read or write them: tools/isa_check.py traces the assembly with the in-order
+    load queue the counts refer to.  (Round 4: handed the loaded registers as in/out operands of a bare `s_waitcnt`, hipcc
+    copied them to fresh registers in front of the wait -- whole 48 x 48 blocks of dW came out wrong on some runs.  The cure is
+    in the source -- the statement that waits is the only reader -- and this is the check that it stays cured; the trace also
+    proves the counts themselves: an MFMA reading an operand whose load is still among the N youngest is reported.)"""
+    import isa_check
+    assert len(HAND_ISSUED) == 8
+    body = isa_check.kernel_body(isa_check.device_asm(), name)
+    assert sum(1 for i, l in enumerate(body) if 'global_load' in l and 'ASMSTART' in body[i - 1] + body[i - 2] + body[i - 3]) >= 8
+    assert isa_check.inflight_violations(body) == []
+
+
+def test_the_register_trace_sees_the_hazards_it_is_there_for():
+    import isa_check
+    asm = """
+.LBB0_1: ; Loop Header
+	;;#ASMSTART
+	global_load_dword v10, v2, s[0:1]
+	global_load_dword v11, v2, s[0:1] offset:64
+	;;#ASMEND
+	;;#ASMSTART
+	global_load_dword v12, v3, s[0:1]
+	;;#ASMEND
+	%s
+	;;#ASMSTART
+	s_waitcnt vmcnt(%d)
+	;;#ASMEND
+	;;#ASMSTART
+	v_mfma_f32_16x16x4_f32 v[20:23], v10, v11, v[20:23]
+	;;#ASMEND
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+"""
+    ok = isa_check.inflight_violations((asm % ('s_nop 0', 1)).split('\n'))
+    assert ok == []
+    copied = isa_check.inflight_violations((asm % ('v_mov_b32_e32 v30, v11', 1)).split('\n'))          # a copy in front of the wait
+    assert [v[2] for v in copied] == [[11]]
+    clobber = isa_check.inflight_violations((asm % ('v_add_u32_e32 v12, 4, v3', 1)).split('\n'))       # the allocator reuses v12
+    assert [v[2] for v in clobber] == [[12]]
+    short = isa_check.inflight_violations((asm % ('s_nop 0', 2)).split('\n'))                          # a wait that is one short
+    assert [v[2] for v in short] == [[11]] and 'v_mfma' in short[0][1]
+
+
+def test_the_register_trace_follows_the_path_that_skips_a_wait():
+    """The consumer of a load (wait + MFMAs) sits behind a wave-uniform branch -- a k-step without pairs, an absent row group.
+    On the path that jumps over it the load is still in flight when the next address is computed: a temporary in the load's
+    register is overwritten when the data lands (round 4: a GPU memory fault in conv_wgrad_flow_kernel; latent in the
+    conv_fwd_flow_kernel of the same round).  The cure pinned by test_nothing_touches_a_register_of_a_load_in_flight: load
+    destinations are in/out operands, so the register is never free."""
+    import isa_check
+    asm = """
+.LBB0_1: ; Loop Header
+	;;#ASMSTART
+	global_load_dword v10, v2, s[0:1]
+	;;#ASMEND
+	s_cbranch_scc1 .LBB0_3
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	;;#ASMSTART
+	v_mfma_f32_16x16x4_f32 v[20:23], v10, v11, v[20:23]
+	;;#ASMEND
+.LBB0_3:
+	%s
+	s_cbranch_scc0 .LBB0_1
+	s_endpgm
+"""
+    assert isa_check.inflight_violations((asm % 'v_add_u32_e32 v2, 4, v2').split('\n')) == []
+    hit = isa_check.inflight_violations((asm % 'v_lshrrev_b32_e32 v10, 24, v3').split('\n'))     # the "dead" register as a temporary
+    assert [v[2] for v in hit] == [[10]]

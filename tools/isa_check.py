@@ -66,6 +66,110 @@ def _summarise(body):
     return {'mfma': len(idx), 'loop_waits': waits}
 
 
+def kernel_body(asm_path, name):
+    s = open(asm_path).read()
+    i = s.index(name + ':')
+    return s[i:s.index('.end_amdhsa_kernel', i)].split('\n')
+
+
+_REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+
+
+def _regs(text):
+    out = set()
+    for m in _REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def inflight_violations(body):
+    """Hand-issued loads (global_load_* inside an asm statement) are invisible to hipcc's wait insertion: until the counted
+    `s_waitcnt vmcnt(N)` that covers a load has run, NOTHING may read or write the registers it is going to fill -- not the
+    MFMAs (a wrong count), not a compiler-generated copy, not another value the allocator put there.  This traces the kernel
+    with the in-order load queue vmcnt counts against (every global_load enters it, `vmcnt(N)` leaves the N youngest) and
+    returns the instructions that touch a register of a hand-issued load still in the queue.  The trace: unconditional
+    branches are followed, conditional ones fall through unless they jump BACK (a loop's back edge: taken until the target
+    has been passed twice, so values carried around a loop are followed once); code the trace never reaches is traced
+    afterwards, block by block, from an empty queue.  A second trace takes every forward branch that jumps over a counted
+    wait (and no load): the consumer of a register is skipped (a k-step without pairs, an absent row group), its load is
+    still in flight behind the branch -- and the register, dead in hipcc's eyes, is a favourite for the next temporary."""
+    labels = {}
+    for k, l in enumerate(body):
+        m = re.match(r'^(\.LBB\d+_\d+):', l)
+        if m:
+            labels[m.group(1)] = k
+    bad = {}
+
+    def skips_a_wait(k, t):
+        region = body[k:t]
+        return (any(re.search(r's_waitcnt.*vmcnt', l) and 'ASMSTART' in region[i - 1] for i, l in enumerate(region) if i)
+                and not any('global_load' in l or 'buffer_load' in l for l in region))
+
+    def trace(start, visits, skip):
+        queue = []          # (hand_issued, destination registers), oldest first
+        in_asm = False
+        k = start
+        while k < len(body):
+            if visits[k] >= 2:
+                return
+            visits[k] += 1
+            raw = body[k].strip()
+            k += 1
+            if raw.startswith(';;#ASMSTART'):
+                in_asm = True
+                continue
+            if raw.startswith(';;#ASMEND'):
+                in_asm = False
+                continue
+            l = raw.split(';')[0].strip()
+            if not l or l.endswith(':') or l.startswith('.'):
+                continue
+            if l.startswith('s_endpgm'):
+                return
+            m = re.match(r's_waitcnt.*vmcnt\((\d+)\)', l)
+            if m:
+                n = int(m.group(1))
+                if len(queue) > n:
+                    queue = queue[len(queue) - n:] if n else []
+                continue
+            m = re.match(r's_(c?)branch\w*\s+(\.LBB\d+_\d+)', l)
+            if m:
+                t = labels.get(m.group(2))
+                if t is None:
+                    continue
+                if not m.group(1):                       # unconditional
+                    k = t
+                elif t < k and visits[t] < 2:            # back edge
+                    k = t
+                elif t > k and skip and skips_a_wait(k, t):
+                    k = t
+                continue
+            ops = l.split(None, 1)
+            regs = _regs(ops[1]) if len(ops) > 1 else set()
+            pending = set()
+            for hand, dst in queue:
+                if hand:
+                    pending |= dst
+            hit = regs & pending
+            if ops[0].startswith(('global_load', 'buffer_load', 'flat_load')):
+                dst = _regs(ops[1].split(',')[0])
+                hit = (regs - dst) & pending          # (a second load into a register in flight lands in order: harmless)
+                queue.append((in_asm, dst))
+            if hit and k - 1 not in bad:
+                bad[k - 1] = (k - 1, l, sorted(hit))
+
+    for skip in (False, True):
+        visits = [0] * len(body)
+        trace(0, visits, skip)
+        for k in range(len(body)):
+            if visits[k] == 0 and re.match(r'^\.LBB\d+_\d+:', body[k]):
+                trace(k, visits, skip)
+    return [bad[k] for k in sorted(bad)]
+
+
 if __name__ == '__main__':
     ks = kernels(device_asm())
     pats = sys.argv[1:] or ['conv_fwd_flow_kernel', 'conv_wgrad_flow_kernel', 'conv_stem_kernel', 'conv_1x1']
@@ -75,3 +179,5 @@ if __name__ == '__main__':
             print('%-62s vgpr %3s spill %s/%s scratch %s lds %5s occ %s mfma %3d  vmcnt in MFMA region: %s' % (
                 n, k.get('vgpr'), k.get('sgpr_spill'), k.get('vgpr_spill'), k.get('scratch'), k.get('lds'), k.get('occupancy'),
                 k['mfma'], k['loop_waits']))
+            for v in inflight_violations(kernel_body(device_asm(), n)):
+                print('    register of a load in flight touched: line %d  %s  %s' % v)
