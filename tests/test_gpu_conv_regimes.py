@@ -47,6 +47,8 @@ REGIMES = {
     'no_chunk_slices': {'B2M_CONV_CHUNKSPLIT': '0'},
     'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'},
     'wgrad_plain': {'B2M_WGRAD_PIPE': '0'},
+    'wgrad_compiler_tracked_loads': {'B2M_WGRAD_HANDLOADS': '0'},
+    'wgrad_hand_issued_loads_square_blocks_only': {'B2M_WGRAD_HANDLOADS': '1'},
     'wgrad_64_tile_chunks': {'B2M_WGRAD_MIN_TILES': '64'},
     'wgrad_one_offset_per_workgroup': {'B2M_WGRAD_KPACK': '0'},
     'no_xcd_order': {'B2M_XCD': '0'},

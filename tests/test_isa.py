@@ -31,12 +31,17 @@ PINNED = {
     # ... and with hipcc-tracked loads (B2M_CONV_HANDLOADS=0, three steps in flight, diagnostics)
     '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1ELi0EEv8ConvArgs': (168, 3, True),
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi0EEv8ConvArgs': (128, 4, True),
-    # weight gradient: 48 x 48 and 64 x 64 blocks with hand-issued loads (real rulebook / identity map), the shipped variants
+    # weight gradient with hand-issued loads (real rulebooks; every block shape of 2..4 x 2..4 sub-tiles): the shipped variants
+    '_Z22conv_wgrad_flow_kernelILi2ELi2ELi1EEv9WgradArgs': (64, 8, True),
+    '_Z22conv_wgrad_flow_kernelILi2ELi3ELi1EEv9WgradArgs': (72, 7, True),
+    '_Z22conv_wgrad_flow_kernelILi3ELi2ELi1EEv9WgradArgs': (72, 7, True),
+    '_Z22conv_wgrad_flow_kernelILi2ELi4ELi1EEv9WgradArgs': (80, 6, True),
+    '_Z22conv_wgrad_flow_kernelILi4ELi2ELi1EEv9WgradArgs': (80, 6, True),
     '_Z22conv_wgrad_flow_kernelILi3ELi3ELi1EEv9WgradArgs': (88, 5, True),
-    '_Z22conv_wgrad_flow_kernelILi3ELi3ELi2EEv9WgradArgs': (88, 5, True),
+    '_Z22conv_wgrad_flow_kernelILi3ELi4ELi1EEv9WgradArgs': (128, 4, True),
+    '_Z22conv_wgrad_flow_kernelILi4ELi3ELi1EEv9WgradArgs': (128, 4, True),
     '_Z22conv_wgrad_flow_kernelILi4ELi4ELi1EEv9WgradArgs': (128, 4, True),
-    '_Z22conv_wgrad_flow_kernelILi4ELi4ELi2EEv9WgradArgs': (128, 4, True),
-    # ... hipcc-tracked loads (B2M_WGRAD_HANDLOADS=0; the other block shapes always)
+    # ... hipcc-tracked loads (identity maps, B2M_WGRAD_HANDLOADS=0)
     '_Z22conv_wgrad_flow_kernelILi3ELi3ELi0EEv9WgradArgs': (88, 5, True),
     '_Z22conv_wgrad_flow_kernelILi4ELi4ELi0EEv9WgradArgs': (128, 4, True),
     '_Z22conv_wgrad_flow_kernelILi2ELi2ELi0EEv9WgradArgs': (64, 8, True),
@@ -82,7 +87,7 @@ def test_hand_issued_loads_of_the_flow_kernel(kernels):
         assert any('s_waitcnt vmcnt(0)' in l for l in after[:400]), 'no drain of the in-flight loads behind the offset loop'
 
 
-HAND_ISSUED = [n for n in sorted(PINNED) if n.endswith(('Li1ELi1EEv8ConvArgs', 'Li4ELi1EEv8ConvArgs', 'Li1EEv9WgradArgs', 'Li2EEv9WgradArgs'))]
+HAND_ISSUED = [n for n in sorted(PINNED) if n.endswith(('Li1ELi1EEv8ConvArgs', 'Li4ELi1EEv8ConvArgs', 'Li1EEv9WgradArgs'))]
 
 
 @pytest.mark.parametrize('name', HAND_ISSUED)
@@ -94,7 +99,7 @@ def test_nothing_touches_a_register_of_a_load_in_flight(kernels, name):
     in the source -- the statement that waits is the only reader -- and this is the check that it stays cured; the trace also
     proves the counts themselves: an MFMA reading an operand whose load is still among the N youngest is reported.)"""
     import isa_check
-    assert len(HAND_ISSUED) == 8
+    assert len(HAND_ISSUED) == 13
     body = isa_check.kernel_body(isa_check.device_asm(), name)
     assert sum(1 for i, l in enumerate(body) if 'global_load' in l and 'ASMSTART' in body[i - 1] + body[i - 2] + body[i - 3]) >= 8
     assert isa_check.inflight_violations(body) == []
