@@ -58,6 +58,30 @@ __device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float
 }
 #define tile_column_sums(a, strip, tile, row0, col0, lane) strip_column_sums<SW>(a, strip, tile, row0, col0, lane)
 
+// Half output (F16 kernels): four consecutive columns of output row `grow` -- the inference epilogue in fp32 (scale / shift,
+// residual read as half, ReLU), one rounding to half, one 8-byte store.  ConvArgs::y / ep_res hold half data here.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_half4(const ConvArgs& a, f32x4 v, int64_t grow, int col) {
+    if (a.ep_scale) {
+        const f32x4 s = *(const f32x4*)(a.ep_scale + col), b = *(const f32x4*)(a.ep_shift + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_fmaf(v[u], s[u], b[u]);
+    }
+    if (a.ep_res) {
+        const f16x4 r = *(const f16x4*)((const _Float16*)a.ep_res + grow * a.ld_res + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] += (float)r[u];
+    }
+    if (a.ep_relu) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = v[u] > 0.f ? v[u] : 0.f;
+    }
+    f16x4 h;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) h[u] = (_Float16)v[u];
+    *(f16x4*)((_Float16*)a.y + grow * a.ldy + col) = h;
+}
+
 // DBG (diagnostic builds of tools/pipe_breakdown.py only, results are WRONG): 1 = no strip flush, 2 = no gathers inside
 // the loop, 4 = no weight loads inside the loop, 8 = no MFMAs (everything else: the floor a faster multiply would leave) -- each removes one component so that its cost shows in the launch time
 // WPB = 4: split maps (deep U-Net levels).  The four waves of a workgroup are four slices of ONE (tile, strip): the
@@ -71,9 +95,20 @@ __device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float
 // per step the one-group steps -- a third of all steps on the benchmark's maps -- were bound by that path, not by their
 // 12 * TW MFMAs.  A conditional (branchy) narrow load in C++ loses hipcc's counted waits (vmcnt(0) in front of every MFMA
 // block); the EXEC mask around ONE load instruction keeps the instruction count and costs two scalar moves.
-template <int D, int TW, int DBG = 0, int WPB = 1, int HL = 0>
+// F16 = 1 (round 4, inference only: b2m_conv_fwd_h): activations, residual and output are IEEE half in HBM, the packed weights
+// half, the accumulators and the LDS strip fp32.  A step is still one 64-byte piece of every gathered row and TW one-KiB
+// weight pieces -- now 32 input channels -- and ONE v_mfma_f32_16x16x32_f16 per (row group, column tile) instead of four
+// v_mfma_f32_16x16x4_f32: the same pipeline, waits and masks, a sixteenth of the MFMA cycles per channel.  No bias, no
+// accumulate, no BatchNorm column sums; at most 4 slices (the combine of more is an fp32 atomic into Y).
+// F16 = 2: 16 input channels per step (8-byte loads, v_mfma_f32_16x16x16_f16) for the layers whose 32-channel chunks cannot be
+// dealt to the D steps of a round (32 input channels: one chunk per offset).
+template <int D, int TW, int DBG = 0, int WPB = 1, int HL = 0, int F16 = 0>
 __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
+    static_assert(!F16 || HL, "the half variant exists with hand-issued loads only");
     constexpr int KS = 4;                     // k-steps per 16-channel chunk == floats per lane per gathered row
+    constexpr int ESZ = F16 ? 2 : 4;          // bytes per activation element
+    constexpr int CSH = F16 == 1 ? 5 : 4;     // log2(input channels per step): 64 bytes of a row (F16 = 2: 32 bytes, see below)
+    constexpr int RB = F16 == 2 ? 32 : 64;    // bytes of a row per step
     constexpr int SW = 16 * TW;               // output channels per strip
     constexpr int LW = 64 * TW * KS;          // floats per packed weight block
     constexpr int PITCH = SW + 4;             // strip row pitch in floats: 16-byte multiples that do not alias banks
@@ -84,7 +119,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     const int i = lane & 15, q = lane >> 4;
     const int64_t wg = a.xcd_start ? wg_index_balanced(a.xcd_start, a.wg_per_tile) : wg_index(a.nwg, a.xcd_per);
     if (wg < 0) return;
-    const int nch1 = a.c1 >> 4, NC = (a.c1 + a.c2) >> 4;      // chunks of the first source / in all
+    const int nch1 = a.c1 >> CSH, NC = (a.c1 + a.c2) >> CSH;  // chunks of the first source / in all
     int64_t item = wg;
     int slice = 0, nks = 1, cb = 0, ce = NC;                  // offset slice of nks, chunk range [cb, ce): (ce - cb) % D == 0
     bool lead = true;
@@ -115,8 +150,11 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         for (int u = 0; u < 4; ++u) {
             const int col = col0 + c4 + u;
             if (col < a.cout) {
-                float t = (a.bias && lead) ? a.bias[col] : 0.f;
-                if (a.accumulate && a.nslice == 1 && grow < a.n_out) t += a.y[grow * a.ldy + col];
+                float t = 0.f;
+                if constexpr (!F16) {
+                    t = (a.bias && lead) ? a.bias[col] : 0.f;
+                    if (a.accumulate && a.nslice == 1 && grow < a.n_out) t += a.y[grow * a.ldy + col];
+                }
                 v[u] = t;
             }
         }
@@ -176,9 +214,9 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             for (int g = 0; g < NG; ++g) w[g] = (uint32_t)__builtin_amdgcn_ds_bpermute((16 * g + i) << 2, (int)word);
         };
 
-        const uint32_t wlo = (uint32_t)lane * 16u;         // packed block layout [u][lane][4 floats]: pack_pos()
-        const uint32_t q16 = (uint32_t)q * 16u;
-        const uint32_t ld1 = (uint32_t)a.ldx1 * 4u, ld2 = (uint32_t)a.ldx2 * 4u;
+        const uint32_t wlo = (uint32_t)lane * (F16 == 2 ? 8u : 16u);         // packed block layout [u][lane][4 floats]: pack_pos()
+        const uint32_t q16 = (uint32_t)q * (F16 == 2 ? 8u : 16u);       // the lane's bytes inside the row piece
+        const uint32_t ld1 = (uint32_t)a.ldx1 * (uint32_t)ESZ, ld2 = (uint32_t)a.ldx2 * (uint32_t)ESZ;     // row pitch in bytes
         const uint32_t wstrip = (uint32_t)strip * (uint32_t)NC;
         const uint32_t wkstride = (uint32_t)a.nstrips * (uint32_t)NC;
         // operand registers: buffer j holds row group g's four k-steps (one 16-byte gather) and the TW weight pieces; MFMA operand
@@ -186,14 +224,15 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         // load statement takes its destination as an IN/OUT operand: the previous content stays alive, in that very register, up
         // to the load -- hipcc, which does not know that a skipped group's load may still be in flight, would otherwise hand the
         // "dead" register to the next address computation (tests/test_isa.py traces this).
-        f32x4 av[D][NG], bw[D][TW];
+        using opv = std::conditional_t<F16 == 2, f32x2, f32x4>;           // one load's registers
+        opv av[D][NG], bw[D][TW];
         if constexpr (HL) {
 #pragma unroll
             for (int j = 0; j < D; ++j) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) av[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < NG; ++g) av[j][g] = opv{};
 #pragma unroll
-                for (int u = 0; u < TW; ++u) bw[j][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < TW; ++u) bw[j][u] = opv{};
             }
         }
 #define B2M_BV(j, s, t) bw[j][(TW * (s) + (t)) >> 2][(TW * (s) + (t)) & 3]
@@ -201,30 +240,38 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         auto src_of = [&](int c, uint32_t& ld4) -> const char* {
             const bool first = c < nch1;                                        // wave-uniform source select
             ld4 = first ? ld1 : ld2;
-            return (const char*)(first ? a.x1 + (c << 4) : a.x2 + ((c - nch1) << 4));
+            return (first ? (const char*)a.x1 + c * RB : (const char*)a.x2 + (c - nch1) * RB);
         };
         // `present` (wave-uniform): the step that will consume this buffer has row group g
         auto gather = [&](int j, int g, const char* src, uint32_t ld4, uint32_t word, bool present) {
             const uint32_t off = __umul24(word & 0xFFFFFFu, ld4) + q16;
             if constexpr (HL) {
                 const uint64_t em = present ? ~0ull : 1ull;                 // absent group: one lane fetches, the rest keep stale registers
-                asm volatile("s_mov_b64 exec, %3\n\tglobal_load_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, -1"
-                             : "+v"(av[j][g]) : "v"(off), "s"(src), "s"(em) : "memory");
+                if constexpr (F16 == 2)
+                    asm volatile("s_mov_b64 exec, %3\n\tglobal_load_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                                 : "+v"(av[j][g]) : "v"(off), "s"(src), "s"(em) : "memory");
+                else
+                    asm volatile("s_mov_b64 exec, %3\n\tglobal_load_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                                 : "+v"(av[j][g]) : "v"(off), "s"(src), "s"(em) : "memory");
             } else {
-                av[j][g] = *(const f32x4*)(src + off);
+                av[j][g] = *(const opv*)(src + off);
             }
         };
         auto weights = [&](int j, int k, int c) {
             const uint32_t blk = (uint32_t)k * wkstride + wstrip + (uint32_t)c;     // wave-uniform
-            const char* wsrc = (const char*)a.wp + (size_t)blk * (size_t)(LW * 4);
+            const char* wsrc = (const char*)a.wp + (size_t)blk * (size_t)(F16 == 2 ? LW * 2 : LW * 4);
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
-                if constexpr (HL) {
+                if constexpr (F16 == 2) {
+                    if (u == 0) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                    else if (u == 1) asm volatile("global_load_dwordx2 %0, %1, %2 offset:512" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                    else asm volatile("global_load_dwordx2 %0, %1, %2 offset:1024" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                } else if constexpr (HL) {
                     if (u == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
                     else if (u == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
                     else asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
                 } else {
-                    bw[j][u] = *(const f32x4*)(wsrc + (wlo + 1024u * u));
+                    bw[j][u] = *(const opv*)(wsrc + (wlo + 1024u * u));
                 }
             }
         };
@@ -267,7 +314,31 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         // apart; the dependent latency is 40).  The hardware interlocks MFMA -> MFMA on the same accumulator; the one
         // software-visible hazard, a non-MFMA read of a fresh result, is covered by the s_nop in front of the flush.
         auto mfma_group = [&](int j, int g) {
-            if constexpr (TW == 3) {
+            if constexpr (F16 == 2) {
+                if constexpr (TW == 3) {
+                    asm volatile("v_mfma_f32_16x16x16_f16 %0, %4, %3, %0\n\tv_mfma_f32_16x16x16_f16 %1, %5, %3, %1\n\t"
+                                 "v_mfma_f32_16x16x16_f16 %2, %6, %3, %2"
+                                 : "+v"(acc[g][0]), "+v"(acc[g][1]), "+v"(acc[g][2])
+                                 : "v"(av[j][g]), "v"(bw[j][0]), "v"(bw[j][1]), "v"(bw[j][2]) : "memory");
+                } else {
+                    asm volatile("v_mfma_f32_16x16x16_f16 %0, %3, %2, %0\n\tv_mfma_f32_16x16x16_f16 %1, %4, %2, %1"
+                                 : "+v"(acc[g][0]), "+v"(acc[g][1])
+                                 : "v"(av[j][g]), "v"(bw[j][0]), "v"(bw[j][1]) : "memory");
+                }
+            } else if constexpr (F16) {
+                // weights = A (lane (i, q): input channels 8q .. 8q + 7 of output channel 16t + i), gathered rows = B (lane (i, q):
+                // the same eight channels of pair i): D[channel][pair] as in the fp32 form
+                if constexpr (TW == 3) {
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %3, %0\n\tv_mfma_f32_16x16x32_f16 %1, %5, %3, %1\n\t"
+                                 "v_mfma_f32_16x16x32_f16 %2, %6, %3, %2"
+                                 : "+v"(acc[g][0]), "+v"(acc[g][1]), "+v"(acc[g][2])
+                                 : "v"(av[j][g]), "v"(bw[j][0]), "v"(bw[j][1]), "v"(bw[j][2]) : "memory");
+                } else {
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %3, %2, %0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %2, %1"
+                                 : "+v"(acc[g][0]), "+v"(acc[g][1])
+                                 : "v"(av[j][g]), "v"(bw[j][0]), "v"(bw[j][1]) : "memory");
+                }
+            } else if constexpr (TW == 3) {
                 asm volatile(
                     "v_mfma_f32_16x16x4_f32 %0, %7, %3, %0\n\tv_mfma_f32_16x16x4_f32 %1, %8, %3, %1\n\tv_mfma_f32_16x16x4_f32 %2, %9, %3, %2\n\t"
                     "v_mfma_f32_16x16x4_f32 %0, %10, %4, %0\n\tv_mfma_f32_16x16x4_f32 %1, %11, %4, %1\n\tv_mfma_f32_16x16x4_f32 %2, %12, %4, %2\n\t"
@@ -386,8 +457,12 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             f32x4 v = *(const f32x4*)&smem[row * PITCH + c4];
 #pragma unroll
             for (int w = 1; w < WPB; ++w) v += *(const f32x4*)&smem[w * STRIP + row * PITCH + c4];
-            if (a.stats) *(f32x4*)&smem[row * PITCH + c4] = v;  // keep the combined strip for the column sums below
+            if (!F16 && a.stats) *(f32x4*)&smem[row * PITCH + c4] = v;  // keep the combined strip for the column sums below
             const int col = col0 + c4;
+            if constexpr (F16) {
+                if (col + 3 < a.cout) store_half4(a, v, grow, col);
+                continue;
+            }
             float* dst = a.y + grow * a.ldy + col;
             if (plain && a.vec_store && col + 3 < a.cout) {
                 if (a.ep_scale) v = conv_epilogue(a, v, grow, col);
@@ -402,19 +477,23 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                 }
             }
         }
-        if (a.stats) {
+        if (!F16 && a.stats) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             tile_column_sums(a, smem, tile, row0, col0, lane);
         }
         return;
     }
-    if (a.stats) tile_column_sums(a, Cs, tile, row0, col0, lane);
+    if (!F16 && a.stats) tile_column_sums(a, Cs, tile, row0, col0, lane);
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
         if (grow >= a.n_out) continue;
         f32x4 v = *(const f32x4*)&Cs[row * PITCH + c4];
         const int col = col0 + c4;
+        if constexpr (F16) {
+            if (col + 3 < a.cout) store_half4(a, v, grow, col);
+            continue;
+        }
         float* dst = a.y + grow * a.ldy + col;
         if (a.vec_store && col + 3 < a.cout) {
             if (a.ep_scale) v = conv_epilogue(a, v, grow, col);
