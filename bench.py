@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_HBM_GBS = 8000.0
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense BF16 / F16 MFMA (~2.5 PFLOP/s)
 
 
 class LaunchTimer:
@@ -124,10 +125,19 @@ def main():
     ap.add_argument('--votes', type=int, default=1, help='0 skips the votes -> instance masks leg (outside the timed steps)')
     ap.add_argument('--inference', type=int, default=1, help='0 skips the batch-size-1 inference leg (outside the timed steps)')
     ap.add_argument('--prepare', type=int, default=1, help='0 skips the raw points -> device batch leg (outside the timed steps)')
+    ap.add_argument('--features', default='f32', choices=['f32', 'f16'],
+                    help="f16 adds the `inference_f16` object: the batch-size-1 inference leg with the HALF trunk (activations in "
+                         "HBM as IEEE half, f16 MFMA, fp32 accumulation; BASELINE configs[4]).  Never the headline, never the default")
     ap.add_argument('--workload', default='scannet', choices=['scannet', 's3dis', 'arkit'],
                     help='scannet = BASELINE configs[1] (the headline); s3dis / arkit = configs[4] / [5], own lines under profiles/, '
                          'never the headline')
     args = ap.parse_args()
+    # host-side torch ops (the outputs' clamp, pred2mask's bookkeeping on CPU tensors): the thread count the CPU baseline uses,
+    # set whether or not that leg runs (with the default -- every core of the box -- a 2 k-element op costs milliseconds)
+    try:
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    except AttributeError:
+        pass
     if args.workload != 'scannet':       # the side legs and the CPU baseline belong to the headline workload
         args.votes = args.prepare = args.cpu_baseline = args.inference = 0
 
@@ -466,6 +476,11 @@ def main():
     # ---- inference as the reference's Evaluater runs it: batch_size 1, eval mode, forward + votes -> masks
     if args.inference and world == 1:
         result['inference'] = inference_leg(model, dev, cfg, args.target_voxels, cpu_result, rb_lookup)
+        if args.features == 'f16':
+            result['inference_f16'] = inference_leg(model, dev, cfg, args.target_voxels, None, rb_lookup, half=True)
+    elif args.features == 'f16' and world == 1:     # the S3DIS- / ARKit-shaped workloads: forward of their own batch, fp32 and half
+        result['inference'] = inference_leg(model, dev, cfg, args.target_voxels, None, rb_lookup, own_batch=batch)
+        result['inference_f16'] = inference_leg(model, dev, cfg, args.target_voxels, None, rb_lookup, half=True, own_batch=batch)
 
     # ---- raw scene points -> voxelised, collated device batch (what feeds the step above)
     if args.prepare and world == 1:
@@ -728,7 +743,7 @@ def votes_leg(model, batch, cfg, cpu, pmc=None, pmc_src=None):
     return out
 
 
-def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10):
+def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10, half=False, own_batch=None):
     """The reference's evaluation flow (evaluation.py:70-98: batch_size 1, model.eval(), no gradients): one synthetic scene
     of the metric's size, `Model.get_prediction(batch, with_grad=False)` + `Model.pred2mask(batch, pred, 'eval')`, scenes per
     second.  Every trunk convolution applies its eval-mode BatchNorm (+ residual) (+ ReLU) on the way out of its kernel
@@ -736,24 +751,33 @@ def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10
     pass (small-batch regime: a quarter of the rows per launch of the training benchmark's bs = 8 batches).  Never the
     headline."""
     from box2mask_amd import _lib, synth
-    batch = synth.make_batch(1, seed0=100, target_voxels=target_voxels)
+    # own_batch (the S3DIS- / ARKit-shaped workloads): the forward pass of the workload's own device batch, no masks
+    batch = dict(own_batch) if own_batch is not None else synth.make_batch(1, seed0=100, target_voxels=target_voxels)
     n_vox = int(batch['vox_coords'].shape[0])
     for k in ('vox_coords', 'vox_features', 'pooling_ids'):
         batch[k] = batch[k].to(dev)
     was_training = model.detection_model.training
     model.eval()
+    pred32 = None
+    if half:
+        # the half trunk (SelectionNet.half_trunk): the fp32 inference path's outputs on the same scene first -- the parity figure
+        pred32 = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+        model.detection_model.half_trunk = True
 
-    votes, _ = synthetic_votes(batch, cfg, seed=8)
-    cpu_batch = dict(batch)
-    for k in ('input_location', 'batch_ids'):
-        cpu_batch[k] = batch[k].cpu()
+    with_masks = own_batch is None
+    if with_masks:
+        votes, _ = synthetic_votes(batch, cfg, seed=8)
+        cpu_batch = dict(batch)
+        for k in ('input_location', 'batch_ids'):
+            cpu_batch[k] = batch[k].cpu()
 
-    def once(masks=True):
+    def once(masks=with_masks):
         # the network's forward pass is the real one (its outputs come back to the host as in evaluation.py:86); the masks are
         # made from synthetic votes of the same scene: a random-init network votes every segment into a cluster of its own
-        pred = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=True)
+        # (own_batch legs: the outputs stay on the device -- the S3DIS-shaped batch returns 0.6 GB of per-voxel features)
+        pred = model.get_prediction(batch, with_grad=False, to_cpu=with_masks, min_size=True)
         return model.pred2mask(cpu_batch, votes, 'eval') if masks else pred
-    for _ in range(2):
+    for _ in range(4):                    # (the first passes of a new mix of tensor sizes are the caching allocator's)
         res = once()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -771,12 +795,12 @@ def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10
 
     def hook(name, a, meta_in=None):
         launches[name] = launches.get(name, 0) + 1
-        if name not in ('b2m_conv_fwd_affine', 'b2m_conv_fwd'):
+        if name not in ('b2m_conv_fwd_affine', 'b2m_conv_fwd', 'b2m_conv_fwd_h'):
             return None
         s_ = torch.cuda.Event(enable_timing=True); e_ = torch.cuda.Event(enable_timing=True)
         cin = (meta_in or {}).get('cin', a[2] + a[5])
         # b2m_conv_fwd_affine: x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, ...
-        meta = dict(cin=cin, cout=a[15], K=a[8], n_out=a[12], rb_cnt=a[11]) if name == 'b2m_conv_fwd_affine' else \
+        meta = dict(cin=cin, cout=a[15], K=a[8], n_out=a[12], rb_cnt=a[11], half=name == 'b2m_conv_fwd_h') if name != 'b2m_conv_fwd' else \
             dict(cin=cin, cout=a[16], K=a[8], n_out=a[13], rb_cnt=a[12])
         s_.record()
 
@@ -788,18 +812,29 @@ def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10
     once(masks=False)
     torch.cuda.synchronize()
     _lib.set_hook(None)
-    cache, ms, flops = {}, 0.0, 0.0
+    cache, ms, flops, ms_h, flops_h = {}, 0.0, 0.0, 0.0, 0.0
     for s_, e_, meta in rec:
-        ms += s_.elapsed_time(e_)
-        flops += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']
+        t_, f_ = s_.elapsed_time(e_), 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']
+        ms += t_; flops += f_
+        if meta.get('half'):
+            ms_h += t_; flops_h += f_
     tf = flops / max(ms, 1e-9) / 1e9
+    parity = None
+    if half:
+        pred16 = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+        model.detection_model.half_trunk = False
+        parity = {h: float((pred16[h].double() - pred32[h].double()).abs().max() / max(float(pred32[h].abs().max()), 1e-9))
+                  for h in cfg.network_heads}
     if was_training:
         model.train()
-    out = {'value': round(1.0 / dt, 3), 'unit': 'scenes/s', 'ms_per_scene': round(dt * 1e3, 3),
-           'ms_forward': round(dt_fwd * 1e3, 3), 'voxels': n_vox, 'instances': int(sum(len(r['conf']) for r in res.values())),
-           'flow': "batch_size 1: Model.get_prediction(batch, with_grad=False) [real forward, outputs to the host] + "
-                   "Model.pred2mask(batch, votes, 'eval') on synthetic votes of the same scene (evaluation.py:70-98); masks "
-                   'returned to the host',
+    n_scenes = (int(batch['batch_ids'].max().item()) + 1) if own_batch is not None else 1
+    out = {'value': round(n_scenes / dt, 3), 'unit': 'scenes/s', 'ms_per_scene': round(dt * 1e3 / n_scenes, 3),
+           'ms_forward': round(dt_fwd * 1e3, 3), 'voxels': n_vox, 'scenes_per_pass': n_scenes,
+           'instances': int(sum(len(r['conf']) for r in res.values())) if with_masks else None,
+           'flow': ("batch_size 1: Model.get_prediction(batch, with_grad=False) [real forward, outputs to the host] + "
+                    "Model.pred2mask(batch, votes, 'eval') on synthetic votes of the same scene (evaluation.py:70-98); masks "
+                    'returned to the host') if with_masks else
+                   "Model.get_prediction(batch, with_grad=False, to_cpu=False) on the workload's own batch (forward only, outputs stay on the device)",
            'launches_forward': int(sum(launches.values())),
            'fused_conv_bn_launches': int(launches.get('b2m_conv_fwd_affine', 0)),
            'batchnorm_launches': int(launches.get('b2m_bn_apply', 0) + launches.get('b2m_bn_apply2', 0)),
@@ -808,6 +843,21 @@ def inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=10
                         'kernel': 'b2m_conv_fwd_affine (conv_fwd_flow_kernel / conv_1x1_kernel / conv_stem_kernel with the '
                                   'BatchNorm epilogue) + b2m_conv_fwd (heads)',
                         'launches': len(rec), 'ms': round(ms, 3), 'gflop': round(flops / 1e9, 2)}}
+    if half:
+        tf_h = flops_h / max(ms_h, 1e-9) / 1e9
+        out['features'] = 'f16 (trunk activations and weights IEEE half in HBM, v_mfma_f32_16x16x32_f16 / 16x16x16_f16, fp32 ' \
+                          'accumulation and BatchNorm epilogue; 6-channel stem, pooled features and heads fp32)'
+        out['half_conv_launches'] = int(launches.get('b2m_conv_fwd_h', 0))
+        out['max_rel_err_vs_fp32_path'] = {h: float('%.3e' % e) for h, e in parity.items()}
+        out['parity_note'] = ('largest |half - fp32| / max|fp32| per head on this scene; the fp32 path is the one pinned against the '
+                              'CPU oracle (gpu_vs_oracle), and tests/test_gpu_half.py compares the half trunk with the oracle '
+                              'directly (<= 2e-2)')
+        out['roofline'] = {'bound': 'mfma', 'achieved': round(tf_h, 3), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': round(tf_h / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': None,
+                           'kernel': 'b2m_conv_fwd_h: conv_fwd_flow_kernel<.., F16> (the half launches only; the kernel is bound by the '
+                                     "CU's vector-load path -- 64 bytes per lane-row and KiB weight pieces per MFMA -- not by the f16 "
+                                     'MFMA pipe: DESIGN.md §5)',
+                           'launches': sum(1 for r in rec if r[2].get('half')), 'ms': round(ms_h, 3), 'gflop': round(flops_h / 1e9, 2)}
     if cpu_result is not None and cpu_result.get('inference_s'):
         out['cpu_baseline'] = {'value': round(1.0 / cpu_result['inference_s'], 4), 'unit': 'scenes/s', 'cores': cpu_result['cores'],
                                'kind': 'port',

@@ -36,6 +36,8 @@ PROTOTYPES = {
     'b2m_radix_argsort': [P, I64, C.c_uint64, P, P, P, P],
     'b2m_conv_fwd': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],
     'b2m_conv_fwd_affine': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, I64, P, I64, I32, P, P, P, I64, I32, P, P],
+    'b2m_conv_fwd_h': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, I64, P, I64, I32, P, P, P, I64, I32, P],
+    'b2m_weight_pack_h': [P, I64, I32, I32, I32, I32, P, P],
     'b2m_conv_fwd_stats': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P, P, P],
     'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
     'b2m_weight_pack_run': [P, I32, I64, P],
@@ -94,6 +96,7 @@ PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_
          'b2m_reload_env': (C.c_int, []),
          'b2m_weight_pack_size': (C.c_int64, [I32, I32, I32]),
          'b2m_conv_wgrad_workspace': (C.c_int64, [I32, I32, I32]),
+         'b2m_weight_pack_h_size': (C.c_int64, [I32, I32, I32, I32]),
          'b2m_unique_insert': (C.c_int64, [P, I64, P, I64, P, P, P, P]),
          'b2m_weight_pack_plan_size': (C.c_int32, []),
          'b2m_rulebook_cnt_size': (C.c_int64, [I32, I64]),

@@ -1078,6 +1078,108 @@ extern "C" int b2m_conv_fwd_affine(const float* x1, int64_t ldx1, int32_t c1, co
     return conv_fwd_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, nullptr, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, 0, nullptr,
                          nullptr, stream, &ep, fused);
 }
+// ------------------------------------------------------------------ half activations (inference)
+// Packed HALF weight image of b2m_conv_fwd_h: blocks [k][strip][chunk] of TW pieces, piece t = [lane][E halfs] with E = 8
+// (chunks of CK = 32 input channels, v_mfma_f32_16x16x32_f16) or 4 (CK = 16, v_mfma_f32_16x16x16_f16): lane (i, q) of piece t
+// holds W[k][chunk * CK + E * q + j][strip * 16 * TW + 16 * t + i], j = 0 .. E - 1 -- the MFMA's A operand as it sits in the
+// registers.  Forward weights only (no transpose / mirror: there is no backward pass in half).
+static inline int conv_h_ck(int c1, int c2) {
+    // 32-channel chunks when they can be dealt to the steps of a round (2 or 3 in flight), else 16-channel chunks
+    if (c1 % 32 == 0 && c2 % 32 == 0) { const int nc = (c1 + c2) / 32; if (nc % 2 == 0 || nc % 3 == 0) return 32; }
+    return 16;
+}
+extern "C" int64_t b2m_weight_pack_h_size(int32_t K, int32_t c1, int32_t c2, int32_t cout) {      // in halfs
+    const int TW = conv_tw(cout, K);
+    return (int64_t)K * ((cout + 16 * TW - 1) / (16 * TW)) * ((c1 + c2) / conv_h_ck(c1, c2)) * (64 * TW * (conv_h_ck(c1, c2) / 4));
+}
+__global__ void weight_pack_h_kernel(const float* __restrict__ w, int64_t ldw, int K, int cin, int cout, int CK, int TW,
+                                     _Float16* __restrict__ wp, int64_t total) {
+    const int E = CK / 4, SW = 16 * TW, BLK = 64 * TW * E;
+    const int nchunk = cin / CK, nstrip = (cout + SW - 1) / SW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int pos = (int)(e % BLK);
+        const int t = pos / (64 * E), lane = (pos / E) % 64, j = pos % E;
+        const int64_t blk = e / BLK;
+        const int chunk = (int)(blk % nchunk); const int64_t b2 = blk / nchunk;
+        const int strip = (int)(b2 % nstrip), k = (int)(b2 / nstrip);
+        const int ci = chunk * CK + E * (lane >> 4) + j, co = strip * SW + 16 * t + (lane & 15);
+        wp[e] = (co < cout) ? (_Float16)w[((int64_t)k * cin + ci) * ldw + co] : (_Float16)0.f;
+    }
+}
+extern "C" int b2m_weight_pack_h(const float* w, int64_t ldw, int32_t K, int32_t c1, int32_t c2, int32_t cout, void* wp, void* stream) {
+    B2M_CHECK_ARG(w && wp && K >= 1 && c1 > 0 && c2 >= 0 && cout > 0 && ldw >= cout, "bad arguments");
+    B2M_CHECK_ARG(c1 % 16 == 0 && c2 % 16 == 0, "input channels of both sources must be multiples of 16");
+    const int64_t total = b2m_weight_pack_h_size(K, c1, c2, cout);
+    int64_t grid = (total + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    weight_pack_h_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(w, ldw, K, c1 + c2, cout, conv_h_ck(c1, c2), conv_tw(cout, K),
+                                                                         (_Float16*)wp, total);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+// Y(half) = [relu]( conv(X1 | X2)(half) * scale + shift [+ res(half)] ) through conv_fwd_flow_kernel<.., F16>: real rulebooks
+// only (a 1x1 layer comes with the identity rulebook of its map: b2m_rulebook of K = 1), input channels of both sources in
+// multiples of 16, output channels in multiples of 16, 16-byte aligned rows.  scale / shift may be NULL (plain convolution).
+extern "C" int b2m_conv_fwd_h(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int64_t ldx2, int32_t c2, int64_t n_in,
+                              const void* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                              int64_t n_out, void* y, int64_t ldy, int32_t cout, const float* scale, const float* shift,
+                              const void* res, int64_t ld_res, int32_t relu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(x1 && wp && y && rb_in && rb_out && rb_cnt && c1 > 0 && c2 >= 0 && cout > 0 && K >= 1 && K <= 128, "bad pointers/sizes (K<=128)");
+    B2M_CHECK_ARG(c2 == 0 || x2 != nullptr, "x2 is NULL");
+    B2M_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale and shift: both or none");
+    B2M_CHECK_ARG(c1 % 16 == 0 && c2 % 16 == 0 && cout % 16 == 0, "channels must be multiples of 16");
+    B2M_CHECK_ARG(ldx1 % 8 == 0 && ldx1 >= c1 && (c2 == 0 || (ldx2 % 8 == 0 && ldx2 >= c2)) && ldy % 4 == 0 && ldy >= cout &&
+                  (!res || (ld_res % 4 == 0 && ld_res >= cout)), "row pitches: 16-byte multiples for the inputs, 8 for output / residual");
+    B2M_CHECK_ARG(((uintptr_t)x1 % 16) == 0 && ((uintptr_t)x2 % 16) == 0 && ((uintptr_t)wp % 16) == 0 && ((uintptr_t)y % 8) == 0 &&
+                  ((uintptr_t)res % 8) == 0 && ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0, "alignment");
+    B2M_CHECK_ARG(n_in >= 1 && n_in < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_in * ldx1 * 2 < (1ll << 32) &&
+                  n_in * ldx2 * 2 < (1ll << 32), "inputs must be 32-bit addressable (rows < 2^24, tensors < 4 GiB)");
+    if (n_out == 0) return B2M_OK;
+    ConvArgs a;
+    a.x1 = (const float*)x1; a.ldx1 = ldx1; a.c1 = c1; a.x2 = (const float*)x2; a.ldx2 = ldx2; a.c2 = c2;
+    a.wp = (const float*)wp; a.K = K; a.bias = nullptr;
+    a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
+    a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
+    a.y = (float*)y; a.ldy = ldy; a.cout = cout; a.accumulate = 0; a.stats = nullptr; a.vec_store = 1; a.fast32 = 1;
+    a.ep_scale = scale; a.ep_shift = shift; a.ep_res = (const float*)res; a.ld_res = ld_res; a.ep_relu = relu;
+    a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr; a.zeros = nullptr;
+    const int TW = conv_tw(cout, K);
+    a.nstrips = (cout + 16 * TW - 1) / (16 * TW);
+    const int CK = conv_h_ck(c1, c2), nc = (c1 + c2) / CK;
+    int depth = nc % 2 == 0 ? 2 : 3;
+    B2M_CHECK_ARG(CK == 32 || nc % 2 == 0, "input channels: multiples of 32 (or an even number of 16-channel chunks)");
+    // small maps: the active offsets of an item dealt to the 4 waves of a workgroup (combined in LDS, plain stores); never more
+    const int64_t items0 = a.ntiles * a.nstrips;
+    const int nslice = (items0 < env_flag("B2M_CONV_TARGET", 6144) && K >= 4) ? 4 : 1;
+    a.nslice = nslice; a.ncs = 1; a.wg_combine = nslice == 4;
+    const int wpb = nslice == 1 ? 1 : 4;
+    const int64_t items = items0 * nslice;
+    a.nwg = cdiv64(items, wpb);
+    const int64_t xcd_tiles = env_flag("B2M_XCD", 1) ? (1 << 30) : 0;
+    XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
+    a.xcd_per = fo.chunk;
+    if (a.ntiles >= B2M_BALANCE_MIN_TILES && xcd_tiles > 0 && (a.nstrips * nslice) % wpb == 0 && K > 1 && env_flag("B2M_XCD_BALANCE", 1)) {
+        a.xcd_start = rb_cnt + (int64_t)K * a.ntiles;
+        a.tile_order = env_flag("B2M_XCD_ORDER", 1) ? a.xcd_start + 16 + a.ntiles : nullptr;
+        a.wg_per_tile = a.nstrips * nslice / wpb;
+        fo.grid = (unsigned)(8 * B2M_XCD_CAP(a.ntiles) * a.wg_per_tile);
+    }
+#define B2M_FLOW_H(D_, TW_, WPB_, F_) conv_fwd_flow_kernel<D_, TW_, 0, WPB_, 1, F_><<<fo.grid, 64 * WPB_, 0, st>>>(a)
+    if (CK == 16) {
+        if (wpb == 4) { if (TW == 3) B2M_FLOW_H(2, 3, 4, 2); else B2M_FLOW_H(2, 2, 4, 2); }
+        else { if (TW == 3) B2M_FLOW_H(2, 3, 1, 2); else B2M_FLOW_H(2, 2, 1, 2); }
+    } else if (depth == 2) {
+        if (wpb == 4) { if (TW == 3) B2M_FLOW_H(2, 3, 4, 1); else B2M_FLOW_H(2, 2, 4, 1); }
+        else { if (TW == 3) B2M_FLOW_H(2, 3, 1, 1); else B2M_FLOW_H(2, 2, 1, 1); }
+    } else {
+        if (wpb == 4) { if (TW == 3) B2M_FLOW_H(3, 3, 4, 1); else B2M_FLOW_H(3, 2, 4, 1); }
+        else { if (TW == 3) B2M_FLOW_H(3, 3, 1, 1); else B2M_FLOW_H(3, 2, 1, 1); }
+    }
+#undef B2M_FLOW_H
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
 extern "C" int b2m_conv_fwd_stats(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2,
                                   int64_t n_in, const float* wp, int32_t K, const float* bias, const int32_t* rb_in,
                                   const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, float* y, int64_t ldy,

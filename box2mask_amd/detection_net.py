@@ -156,6 +156,15 @@ class SelectionNet(ResNetBase):
         if mgr is not None:
             mgr.prefetch(8, same=[(0, 5)] + [(l, 3) for l in range(8)], strided=True)
         out_p1 = T('out_p1', cbr(self.conv0p1s1, self.bn0, x))
+        # Half trunk (inference only; BASELINE configs[4] "fp16 features on CDNA4"): behind the 6-channel stem every trunk
+        # activation lives in HBM as IEEE half and every convolution (+ BatchNorm + residual + ReLU) is one
+        # conv_fwd_flow_kernel<.., F16> launch -- half operands, f16 MFMA, fp32 accumulation and epilogue; the pooled
+        # features and the heads are fp32 again.
+        half = bool(getattr(self, 'half_trunk', False))
+        if half:
+            if not self.bn0.fusable():
+                raise RuntimeError('half_trunk is an inference mode: model.eval() and torch.no_grad() (and B2M_CONV_AFFINE=1)')
+            out_p1 = out_p1.new(out_p1.F.half())
         # every encoder output feeds the next strided convolution AND the decoder's ME.cat: the decoder takes the alias the
         # strided convolution hands back (skip=True), so the two gradients are summed inside that convolution's
         # data-gradient kernel
@@ -182,6 +191,8 @@ class SelectionNet(ResNetBase):
         out = T('block7', self.block7(ME.cat(T('up1', cbr(self.convtr6p4s2, self.bntr6, out)), out_b1p2)))
         out = T('block8', self.block8(ME.cat(T('up0', cbr(self.convtr7p2s2, self.bntr7, out)), out_p1)))
 
+        if half:
+            out = out.new(out.F.float())
         outputs = {}
         perm = x.manager.perm if getattr(x, 'manager', None) is not None else None
         if self.requires_voxel_outputs:

@@ -186,11 +186,60 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
     return out
 
 
+# ---- half activations (inference): b2m_conv_fwd_h
+_half_images = {}      # id(weight) -> [weakref(weight), (c1, c2), image, version, data_ptr]
+
+
+def weight_pack_h(weight, c1: int, c2: int):
+    """Half image of a layer's forward weights for b2m_conv_fwd_h (include/b2m.h), cached on the tensor's version counter
+    (inference: the weights change through load_state_dict / an optimizer step, both of which bump it or move the data)."""
+    w3 = weight.detach()
+    w3 = w3 if w3.dim() == 3 else w3.unsqueeze(0)
+    assert w3.dtype == torch.float32 and w3.is_contiguous()
+    K, cin, cout = w3.shape
+    assert cin == c1 + c2
+    e = _half_images.get(id(weight))
+    if e is not None and e[0]() is weight and e[1] == (c1, c2) and e[3] == weight._version and e[4] == weight.data_ptr():
+        return e[2]
+    n = _lib.load().b2m_weight_pack_h_size(K, c1, c2, cout)
+    image = torch.empty(n, dtype=torch.float16, device=w3.device)
+    _call('b2m_weight_pack_h', w3.data_ptr(), cout, K, c1, c2, cout, image.data_ptr())
+    _half_images[id(weight)] = [weakref.ref(weight), (c1, c2), image, weight._version, weight.data_ptr()]
+    return image
+
+
+def conv_affine_h(x1, x2, weight, rb: Rulebook, n_out: int, scale=None, shift=None, residual=None, relu=False):
+    """conv_affine on HALF activations: y(half) = [relu](fmaf(conv(x1 | x2), scale, shift) [+ residual(half)]), fp32
+    accumulation, through conv_fwd_flow_kernel<.., F16> (b2m_conv_fwd_h).  Inference only; `rb` is a real rulebook (a 1x1
+    layer passes CoordinateManager.rulebook_identity)."""
+    assert x1.dtype == torch.float16 and (x2 is None or x2.dtype == torch.float16) and rb is not None
+    x1 = x1 if x1.stride(1) == 1 else x1.contiguous()
+    x2 = None if x2 is None else (x2 if x2.stride(1) == 1 else x2.contiguous())
+    w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+    K, cin, cout = w3.shape
+    c1 = x1.shape[1]
+    c2 = x2.shape[1] if x2 is not None else 0
+    assert rb.K == K and rb.n_out == n_out and c1 + c2 == cin
+    wp = weight_pack_h(weight, c1, c2)
+    out = torch.empty((n_out, cout), dtype=torch.float16, device=x1.device)
+    if n_out == 0:
+        return out
+    if residual is not None:
+        assert residual.dtype == torch.float16 and residual.stride(1) == 1
+    _call('b2m_conv_fwd_h', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2, x1.shape[0],
+          wp.data_ptr(), K, rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr(), n_out, out.data_ptr(), out.stride(0),
+          cout, _ptr(scale), _ptr(shift), _ptr(residual), residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+          meta={'half': True})
+    return out
+
+
 def conv_affine(x1, x2, weight, rb: Rulebook | None, n_out: int, scale, shift, residual=None, relu=False):
     """Inference form of conv -> eval-mode BatchNorm (+ residual) (+ ReLU): y = [relu](fmaf(conv(x), scale, shift) [+ res])
     in ONE launch where the layer's kernel can transform its strip on the way out (b2m_conv_fwd_affine), else convolution
     + b2m_bn_apply -- the same bits either way.  No autograd (the caller checks torch.is_grad_enabled()).
     (/root/reference/models/resnet.py:70-83, detection_net.py:234-337 under model.eval().)"""
+    if x1.dtype == torch.float16:                       # the half trunk (SelectionNet.half_trunk)
+        return conv_affine_h(x1, x2, weight, rb, n_out, scale, shift, residual, relu)
     x1 = _f32c(x1)
     x2 = _f32c(x2) if x2 is not None else None
     c1 = x1.shape[1]

@@ -99,7 +99,8 @@ class MinkowskiConvolution(_ConvBase):
             assert self.bias is None and not passthrough
             scale, shift = bn.eval_affine()
             if self.kernel_volume == 1:
-                rb, n_out, level = None, x1.shape[0], None
+                # (the half kernel walks rulebooks only: a 1x1 layer brings the identity map of its level)
+                rb, n_out, level = (m.rulebook_identity(l) if x1.dtype == torch.float16 else None), x1.shape[0], None
             elif self.stride == 1:
                 rb = m.rulebook_same(l, self.kernel_size); n_out, level = rb.n_out, None
             else:

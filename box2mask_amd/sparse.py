@@ -177,6 +177,17 @@ class CoordinateManager:
                 self._rb[key] = rb
         return self._rb[key]
 
+    def rulebook_identity(self, level: int) -> Rulebook:
+        """The map of a 1x1 layer on `level` as a tile rulebook (pair j of a tile = (row j, row j)): what the half-precision
+        convolution kernel, which only walks rulebooks, takes for the block shortcuts (functional.conv_affine_h)."""
+        key = ('ident', level)
+        if key not in self._rb:
+            self.ensure_level(level)
+            n = self.coords[level].shape[0]
+            nbr = torch.arange(max(n, 1), dtype=torch.int32, device=self.device).unsqueeze(0)
+            self._rb[key] = Rulebook(nbr, 1, n, n)
+        return self._rb[key]
+
     def _stride_tables(self, level: int):
         self.ensure_level(level + 1)
         nf, nc = self.n(level), self.n(level + 1)
@@ -244,7 +255,8 @@ class SparseTensor:
         self.level = level
         dev = coordinate_manager.device
         self.F = features if features.device == dev else features.to(dev, non_blocking=True)
-        if self.F.dtype != torch.float32:
+        # fp32 features; half only for the tensors the half trunk makes itself (SelectionNet.half_trunk, inference)
+        if self.F.dtype != torch.float32 and (fresh or self.F.dtype != torch.float16):
             self.F = self.F.float()
         if fresh and coordinate_manager.perm is not None:
             self.F = self.F[coordinate_manager.perm]        # rows follow the manager's internal (spatial) order

@@ -216,6 +216,22 @@ int b2m_conv_fwd_affine(const float* x1, int64_t ldx1, int32_t c1, const float* 
                         const float* scale, const float* shift, const float* res, int64_t ld_res, int32_t relu,
                         int32_t* fused, void* stream);
 
+/* Half-precision inference form of a trunk layer (BASELINE.json configs[4] "fp16 features on CDNA4"; the reference itself is
+ * fp32-only, so this is a build extension with no reference line to replace -- the layer it computes is the one of
+ * b2m_conv_fwd_affine):  Y(half) = [relu]( fmaf(conv([x1|x2](half), B(half)), scale, shift) [+ res(half)] ),  fp32 accumulation
+ * (v_mfma_f32_16x16x32_f16 / _16x16x16_f16), fp32 epilogue, one rounding to half on the way out.  x1 / x2 / res / y are IEEE
+ * binary16 with row pitches in ELEMENTS (inputs: multiples of 8, 16-byte aligned; y / res: multiples of 4); wp is the image
+ * b2m_weight_pack_h makes of the layer's (K, c1 + c2, cout) fp32 weights (b2m_weight_pack_h_size halfs).  Real rulebooks
+ * only -- a 1x1 layer passes the identity rulebook of its map (b2m_rulebook of the table 0 .. n-1, K = 1).  c1, c2, cout
+ * multiples of 16 (c1 + c2 a multiple of 32, or an even number of 16-channel chunks); rows < 2^24, inputs < 4 GiB.
+ * scale / shift NULL: plain convolution.  Small maps are split over the 4 waves of a workgroup, never further. */
+int64_t b2m_weight_pack_h_size(int32_t K, int32_t c1, int32_t c2, int32_t cout);
+int b2m_weight_pack_h(const float* w, int64_t ldw, int32_t K, int32_t c1, int32_t c2, int32_t cout, void* wp, void* stream);
+int b2m_conv_fwd_h(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int64_t ldx2, int32_t c2, int64_t n_in,
+                   const void* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                   int64_t n_out, void* y, int64_t ldy, int32_t cout, const float* scale, const float* shift,
+                   const void* res, int64_t ld_res, int32_t relu, void* stream);
+
 /* dW[k][ci][co] += sum over pairs (i,o) of offset k:  X[i, ci] * dY[o, co]     (fp32 atomics)
  * Replaces [ME] ConvolutionBackward (weight part).  x: n_in rows indexed by rb_in (ldx, cin columns used),
  * dy: rows indexed by tile*TILE+rb_out.  dw element (k,ci,co) lives at dw[k*dw_kstride + ci*lddw + co]

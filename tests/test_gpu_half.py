@@ -1,0 +1,144 @@
+"""Half-precision inference trunk (BASELINE.json configs[4]: "ARKitScenes config ... fp16 features on CDNA4"; a build extension,
+the reference is fp32-only): activations in HBM as IEEE half, f16 MFMA with fp32 accumulation, fp32 BatchNorm epilogue
+(b2m_conv_fwd_h, conv_fwd_flow_kernel<.., F16>).
+
+  1. every layer kind against the fp32 kernel on the SAME half-rounded operands (what is left is the summation order and the
+     one rounding of the result to half: <= 1e-3 of the tensor's maximum, and 2^-10 relative element by element);
+  2. the whole network: half trunk against the fp32 inference path and the CPU oracle (tolerance stated in the test: the
+     half trunk rounds every activation of ~40 layers to 11 bits).
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-9)
+
+
+@pytest.fixture(scope='module')
+def maps():
+    from test_gpu_ops import _scene
+    from box2mask_amd.sparse import CoordinateManager
+    b = _scene()
+    m = CoordinateManager(b['vox_coords'])
+    m.ensure_level(2)
+    return m
+
+
+CASES = [
+    # (kind, level, (c1, c2), cout): 32-channel chunks 2 / 3 steps in flight, 16-channel chunks; 48- and 32-column strips;
+    # un-split maps and 4 slices per workgroup (level 2)
+    ('k3', 0, (96, 0), 96), ('k3', 0, (96, 32), 96), ('k3', 0, (32, 0), 32), ('k3', 0, (64, 0), 64), ('k3', 1, (128, 0), 128),
+    ('k3', 1, (64, 0), 128), ('k3', 2, (256, 0), 256), ('k3', 2, (256, 128), 256), ('k3', 2, (96, 0), 96), ('k3', 2, (32, 0), 96),
+    ('down', 0, (32, 0), 32), ('down', 1, (96, 0), 96), ('up', 0, (96, 0), 96), ('up', 1, (256, 0), 128),
+    ('1x1', 0, (128, 0), 96), ('1x1', 0, (32, 0), 64), ('1x1', 2, (96, 32), 128), ('1x1', 1, (96, 0), 32),
+    ('k3', 0, (160, 0), 32),      # 5 chunks of 32: falls to 16-channel chunks
+]
+
+
+@pytest.mark.parametrize('res,relu,affine', [(False, True, True), (True, True, True), (False, False, True), (False, False, False)])
+@pytest.mark.parametrize('kind,level,cins,cout', CASES)
+def test_half_layer_equals_fp32_kernel_on_half_rounded_operands(maps, monkeypatch, kind, level, cins, cout, res, relu, affine):
+    from box2mask_amd import functional as F_
+    m = maps
+    c1, c2 = cins
+    if kind == 'k3':
+        rb = m.rulebook_same(level, 3); K = 27; n_in = n_out = m.n(level); rb32 = rb
+    elif kind == 'down':
+        rb = rb32 = m.rulebook_down(level); K = 8; n_in, n_out = m.n(level), m.n(level + 1)
+    elif kind == 'up':
+        rb = rb32 = m.rulebook_up(level); K = 8; n_in, n_out = m.n(level + 1), m.n(level)
+    else:
+        rb = m.rulebook_identity(level); rb32 = None; K = 1; n_in = n_out = m.n(level)
+    torch.manual_seed(zlib.crc32(repr((kind, level, cins, cout)).encode()) % 1000)
+    x1 = torch.randn(n_in, c1, device='cuda').half()
+    x2 = torch.randn(n_in, c2, device='cuda').half() if c2 else None
+    w = torch.randn(K, c1 + c2, cout, device='cuda') * (2.0 / ((c1 + c2) * min(K, 10)) ** 0.5)
+    w = w.half().float().contiguous()                          # weights exactly representable in half
+    if K == 1:
+        w = w[0].contiguous()
+    scale = (torch.rand(cout, device='cuda') + 0.5) if affine else None
+    shift = torch.randn(cout, device='cuda') if affine else None
+    r = torch.randn(n_out, cout, device='cuda').half() if res else None
+    y = F_.conv_affine_h(x1, x2, w, rb, n_out, scale, shift, r, relu)
+    assert y.dtype == torch.float16 and y.shape == (n_out, cout)
+    # reference: the fp32 kernels on the same numbers
+    one = torch.ones(cout, device='cuda'); zero = torch.zeros(cout, device='cuda')
+    ref = F_.conv_affine(x1.float(), x2.float() if c2 else None, w, rb32, n_out, scale if affine else one, shift if affine else zero,
+                         r.float() if res else None, relu)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    e = _rel(y.float(), ref)
+    assert e < 1e-3, 'half layer differs from the fp32 kernel on the same operands: %.3e' % e
+    # element by element: one rounding to half (2^-11 relative, 2^-10 allowed) + the summation order of the fp32 accumulation
+    d = (y.float() - ref).abs()
+    bound = ref.abs() * 2.0 ** -10 + 3e-5 * float(ref.abs().max())
+    assert bool((d <= bound).all()), float((d / bound).max())
+
+
+def _model_and_batch(n_vox=9000, bs=3, seed=5):
+    from test_gpu_inference import _model_and_batch as mb
+    return mb(n_vox, bs, seed)
+
+
+def test_half_trunk_network_against_fp32_inference_and_oracle():
+    from box2mask_amd import _lib
+    from oracle import unet_ref
+    model, batch, cfg = _model_and_batch()
+    p_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    p32 = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    calls = []
+    model.detection_model.half_trunk = True
+    _lib.set_hook(lambda name, a, meta=None: calls.append(name))
+    try:
+        p16 = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    finally:
+        _lib.set_hook(None)
+        model.detection_model.half_trunk = False
+    n_h = sum(1 for c in calls if c == 'b2m_conv_fwd_h')
+    n_a = sum(1 for c in calls if c == 'b2m_conv_fwd_affine')
+    assert n_h >= 75 and n_a == 1, (n_h, n_a)                 # every trunk layer but the 6-channel stem runs in half
+    ref = unet_ref.forward(p_cpu, batch['vox_coords'].numpy(), batch['vox_features'], batch['pooling_ids'], cfg,
+                           training=False, n_segments=batch['input_location'].shape[0])
+    worst = 0.0
+    for h in cfg.network_heads:
+        assert p16[h].dtype == torch.float32 and torch.isfinite(p16[h]).all()
+        e32, eo = _rel(p16[h], p32[h]), _rel(p16[h], ref[h])
+        worst = max(worst, e32, eo)
+        # ~40 layers, each rounding its activations to half (2^-11 relative): observed 2e-3 .. 6e-3 of the head's maximum
+        assert e32 < 2e-2 and eo < 2e-2, (h, e32, eo)
+    print('half trunk vs fp32 inference / oracle: worst rel-to-max %.2e' % worst)
+    # ... and the fp32 path is untouched by the switch
+    p32b = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    for h in cfg.network_heads:
+        assert _rel(p32b[h], p32[h]) < 1e-5
+
+
+def test_half_trunk_refuses_training_mode():
+    model, batch, cfg = _model_and_batch(n_vox=3000, bs=1)
+    model.detection_model.half_trunk = True
+    try:
+        model.detection_model.train()
+        with pytest.raises(RuntimeError):
+            model.get_prediction(batch, with_grad=True, to_cpu=True, min_size=False)
+    finally:
+        model.detection_model.half_trunk = False
+        model.eval()
+
+
+def test_half_weight_image_follows_the_parameters():
+    from box2mask_amd import functional as F_
+    w = torch.nn.Parameter(torch.randn(27, 32, 32, device='cuda'))
+    a = F_.weight_pack_h(w, 32, 0)
+    assert F_.weight_pack_h(w, 32, 0) is a
+    with torch.no_grad():
+        w.mul_(2.0)
+    b = F_.weight_pack_h(w, 32, 0)
+    torch.cuda.synchronize()
+    assert b is not a and torch.equal(b.float(), 2.0 * a.float())

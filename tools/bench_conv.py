@@ -74,6 +74,16 @@ for name, rb, K, c1, c2, co in cases:
             if CORUN:
                 res[v][2].append(timeit(f_both))
     line = '%-22s' % name
+    if os.environ.get('HALF') and (c1 % 16 == 0 and c2 % 16 == 0 and co % 16 == 0):
+        # the half-precision inference kernel on the same map (b2m_conv_fwd_h; a 1x1 layer through the identity rulebook)
+        for k_ in SWITCHES: os.environ.pop(k_, None)
+        _lib.reload_env()
+        rbh = rb if rb is not None else m.rulebook_identity(0)
+        x1h = x1.half(); x2h = x2.half() if c2 else None
+        wh = (w if K > 1 else w[0]).contiguous()
+        f_h = lambda: F_.conv_affine_h(x1h, x2h, wh, rbh, n_out)
+        f_h(); torch.cuda.synchronize()
+        line += ' | half fwd %6.2f TF' % (fl / min(timeit(f_h) for _ in range(4)) / 1e9)
     for v, _ in VARIANTS:
         line += ' | %s fwd %6.2f TF wg %6.2f TF' % (v, fl / min(res[v][0]) / 1e9, fl / min(res[v][1]) / 1e9)
         if CORUN:
