@@ -139,7 +139,16 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream():
+    """Handle of torch's current HIP stream on the current device.  (torch.cuda.current_stream() builds a Stream object per
+    call: 9 us of the 18 us a launch through this module cost, on ~1300 launches per training step and ~210 per batch-size-1
+    inference pass; the raw getter is what torch's own extensions use.)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -155,7 +164,7 @@ def set_hook(fn):
 def call(name, *args, meta=None):
     """Invoke a b2m_* entry on the current stream; raise B2MError on a negative return.  `meta`: facts about the call the
     raw arguments do not carry (the logical channel count of a padded input), for the observer only."""
-    lib = load()
+    lib = _lib if _lib is not None else load()
     done = _hook(name, args, meta) if _hook is not None else None
     rc = getattr(lib, name)(*args, stream())
     if done is not None:
