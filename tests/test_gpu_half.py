@@ -142,3 +142,52 @@ def test_half_weight_image_follows_the_parameters():
     b = F_.weight_pack_h(w, 32, 0)
     torch.cuda.synchronize()
     assert b is not a and torch.equal(b.float(), 2.0 * a.float())
+
+
+def test_half_trunk_on_the_arkit_and_s3dis_configurations():
+    """BASELINE configs[4] as written: 4 cm voxels, batch 4, 28 classes, features arriving as fp16, mixed scene sizes -- and the
+    S3DIS configuration, whose per-voxel head reads the trunk's (converted) output on every voxel: half trunk against the
+    fp32 inference path of the same model, instance masks from both."""
+    from test_gpu_configs import _arkit_tables, _s3dis_cfg, _s3dis_tables
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    # ---- ARKit-shaped
+    cfg = scannet_config(eval_ths=[0.5, 0.05, 0.4, 0.6], loss_weight_bb_scores=3.0, loss_weight_semantics=0.3, voxel_size=0.04, batch_size=4)
+    torch.manual_seed(1)
+    model = Model(cfg, *_arkit_tables())
+    items = [synth.make_scene(10 + i, target_voxels=tv, voxel_size=0.04, pts_per_m2=5000.0) for i, tv in enumerate([8000, 30000, 15000, 50000])]
+    batch = synth.collate(items)
+    batch['vox_features'] = batch['vox_features'].half()               # "fp16 features"
+    model.eval()
+    p32 = model.get_prediction(batch)
+    model.detection_model.half_trunk = True
+    try:
+        p16 = model.get_prediction(batch)
+        res = model.pred2mask(batch, p16, 'eval')
+    finally:
+        model.detection_model.half_trunk = False
+    assert set(res) == {s['name'] for s in batch['scene']}
+    for h in p32:
+        assert p16[h].dtype == torch.float32 and p16[h].shape == p32[h].shape
+        assert _rel(p16[h], p32[h]) < 2e-2, (h, _rel(p16[h], p32[h]))
+    # ---- S3DIS-shaped: per-voxel semantics head
+    cfg = _s3dis_cfg()
+    torch.manual_seed(0)
+    model = Model(cfg, *_s3dis_tables())
+    one = synth.collate([synth.make_scene(0, target_voxels=60_000)], mode='test')
+    model.eval()
+    p32 = model.get_prediction(one)
+    model.detection_model.half_trunk = True
+    try:
+        p16 = model.get_prediction(one)
+    finally:
+        model.detection_model.half_trunk = False
+    assert p16['mlp_per_vox_semantics'].shape == (one['vox_coords'].shape[0], 13)
+    for h in p32:
+        assert _rel(p16[h], p32[h]) < 2e-2, (h, _rel(p16[h], p32[h]))
+    # the per-voxel class decisions: equal wherever the fp32 margin between the two best classes is not a rounding matter
+    a, b = p16['mlp_per_vox_semantics'], p32['mlp_per_vox_semantics']
+    top2 = b.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2e-2 * float(b.abs().max())
+    assert bool((a.argmax(1)[clear] == b.argmax(1)[clear]).all()) and float(clear.float().mean()) > 0.5
