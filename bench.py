@@ -478,6 +478,10 @@ def main():
         result['inference'] = inference_leg(model, dev, cfg, args.target_voxels, cpu_result, rb_lookup)
         if args.features == 'f16':
             result['inference_f16'] = inference_leg(model, dev, cfg, args.target_voxels, None, rb_lookup, half=True)
+            # ... and the forward pass of the step's own batch (bs scenes at once: the launches are long enough for the device,
+            # not the host's launch rate, to set the pace), fp32 and half
+            result['inference_batched'] = inference_leg(model, dev, cfg, args.target_voxels, None, rb_lookup, own_batch=batch)
+            result['inference_batched_f16'] = inference_leg(model, dev, cfg, args.target_voxels, None, rb_lookup, half=True, own_batch=batch)
     elif args.features == 'f16' and world == 1:     # the S3DIS- / ARKit-shaped workloads: forward of their own batch, fp32 and half
         result['inference'] = inference_leg(model, dev, cfg, args.target_voxels, None, rb_lookup, own_batch=batch)
         result['inference_f16'] = inference_leg(model, dev, cfg, args.target_voxels, None, rb_lookup, half=True, own_batch=batch)

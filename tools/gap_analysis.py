@@ -20,7 +20,12 @@ def main():
         seq = rows[a:b]
         wall = (seq[-1][1] - seq[0][0]) / 1e6
         busy = sum(e - s for s, e, _ in seq) / 1e6
-        gaps = [((seq[i + 1][0] - seq[i][1]) / 1e3, seq[i][2][:50], seq[i + 1][2][:50]) for i in range(len(seq) - 1)]
+        # (kernels of the two streams overlap: a gap is the time NO kernel runs -- from the latest end so far to the next start)
+        gaps, cur_end, last = [], seq[0][1], seq[0][2]
+        for s_, e_, n_ in seq[1:]:
+            gaps.append(((s_ - cur_end) / 1e3, last[:50], n_[:50]))
+            if e_ > cur_end:
+                cur_end, last = e_, n_
         idle = sum(max(g[0], 0) for g in gaps) / 1e3
         print('step: %d kernels  wall %.2f ms  kernels %.2f ms  idle %.2f ms' % (len(seq), wall, busy, idle))
         hist = [0, 0, 0, 0]
