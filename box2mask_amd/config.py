@@ -23,6 +23,7 @@ def scannet_config(**overrides):
         mlp_bb_scores_start_epoch=100, mlp_center_scores_start_epoch=0,
         eval_ths=[0.5, 0.05, 0.3, 0.6],                                                    # configs/scannet.txt:15
         checkpoint_path='experiments/scannet/checkpoints/', voxel_size=0.02, batch_size=8, lr=1e-3,
+        half_inference=False,        # build extension (no reference field): inference on half activations, see model.Model
     )
     for k, v in overrides.items():
         setattr(cfg, k, v)

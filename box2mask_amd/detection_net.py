@@ -160,7 +160,10 @@ class SelectionNet(ResNetBase):
         # activation lives in HBM as IEEE half and every convolution (+ BatchNorm + residual + ReLU) is one
         # conv_fwd_flow_kernel<.., F16> launch -- half operands, f16 MFMA, fp32 accumulation and epilogue; the pooled
         # features and the heads are fp32 again.
-        half = bool(getattr(self, 'half_trunk', False))
+        # half_trunk: True (every pass must be an inference pass) | 'inference' (cfg.half_inference: inference passes run in half,
+        # training passes in fp32) | False
+        ht = getattr(self, 'half_trunk', False)
+        half = bool(ht) and (ht != 'inference' or self.bn0.fusable())
         if half:
             if not self.bn0.fusable():
                 raise RuntimeError('half_trunk is an inference mode: model.eval() and torch.no_grad() (and B2M_CONV_AFFINE=1)')

@@ -50,6 +50,9 @@ class Model:
         self.is_foreground = is_foreground
         self.detection_model = SelectionNet(cfg, device, semantic_valid_class_ids, is_foreground,
                                             out_channels=[96, 96, 6]).to(device)
+        # cfg.half_inference (a build extension, BASELINE configs[4] "fp16 features on CDNA4"; absent in the reference's configs):
+        # inference passes -- model.eval() + no gradients -- run the trunk on half activations (SelectionNet.half_trunk)
+        self.detection_model.half_trunk = 'inference' if getattr(cfg, 'half_inference', False) else False
         self._dp = None
         # every parameter gradient is a view into one flat buffer (one memset per step, in-place all-reduce)
         from .grad_arena import GradArena

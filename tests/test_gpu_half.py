@@ -191,3 +191,26 @@ def test_half_trunk_on_the_arkit_and_s3dis_configurations():
     top2 = b.topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 2e-2 * float(b.abs().max())
     assert bool((a.argmax(1)[clear] == b.argmax(1)[clear]).all()) and float(clear.float().mean()) > 0.5
+
+
+def test_cfg_half_inference_switches_only_the_inference_passes():
+    """cfg.half_inference: get_prediction runs the half trunk, a training step of the same model runs fp32 as before."""
+    from box2mask_amd import _lib, synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    torch.manual_seed(2)
+    model = Model(scannet_config(half_inference=True), *synth.scannet_tables(), device='cuda:0')
+    batch = synth.make_batch(2, seed0=9, target_voxels=4000, pts_per_m2=6000.0)
+    calls = []
+    _lib.set_hook(lambda name, a, meta=None: calls.append(name))
+    try:
+        model.train()
+        losses = model.compute_loss(batch, 150)
+        losses['optimization_loss'].backward()
+        n_train_h = calls.count('b2m_conv_fwd_h')
+        model.eval()
+        pred = model.get_prediction(batch)
+    finally:
+        _lib.set_hook(None)
+    assert n_train_h == 0 and calls.count('b2m_conv_fwd_h') >= 75
+    assert np.isfinite(losses['optimization_loss'].item()) and all(torch.isfinite(v).all() for v in pred.values())
