@@ -214,3 +214,34 @@ def test_cfg_half_inference_switches_only_the_inference_passes():
         _lib.set_hook(None)
     assert n_train_h == 0 and calls.count('b2m_conv_fwd_h') >= 75
     assert np.isfinite(losses['optimization_loss'].item()) and all(torch.isfinite(v).all() for v in pred.values())
+
+
+def test_half_layer_isolated_voxels_wide_pitches_and_empty_map():
+    """Rows without any neighbour (an offset's pair list empty in most tiles), operands that are column windows of wider
+    tensors (row pitch > channels), an output written into a window -- and a map without rows."""
+    from box2mask_amd import functional as F_
+    from box2mask_amd.sparse import CoordinateManager
+    c = np.array([[0, 10 * i, 7 * (i % 5), 3 * (i % 7)] for i in range(300)], np.int32)
+    c = np.unique(c, axis=0)
+    m = CoordinateManager(torch.from_numpy(c))
+    rb = m.rulebook_same(0, 3)
+    n = len(c)
+    torch.manual_seed(4)
+    wide = torch.randn(n, 160, device='cuda').half()
+    x1, x2 = wide[:, :96], wide[:, 96:128]                       # pitch 160 halfs, 16-byte aligned windows
+    w = (torch.randn(27, 128, 64, device='cuda') * 0.1).half().float()
+    res_wide = torch.randn(n, 72, device='cuda').half()
+    res = res_wide[:, 8:]                                        # pitch 72, window at an 16-byte offset
+    scale = torch.rand(64, device='cuda') + 0.5; shift = torch.randn(64, device='cuda')
+    y = F_.conv_affine_h(x1, x2, w, rb, n, scale, shift, res, True)
+    ref = F_.conv_affine(x1.float().contiguous(), x2.float().contiguous(), w, rb, n, scale, shift, res.float().contiguous(), True)
+    torch.cuda.synchronize()
+    assert _rel(y.float(), ref) < 1e-3
+    # isolated rows see only the centre offset: y = relu(x W[13] * scale + shift + res)
+    t = torch.relu((torch.cat([x1, x2], 1).float() @ w[13]) * scale + shift + res.float())
+    iso = torch.from_numpy(np.array([i for i in range(n) if i % 7 == 0])).cuda()
+    assert _rel(y.float()[iso], t[iso]) < 2e-3
+    # an empty map
+    e = F_.conv_affine_h(torch.empty(0, 32, device='cuda', dtype=torch.float16), None, w[:, :32, :32].contiguous(),
+                         CoordinateManager(torch.zeros((0, 4), dtype=torch.int32)).rulebook_same(0, 3), 0)
+    assert e.shape == (0, 32) and e.dtype == torch.float16
