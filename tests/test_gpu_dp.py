@@ -79,23 +79,28 @@ def test_syncbn_execution_modes_agree_two_ranks():
     separate layers, and the small-map half-kernels (statistics -> all-reduce -> apply) against the two-stage kernels --
     EVERY parameter gradient, the BatchNorm weights and biases included (round 3's pair wrote them from the all-reduced sums:
     world_size x too large), and the predictions."""
-    base = _run_two_ranks('gloo')
+    # (deterministic mode on both sides: the comparison is then the same on every run -- with the default fp32-atomic combines
+    # the few ReLU decisions that flip differ from run to run, and with them the worst gradient figure)
+    det = {'B2M_DETERMINISTIC': '1'}
+    base = _run_two_ranks('gloo', det)
     for what, env in (('unpaired', {'B2M_BN_PAIR': '0'}), ('two-stage small maps', {'B2M_BN_SMALL_ROWS': '0'})):
-        other = _run_two_ranks('gloo', env)
+        other = _run_two_ranks('gloo', dict(det, **env))
         for r in (0, 1):
             a, b = base[r]['named'], other[r]['named']
             assert set(a) == set(b) and len(a) > 250
-            worst = max((float(np.abs(a[n] - b[n]).max()) / max(float(np.abs(b[n]).max()), 1e-12), n) for n in a)
-            # (other summation orders through eight levels of train-mode BatchNorm on tiny maps flip a few ReLU decisions: per
-            # cent level, tests/_parity.py; the bug this guards against -- parameter gradients from the all-reduced sums -- is a
-            # factor world_size = 2, i.e. an error of 1.0 on exactly the paired layers)
-            assert worst[0] < 0.15, (what, r, worst)
-            bn = max((float(np.abs(a[n] - b[n]).max()) / max(float(np.abs(b[n]).max()), 1e-12), n) for n in a
-                     if 'downsample.1.bn' in n or 'norm2.bn' in n)
-            assert bn[0] < 0.15, (what, r, bn)
+            rel = {n: float(np.abs(a[n] - b[n]).max()) / max(float(np.abs(b[n]).max()), 1e-12) for n in a}
+            worst = max((v, n) for n, v in rel.items())
+            print(what, r, 'worst parameter-gradient difference %.3g (%s), 95th percentile %.3g' % (worst + (float(np.percentile(list(rel.values()), 95)),)))
+            # Another summation order through eight levels of train-mode BatchNorm on tiny maps flips a few ReLU decisions: single
+            # parameters move by 10-30 % (tests/_parity.py), the bulk by far less.  The bug this guards against -- parameter gradients
+            # written from the all-reduced sums -- is a factor world_size = 2, i.e. a difference of 1.0 on exactly the paired layers.
+            assert worst[0] < 0.6, (what, r, worst)
+            assert float(np.percentile(list(rel.values()), 95)) < 0.05, (what, r)
+            bn = max((v, n) for n, v in rel.items() if 'downsample.1.bn' in n or 'norm2.bn' in n)
+            assert bn[0] < 0.5, (what, r, bn)
             for h in base[r]['pred']:
                 e = np.abs(base[r]['pred'][h] - other[r]['pred'][h]).max() / max(np.abs(other[r]['pred'][h]).max(), 1e-9)
-                assert e < 1e-4, (what, r, h, e)
+                assert e < 1e-3, (what, r, h, e)
 
 
 def _two_rank_check(backend):
