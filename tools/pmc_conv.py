@@ -13,4 +13,8 @@ for _ in range(3):
 dy = torch.randn(rb.n_out, 96, device='cuda'); dw = torch.zeros_like(w)
 for _ in range(2):
     F_.wgrad_raw(x, dy, rb, 27, dw, 0)
+if os.environ.get('HALF'):          # ... and the half-precision inference kernel on the same map (b2m_conv_fwd_h)
+    xh = x.half()
+    for _ in range(3):
+        F_.conv_affine_h(xh, None, w, rb, rb.n_out)
 torch.cuda.synchronize()
