@@ -204,6 +204,9 @@ def weight_pack_h(weight, c1: int, c2: int):
     n = _lib.load().b2m_weight_pack_h_size(K, c1, c2, cout)
     image = torch.empty(n, dtype=torch.float16, device=w3.device)
     _call('b2m_weight_pack_h', w3.data_ptr(), cout, K, c1, c2, cout, image.data_ptr())
+    if e is None:                                   # a new parameter: drop the images of parameters that no longer exist
+        for k in [k for k, v in _half_images.items() if v[0]() is None]:
+            del _half_images[k]
     _half_images[id(weight)] = [weakref.ref(weight), (c1, c2), image, weight._version, weight.data_ptr()]
     return image
 
