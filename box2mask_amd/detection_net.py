@@ -144,6 +144,9 @@ class SelectionNet(ResNetBase):
         arena = getattr(self, '_grad_arena', None)
         if arena is not None and torch.is_grad_enabled():
             arena.begin_pass()                      # one memset: every parameter gradient of this pass starts at zero
+        if self.training or torch.is_grad_enabled():
+            F_.note_training_pass()                 # an optimizer step may follow: what inference caches (half weight images, eval-mode
+                                                    # BatchNorm affine maps) goes stale
 
         def T(name, t):
             if tr is not None:

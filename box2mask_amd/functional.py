@@ -187,19 +187,39 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
 
 
 # ---- half activations (inference): b2m_conv_fwd_h
-_half_images = {}      # id(weight) -> [weakref(weight), (c1, c2), image, version, data_ptr]
+_half_images = {}      # id(weight) -> [weakref(weight), (c1, c2), image, version, data_ptr, epoch]
+_half_epoch = [0]
+
+
+def note_training_pass():
+    """Advance the training epoch: everything cached for INFERENCE from parameters and running statistics -- the half weight
+    images (weight_pack_h), the eval-mode BatchNorm affine maps (nn.MinkowskiBatchNorm.eval_affine) -- is rebuilt on its next
+    use.  Called by every training-mode pass (SelectionNet.forward, every training-mode BatchNorm): an optimizer step follows,
+    and neither a fused optimizer's update of the parameters nor this package's update of the running statistics bumps the
+    tensors' version counters, so a validation pass between training steps would otherwise run on stale weights / statistics."""
+    _half_epoch[0] += 1
+
+
+def training_epoch() -> int:
+    return _half_epoch[0]
+
+
+invalidate_half_images = note_training_pass
+
 
 
 def weight_pack_h(weight, c1: int, c2: int):
-    """Half image of a layer's forward weights for b2m_conv_fwd_h (include/b2m.h), cached on the tensor's version counter
-    (inference: the weights change through load_state_dict / an optimizer step, both of which bump it or move the data)."""
+    """Half image of a layer's forward weights for b2m_conv_fwd_h (include/b2m.h), cached on the tensor's version counter and
+    address (load_state_dict, in-place edits) and on the epoch counter that every training pass advances
+    (invalidate_half_images)."""
     w3 = weight.detach()
     w3 = w3 if w3.dim() == 3 else w3.unsqueeze(0)
     assert w3.dtype == torch.float32 and w3.is_contiguous()
     K, cin, cout = w3.shape
     assert cin == c1 + c2
     e = _half_images.get(id(weight))
-    if e is not None and e[0]() is weight and e[1] == (c1, c2) and e[3] == weight._version and e[4] == weight.data_ptr():
+    if (e is not None and e[0]() is weight and e[1] == (c1, c2) and e[3] == weight._version and e[4] == weight.data_ptr()
+            and e[5] == _half_epoch[0]):
         return e[2]
     n = _lib.load().b2m_weight_pack_h_size(K, c1, c2, cout)
     image = torch.empty(n, dtype=torch.float16, device=w3.device)
@@ -207,7 +227,7 @@ def weight_pack_h(weight, c1: int, c2: int):
     if e is None:                                   # a new parameter: drop the images of parameters that no longer exist
         for k in [k for k, v in _half_images.items() if v[0]() is None]:
             del _half_images[k]
-    _half_images[id(weight)] = [weakref.ref(weight), (c1, c2), image, weight._version, weight.data_ptr()]
+    _half_images[id(weight)] = [weakref.ref(weight), (c1, c2), image, weight._version, weight.data_ptr(), _half_epoch[0]]
     return image
 
 

@@ -166,11 +166,13 @@ class MinkowskiBatchNorm(nn.Module):
                 and bn.num_features % 4 == 0 and F_.conv_affine_enabled())
 
     def eval_affine(self):
-        """(scale, shift) of the eval-mode layer, recomputed only when a parameter or running statistic changed (in-place
-        writes -- load_state_dict, an optimizer step, a training-mode forward -- bump the tensors' version counters)."""
+        """(scale, shift) of the eval-mode layer, recomputed only when a parameter or running statistic may have changed: torch's
+        in-place writes (load_state_dict, fill_) bump the tensors' version counters; the running statistics a TRAINING pass of
+        this package updates and the parameters a fused optimizer steps do not -- every training-mode BatchNorm call advances
+        functional's training epoch instead (F_.note_training_pass), which is part of the key."""
         bn = self.bn
         key = tuple((t.data_ptr(), t._version) if t is not None else None
-                    for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+                    for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)) + (F_.training_epoch(),)
         cached = getattr(self, '_affine_cache', None)
         if cached is None or cached[0] != key:
             cached = (key, F_.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps))
@@ -188,6 +190,8 @@ class MinkowskiBatchNorm(nn.Module):
                 _pending_counters.append(bn.num_batches_tracked)
             else:
                 bn.num_batches_tracked.add_(1)
+        if training:
+            F_.note_training_pass()        # running statistics are about to change behind torch's back (eval_affine)
         return F_.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                              bn.momentum, bn.eps, residual, relu, self.sync, count_key)
 
@@ -206,6 +210,8 @@ class MinkowskiBatchNorm(nn.Module):
                 _pending_counters.append(bn.num_batches_tracked)
             else:
                 bn.num_batches_tracked.add_(1)
+        if training:
+            F_.note_training_pass()
         return training, (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
 
 

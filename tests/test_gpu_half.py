@@ -214,6 +214,22 @@ def test_cfg_half_inference_switches_only_the_inference_passes():
         _lib.set_hook(None)
     assert n_train_h == 0 and calls.count('b2m_conv_fwd_h') >= 75
     assert np.isfinite(losses['optimization_loss'].item()) and all(torch.isfinite(v).all() for v in pred.values())
+    # a validation pass after further training sees the UPDATED weights and running statistics (neither a fused optimizer nor this
+    # package's BatchNorm kernels bump torch's version counters: every training pass advances functional's training epoch)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    model.train()
+    for _ in range(3):
+        opt.zero_grad()
+        model.compute_loss(batch, 150)['optimization_loss'].backward()
+        opt.step()
+    model.eval()
+    pred2 = model.get_prediction(batch)
+    model.detection_model.half_trunk = False
+    pred2_f32 = model.get_prediction(batch)
+    for h in pred:
+        assert torch.isfinite(pred2_f32[h]).all()
+        assert _rel(pred2[h], pred2_f32[h]) < 2e-2, h                  # the half pass follows the fp32 pass of the NEW state
+    assert max(_rel(pred2[h], pred[h]) for h in pred) > 1e-2             # ... which differs from the old one
 
 
 def test_half_layer_isolated_voxels_wide_pitches_and_empty_map():

@@ -172,3 +172,33 @@ def test_eval_affine_cache_follows_the_parameters():
         bn.load_state_dict(sd)
         s2, _ = bn.eval_affine()
         assert torch.allclose(s2, 2.0 * s1)
+
+
+def test_eval_between_training_steps_sees_the_new_statistics(monkeypatch):
+    """train -> eval -> train -> eval: the second inference pass must run on the running statistics and parameters as the
+    training passes in between left them.  This package's BatchNorm kernels update the running statistics through raw
+    pointers and a fused optimizer steps the parameters without bumping version counters -- the cached eval-mode affine maps
+    (MinkowskiBatchNorm.eval_affine) are keyed on functional's training epoch as well.  Reference: the unfused inference path
+    (B2M_CONV_AFFINE=0), which reads the running statistics afresh in every pass."""
+    model, batch, cfg = _model_and_batch(n_vox=4000, bs=2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+
+    def train_steps(k):
+        model.train()
+        for _ in range(k):
+            opt.zero_grad()
+            model.compute_loss(batch, 150)['optimization_loss'].backward()
+            opt.step()
+        model.eval()
+
+    def predict(fused):
+        monkeypatch.setenv('B2M_CONV_AFFINE', '1' if fused else '0')
+        return model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    train_steps(1)
+    first = predict(True)                       # builds the caches
+    train_steps(3)
+    fused, unfused = predict(True), predict(False)
+    for h in cfg.network_heads:
+        assert torch.isfinite(unfused[h]).all()
+        assert _rel(fused[h], unfused[h]) < 1e-5, (h, _rel(fused[h], unfused[h]))
+    assert max(_rel(fused[h], first[h]) for h in cfg.network_heads) > 1e-3      # the state did move
