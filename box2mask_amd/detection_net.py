@@ -140,7 +140,9 @@ class SelectionNet(ResNetBase):
         cbr = self._cbr
         tr = getattr(self, '_trace', None)          # optional dict: named intermediates for parity debugging
         F_.join_side_streams()                      # (a backward pass that died half-way leaves its side stream un-joined)
-        F_.packed_weights.begin_pass()              # one launch repacks every layer's weight images for this pass
+        # one launch repacks every layer's weight images for this pass (an inference pass keeps the previous ones if no
+        # training pass ran in between)
+        F_.packed_weights.begin_pass(inference=not (self.training or torch.is_grad_enabled()))
         arena = getattr(self, '_grad_arena', None)
         if arena is not None and torch.is_grad_enabled():
             arena.begin_pass()                      # one memset: every parameter gradient of this pass starts at zero

@@ -202,3 +202,26 @@ def test_eval_between_training_steps_sees_the_new_statistics(monkeypatch):
         assert torch.isfinite(unfused[h]).all()
         assert _rel(fused[h], unfused[h]) < 1e-5, (h, _rel(fused[h], unfused[h]))
     assert max(_rel(fused[h], first[h]) for h in cfg.network_heads) > 1e-3      # the state did move
+
+
+def test_inference_passes_follow_load_state_dict(monkeypatch):
+    """Two inference passes with a load_state_dict in between (no training pass: the packed weight images of the first pass
+    are kept by default) -- the second one runs on the loaded weights: the copies bump the parameters' version counters and
+    the images are rebuilt at lookup.  Checked against a fresh model that never saw the old weights."""
+    model, batch, cfg = _model_and_batch(n_vox=4000, bs=2)
+    first = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    again = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    for h in cfg.network_heads:
+        assert _rel(again[h], first[h]) < 1e-5
+    torch.manual_seed(77)
+    sd = {k: (v + 0.05 * torch.randn_like(v) if v.is_floating_point() and 'running_var' not in k and v.dim() > 0 else v.clone())
+          for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    loaded = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    fresh, _, _ = _model_and_batch(n_vox=4000, bs=2)
+    fresh.load_state_dict(sd)
+    fresh.eval()
+    ref = fresh.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    for h in cfg.network_heads:
+        assert _rel(loaded[h], ref[h]) < 1e-5, (h, _rel(loaded[h], ref[h]))
+    assert max(_rel(loaded[h], first[h]) for h in cfg.network_heads) > 1e-3
