@@ -225,3 +225,29 @@ def test_inference_passes_follow_load_state_dict(monkeypatch):
     for h in cfg.network_heads:
         assert _rel(loaded[h], ref[h]) < 1e-5, (h, _rel(loaded[h], ref[h]))
     assert max(_rel(loaded[h], first[h]) for h in cfg.network_heads) > 1e-3
+
+
+def test_validation_losses_between_training_steps_like_the_reference_trainer(monkeypatch):
+    """/root/reference/models/training.py:64-66, 263-284: `model.train(); compute_loss; backward; step` with, every so often,
+    `model.eval(); with torch.no_grad(): compute_loss(val_batch)`.  The validation passes run the fused inference layers; their
+    losses must be those of the unfused layering (B2M_CONV_AFFINE=0) on the model's CURRENT state at every validation."""
+    model, batch, cfg = _model_and_batch(n_vox=4000, bs=2)
+    val_batch = _model_and_batch(n_vox=3000, bs=2, seed=9)[1]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+
+    def val(fused):
+        monkeypatch.setenv('B2M_CONV_AFFINE', '1' if fused else '0')
+        model.eval()
+        with torch.no_grad():
+            return {k: float(v) for k, v in model.compute_loss(val_batch, 150).items() if hasattr(v, 'item') or isinstance(v, float)}
+    seen = []
+    for it in range(3):
+        model.train()
+        opt.zero_grad()
+        model.compute_loss(batch, 150)['optimization_loss'].backward()
+        opt.step()
+        a, b = val(True), val(False)
+        for k in a:
+            assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(b[k])), (it, k, a[k], b[k])
+        seen.append(a['optimization_loss'])
+    assert len(set(round(v, 6) for v in seen)) == 3           # the state moved between the validations
