@@ -78,7 +78,11 @@ __device__ __forceinline__ void store_half4(const ConvArgs& a, f32x4 v, int64_t 
     }
     f16x4 h;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) h[u] = (_Float16)v[u];
+    for (int u = 0; u < 4; ++u) {
+        // saturate instead of overflowing to infinity (|x| > 65504: an un-normalised activation; inf - inf = NaN three layers on)
+        const float c = __builtin_fminf(__builtin_fmaxf(v[u], -65504.f), 65504.f);
+        h[u] = (_Float16)c;
+    }
     *(f16x4*)((_Float16*)a.y + grow * a.ldy + col) = h;
 }
 

@@ -261,3 +261,16 @@ def test_half_layer_isolated_voxels_wide_pitches_and_empty_map():
     e = F_.conv_affine_h(torch.empty(0, 32, device='cuda', dtype=torch.float16), None, w[:, :32, :32].contiguous(),
                          CoordinateManager(torch.zeros((0, 4), dtype=torch.int32)).rulebook_same(0, 3), 0)
     assert e.shape == (0, 32) and e.dtype == torch.float16
+
+
+def test_half_output_saturates_instead_of_overflowing(maps):
+    from box2mask_amd import functional as F_
+    m = maps
+    rb = m.rulebook_same(2, 3); n = m.n(2)
+    x = torch.full((n, 32), 200.0, device='cuda').half()
+    w = torch.full((27, 32, 32), 8.0, device='cuda')
+    y = F_.conv_affine_h(x, None, w, rb, n)                      # 200 * 8 * 32 * (>= 1 neighbour) = 51 200 per neighbour
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all() and float(y.float().max()) == 65504.0
+    y = F_.conv_affine_h(x, None, -w, rb, n)
+    assert torch.isfinite(y.float()).all() and float(y.float().min()) == -65504.0
