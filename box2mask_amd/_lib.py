@@ -25,6 +25,7 @@ F64 = C.c_double
 PROTOTYPES = {
     'b2m_coords_build': [P, I64, P, P, I64, P, P],
     'b2m_morton_keys': [P, I64, P, P],
+    'b2m_hilbert_keys': [P, I64, I32, P, P],
     'b2m_coords_stride': [P, I64, I32, P, P, P, P, P, I64, P, C.POINTER(I64), P],
     'b2m_kernel_map': [P, I64, I32, I32, P, P, I64, P, I32, I32, I32, P, I64, P],
     'b2m_occupancy': [P, I64, I32, I32, I32, I32, P, I64, P],

@@ -78,10 +78,14 @@ class CoordinateManager:
         if reorder and c0.shape[0] > 1:
             n0 = c0.shape[0]
             keys = torch.empty(n0, dtype=torch.int64, device=dev)
-            _lib.call('b2m_morton_keys', c0.data_ptr(), n0, keys.data_ptr())
+            bits = max(int(mx).bit_length(), 1) if (check and coords.numel()) else 16
+            # row order: Hilbert curve (B2M_ROW_ORDER=morton: Z-order, the order of rounds 1-3)
+            if os.environ.get('B2M_ROW_ORDER', 'hilbert') == 'morton':
+                _lib.call('b2m_morton_keys', c0.data_ptr(), n0, keys.data_ptr())
+            else:
+                _lib.call('b2m_hilbert_keys', c0.data_ptr(), n0, bits, keys.data_ptr())
             # radix argsort over the key bits that can differ: 3 x bitlength(largest coordinate) interleaved bits + the
             # batch index at bit 48 (the bounds check above read the maximum; without it all 64 bits)
-            bits = max(int(mx).bit_length(), 1) if (check and coords.numel()) else 16
             mask = ((1 << (3 * bits)) - 1) | (((1 << bits) - 1) << 48)
             self.perm = torch.empty(n0, dtype=torch.int64, device=dev)
             self.inv_perm = torch.empty(n0, dtype=torch.int64, device=dev)

@@ -52,6 +52,10 @@ int b2m_coords_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* 
  * fewer active offsets per tile, better L2 locality of the gathers); row order is otherwise free ([ME] gives no
  * order guarantee beyond input order, which the host restores at the boundary).  Requires b < 32768. */
 int b2m_morton_keys(const int32_t* coords, int64_t n, int64_t* keys, void* stream);
+/* Hilbert-curve key per coordinate row, same layout (batch index in bits 48.., 3 x `bits` index bits below; every coordinate
+ * < 2^bits, bits <= 16): the default row order -- a curve without the Z-order's jumps gives more compact tiles (denser
+ * rulebook groups, fewer active offsets per tile). */
+int b2m_hilbert_keys(const int32_t* coords, int64_t n, int32_t bits, int64_t* keys, void* stream);
 
 /* Stable argsort of n 64-bit keys (LSD radix sort, 8 bits per pass, only over the bytes in which `bit_mask` has a bit: the bits
  * that can differ between keys; ~0 = all eight): perm[j] = index of the j-th smallest key, inv_perm[perm[j]] = j (int64, ready
