@@ -302,3 +302,26 @@ def test_hilbert_keys_walk_a_dense_cube_cell_by_cell_and_match_the_restatement()
     m = CoordinateManager(torch.from_numpy(cu), reorder=True)
     order = np.argsort(_hilbert_keys_numpy(cu, int(cu.max()).bit_length()), kind='stable')
     assert np.array_equal(m.perm.cpu().numpy(), order)
+
+
+def test_row_order_switch_morton_keeps_the_z_order(monkeypatch):
+    """B2M_ROW_ORDER=morton: the manager's rows follow b2m_morton_keys (batch index, then interleaved x / y / z bits) -- the order
+    of rounds 1-3, kept for A/B -- and a network forward is the same function of its input in either order."""
+    from box2mask_amd.sparse import CoordinateManager
+    rng = np.random.default_rng(5)
+    c = np.unique(np.concatenate([rng.integers(0, 2, (4000, 1)), rng.integers(0, 300, (4000, 3))], 1), axis=0).astype(np.int32)
+
+    def zkey(c):
+        k = c[:, 0].astype(np.uint64) << np.uint64(48)
+        for bit in range(16):
+            for a, sh in ((1, 0), (2, 1), (3, 2)):
+                k |= ((c[:, a].astype(np.uint64) >> np.uint64(bit)) & np.uint64(1)) << np.uint64(3 * bit + sh)
+        return k
+    monkeypatch.setenv('B2M_ROW_ORDER', 'morton')
+    m = CoordinateManager(torch.from_numpy(c), reorder=True)
+    assert np.array_equal(m.perm.cpu().numpy(), np.argsort(zkey(c), kind='stable'))
+    monkeypatch.delenv('B2M_ROW_ORDER')
+    h = CoordinateManager(torch.from_numpy(c), reorder=True)
+    assert not np.array_equal(h.perm.cpu().numpy(), m.perm.cpu().numpy())
+    # the same kernel map in both orders: pairs of level-0 k3, as (input coordinate, output coordinate, offset) sets
+    assert m.rulebook_same(0, 3).pairs == h.rulebook_same(0, 3).pairs
