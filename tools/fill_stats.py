@@ -16,7 +16,36 @@ def morton(c):
         k |= ((y>>bit)&1).astype(np.uint64) << np.uint64(3*bit+1)
         k |= ((z>>bit)&1).astype(np.uint64) << np.uint64(3*bit)
     return np.argsort(k, kind='stable')
-c = c[morton(c)]
+def hilbert(c, nbits=12):
+    """Row order along a Hilbert curve (Skilling's transform; the product's b2m_hilbert_keys)."""
+    X = np.stack([c[:,1]-c[:,1].min(), c[:,2]-c[:,2].min(), c[:,3]-c[:,3].min()], 1).astype(np.uint64).copy()
+    M = np.uint64(1) << np.uint64(nbits - 1)
+    Q = M
+    while Q > 1:
+        P = Q - np.uint64(1)
+        for a in range(3):
+            sel = (X[:, a] & Q) != 0
+            X[sel, 0] ^= P
+            ns = ~sel
+            t = (X[ns, 0] ^ X[ns, a]) & P
+            X[ns, 0] ^= t; X[ns, a] ^= t
+        Q >>= np.uint64(1)
+    X[:, 1] ^= X[:, 0]; X[:, 2] ^= X[:, 1]
+    t = np.zeros(len(X), np.uint64)
+    Q = M
+    while Q > 1:
+        t[(X[:, 2] & Q) != 0] ^= (Q - np.uint64(1))
+        Q >>= np.uint64(1)
+    X ^= t[:, None]
+    k = np.zeros(len(X), np.uint64)
+    for bit in range(nbits):
+        for a in range(3):
+            k |= ((X[:, a] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(3*bit + (2-a))
+    return np.argsort(k, kind='stable')
+import os
+ORDER = os.environ.get('ORDER', 'hilbert')             # ORDER=morton: the Z-order of rounds 1-3
+print('row order:', ORDER)
+c = c[hilbert(c) if ORDER == 'hilbert' else morton(c)]
 for lvl in range(4):
     ts = 1<<lvl
     nbr = np.asarray(S.kernel_map_same(c, 3, ts))
@@ -30,3 +59,4 @@ for lvl in range(4):
         print('level', lvl, 'N', N, 'T', T, 'pairs/row %.1f'%(v.sum()/N), 'avg cnt/active %.1f'%v[act].mean(), 'active/tile %.1f'%act.sum(0).mean(),
               'useful %.3f'%(v.sum()/ (16*g.sum())), 'G hist', np.round(np.bincount(g[act].ravel(), minlength=T//16+1)/act.sum(),2))
     c = S.stride_coords(c, ts)[0].astype(np.int64)
+    c = c[hilbert(c) if ORDER == 'hilbert' else morton(c)]
