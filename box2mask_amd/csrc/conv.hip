@@ -648,6 +648,7 @@ __global__ __launch_bounds__(256, 4) void conv_stem_kernel(ConvArgs a) {
 }
 
 #include "conv_fwd_flow.h"
+#include "conv_fwd_coop.h"
 #include "conv_1x1.h"
 
 static int env_flag(const char* name, int dflt);
@@ -980,6 +981,27 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
             }
             const int dbg = env_flag("B2M_PIPE_DBG", 0);      // diagnostic builds, wrong results: tools/pipe_breakdown.py
             const int hl = env_flag("B2M_CONV_HANDLOADS", 1);     // hand-issued operand loads, absent row groups masked (conv_fwd_flow.h)
+            // un-split maps with enough tiles: four tiles per workgroup, their pair lists cut into units of <= 64 pairs
+            // (conv_fwd_coop.h); not in deterministic mode (the waves' flushes into the shared strip are ordered by a lock)
+            if (hl && depth == 2 && !dbg && wpb == 1 && K <= 32 && n_in < (1 << 23) && nc % 2 == 0 &&
+                a.ntiles >= env_flag("B2M_CONV_COOP_MIN_TILES", 512) && !env_flag("B2M_DETERMINISTIC", 0) && env_flag("B2M_CONV_COOP", 0)) {
+                const int64_t nst = cdiv64(a.ntiles, 4);
+                a.nwg = nst * a.nstrips;
+                a.xcd_start = nullptr; a.tile_order = nullptr; a.wg_per_tile = 0;
+                const XcdOrder co = xcd_order(a.nwg, xcd_tiles > 0 ? (int64_t)1 << 40 : 0);
+                a.xcd_per = co.chunk;
+                const int cdbg = env_flag("B2M_COOP_DBG", 0);
+                if (cdbg == 1 && TW == 3) conv_fwd_coop_kernel<3, 1><<<co.grid, 256, 0, st>>>(a);
+                else if (cdbg == 2 && TW == 3) conv_fwd_coop_kernel<3, 0, 1><<<co.grid, 256, 0, st>>>(a);
+                else if (cdbg == 3 && TW == 3) conv_fwd_coop_kernel<3, 1, 1><<<co.grid, 256, 0, st>>>(a);
+                else if (cdbg == 1) conv_fwd_coop_kernel<2, 1><<<co.grid, 256, 0, st>>>(a);
+                else if (cdbg == 2) conv_fwd_coop_kernel<2, 0, 1><<<co.grid, 256, 0, st>>>(a);
+                else if (cdbg == 3) conv_fwd_coop_kernel<2, 1, 1><<<co.grid, 256, 0, st>>>(a);
+                else if (TW == 3) conv_fwd_coop_kernel<3><<<co.grid, 256, 0, st>>>(a);
+                else conv_fwd_coop_kernel<2><<<co.grid, 256, 0, st>>>(a);
+                B2M_LAUNCH_CHECK();
+                return B2M_OK;
+            }
             if (hl && depth == 2 && !dbg) {
                 if (wpb == 4) {
                     if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4, 1><<<fo.grid, 256, 0, st>>>(a);
