@@ -24,6 +24,7 @@ struct ConvArgs {
     int64_t n_out, ntiles;
     float* y; int64_t ldy; int cout; int accumulate; int nstrips; int vec_store;
     int nslice;      // >1: the tile's active offsets are dealt to nslice waves which add their strips atomically
+    int chain;       // conv_fwd_flow_kernel, un-split maps: full visits first, chained in registers (conv_fwd_flow.h)
     int fast32;      // rows < 2^24, pitches < 2^22 floats, tensors < 4 GiB: 24-bit multiply + 32-bit byte offsets
     const float* zeros;   // address of g_zeros passed as data (a select of addresses, not a branch around the load)
     int ncs;         // chunk slices: a slice is (offset slice, part ncs of the input-channel chunks); nslice % ncs == 0
@@ -874,7 +875,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
     a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
-    a.stats = nullptr;
+    a.stats = nullptr; a.chain = 0;
     a.ep_scale = a.ep_shift = a.ep_res = nullptr; a.ld_res = 0; a.ep_relu = 0;
     a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr;
     const int TW = conv_tw(cout, K);
@@ -961,6 +962,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
         if (depth >= 2 && !ident && fast && KC == 16 && split_ok && a.fast32 && nc % ncs == 0 && (nc / ncs) % depth == 0 &&
             nc / ncs >= depth) {
             const int wpb = nslice == 1 ? 1 : 4;
+            a.chain = (wpb == 1 && env_flag("B2M_CONV_CHAIN", 1)) ? 1 : 0;
             // the workgroup that writes a (tile, strip) sees its final values: un-split maps, or exactly 4 slices
             // combined in LDS and stored plainly
             if (tile_stats && (nslice == 1 || (nslice == 4 && !accumulate))) {
@@ -999,6 +1001,11 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 else if (cdbg == 3) conv_fwd_coop_kernel<2, 1, 1><<<co.grid, 256, 0, st>>>(a);
                 else if (TW == 3) conv_fwd_coop_kernel<3><<<co.grid, 256, 0, st>>>(a);
                 else conv_fwd_coop_kernel<2><<<co.grid, 256, 0, st>>>(a);
+                B2M_LAUNCH_CHECK();
+                return B2M_OK;
+            }
+            if (hl && depth == 2 && dbg == 32 && wpb == 1 && TW == 3) {       // diagnostic: the walk twice per wave
+                conv_fwd_flow_kernel<2, 3, 32, 1, 1><<<fo.grid, 64, 0, st>>>(a);
                 B2M_LAUNCH_CHECK();
                 return B2M_OK;
             }

@@ -139,6 +139,10 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     const int strip = (int)(item % a.nstrips);
     if (tile >= a.ntiles) return;             // the whole workgroup leaves (its waves share the item)
     B2M_CLOCK_BEGIN();
+#ifdef B2M_STAMPS
+    unsigned long long fs_begin, fs_init = 0, fs_pro = 0, fs_t0 = 0, fs_t1 = 0, fs_t2 = 0, fs_loop = 0, fs_flush = 0, fs_adv = 0, fs_vis = 0, fs_walk = 0, fs_stat = 0;
+    if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) { B2M_STAMP(fs_begin); }
+#endif
     if (a.tile_order) tile = a.tile_order[tile];
     const int col0 = strip * SW;
     float* Cs = smem + wave * STRIP;
@@ -165,6 +169,11 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         *(f32x4*)&Cs[row * PITCH + c4] = v;
     }
 
+#ifdef B2M_STAMPS
+            if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
+    B2M_STAMP(fs_init);
+            }
+#endif
     // ---- active offsets (K <= 128): lane k holds the pair count of offset k / k + 64
     int cnt0 = 0, cnt1 = 0;
     if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
@@ -175,29 +184,55 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         m0 = __ballot(cnt0 > 0 && r0 % nks == slice);
         m1 = __ballot(cnt1 > 0 && r1 % nks == slice);
     }
-    auto next_active = [&](int k) -> int {    // first active offset after k, or -1 (scalar)
+    // Round 5: FULL visits first, chained in registers.  A visit with all 64 pairs (a third of the visits on the benchmark's
+    // level-0 maps, a fifth on level 1: tools/fill_stats_units.py) maps pair j to output row j, so consecutive full visits add
+    // into the SAME accumulator tiles: walked first, they need one flush at the end of their chain instead of one each -- half
+    // of the flush work of a level-0 tile (a flush is 2 * G * TW 16-byte LDS accesses on the wave's critical path).  An offset
+    // is carried as k | 128 once the walk has left the full ones (un-split maps only; ConvArgs::chain).
+    uint64_t f0 = 0, f1 = 0;
+    if constexpr (WPB == 1) {
+        if (a.chain) { f0 = __ballot(cnt0 == B2M_TILE); f1 = __ballot(cnt1 == B2M_TILE); m0 &= ~f0; m1 &= ~f1; }
+    }
+    auto next_in = [&](uint64_t a0, uint64_t a1, int k) -> int {    // first set offset after k, or -1 (scalar)
         int kk = k + 1;
         if (kk < 64) {
-            const uint64_t r = m0 >> kk;
+            const uint64_t r = a0 >> kk;
             if (r) return kk + __builtin_ctzll(r);
             kk = 64;
         }
         if (kk < 128) {
-            const uint64_t r = m1 >> (kk - 64);
+            const uint64_t r = a1 >> (kk - 64);
             if (r) return kk + __builtin_ctzll(r);
         }
         return -1;
     };
-    auto groups_of = [&](int k) -> int {
+    auto next_active = [&](int e) -> int {    // offset after e (-1: the first) in the walk: the full ones, then the rest | 128
+        int k = e < 0 ? -1 : (e & 127);
+        if constexpr (WPB == 1) {
+            if (e < 128) {
+                const int r = next_in(f0, f1, k);
+                if (r >= 0) return r;
+                k = -1;
+            }
+        }
+        const int r = next_in(m0, m1, k);
+        return r < 0 ? -1 : (r | 128);
+    };
+    auto groups_of = [&](int e) -> int {
+        const int k = e & 127;
         const int n = k < 64 ? __builtin_amdgcn_readlane(cnt0, k) : __builtin_amdgcn_readlane(cnt1, k - 64);
         return (n + 15) >> 4;
     };
 
+    // (DBG & 32, diagnostic: the walk runs TWICE per wave -- what a launch costs per wave outside the walk shows as
+    // 2 * T(plain) - T(this); results are wrong by the second pass's sums)
+#pragma unroll 1
+    for (int rep = 0; rep < ((DBG & 32) ? 2 : 1); ++rep) {
     int kC = next_active(-1);
     if (kC >= 0) {
         // pair list of an offset: slot `lane` -> word = input row | output row << 24 (padded slot: row 0, output row 64)
-        auto list_load = [&](int k, int& r_in, int& r_out) {
-            const int64_t base = (int64_t)k * ldr + row0 + lane;
+        auto list_load = [&](int e, int& r_in, int& r_out) {
+            const int64_t base = (int64_t)(e & 127) * ldr + row0 + lane;
             r_in = a.rb_in[base];
             r_out = a.rb_out[base];
         };
@@ -205,8 +240,8 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         // many operand loads are younger -- instead of hipcc's vmcnt(0), which cannot see the hand-issued loads and would drain
         // all of them at every offset advance
         const uint32_t lane4 = (uint32_t)lane * 4u;
-        auto list_load_hl = [&](int k, int& r_in, int& r_out) {
-            const int64_t base = (int64_t)k * ldr + row0;                  // wave-uniform
+        auto list_load_hl = [&](int e, int& r_in, int& r_out) {
+            const int64_t base = (int64_t)(e & 127) * ldr + row0;          // wave-uniform
             const int32_t* pin = a.rb_in + base;
             const uint8_t* pout = a.rb_out + base;
             asm volatile("global_load_dword %0, %1, %2" : "=v"(r_in) : "v"(lane4), "s"(pin) : "memory");
@@ -261,8 +296,8 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                 av[j][g] = *(const opv*)(src + off);
             }
         };
-        auto weights = [&](int j, int k, int c) {
-            const uint32_t blk = (uint32_t)k * wkstride + wstrip + (uint32_t)c;     // wave-uniform
+        auto weights = [&](int j, int e, int c) {
+            const uint32_t blk = (uint32_t)(e & 127) * wkstride + wstrip + (uint32_t)c;     // wave-uniform
             const char* wsrc = (const char*)a.wp + (size_t)blk * (size_t)(F16 == 2 ? LW * 2 : LW * 4);
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
@@ -368,6 +403,12 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         };
 
         for (;;) {
+#ifdef B2M_STAMPS
+            if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
+            B2M_STAMP(fs_t0);
+            if (fs_vis == 0 && fs_loop == 0 && fs_pro == 0) fs_pro = fs_t0;
+            }
+#endif
             int c0 = cb;
             do {                              // (bottom-tested, ce - cb >= D: with a zero-trip path hipcc cannot count the loads behind the
                                               // pair-list fetch and drains the whole queue -- s_waitcnt vmcnt(0) -- at every offset advance)
@@ -403,8 +444,15 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                 }
                 c0 += D;
             } while (c0 < ce);
+#ifdef B2M_STAMPS
+            if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
+            B2M_STAMP(fs_t1); fs_loop += fs_t1 - fs_t0;
+            }
+#endif
             // ---- add the offset's result into the strip: lane (i,q) holds channels 16t + 4q .. +3 of pair 16g + i;
-            // padded pairs (output row 64) take no part
+            // padded pairs (output row 64) take no part.  Not between two full visits: the next one adds into the same tiles
+            const bool chained = WPB == 1 && kC < 128 && kN >= 0 && kN < 128;
+            if (!chained) {
             asm volatile("s_nop 15" ::: "memory");        // MFMA result -> VALU read: >= 11 wait states (8-pass MFMA)
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -424,6 +472,12 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
                     for (int t = 0; t < TW; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+            }
+#ifdef B2M_STAMPS
+            if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
+            B2M_STAMP(fs_t2); fs_flush += fs_t2 - fs_t1; fs_vis += 1;
+            }
+#endif
             if (kN < 0) break;
             // ---- advance: next offset becomes current; the list fetched an offset ago becomes next; fetch one more
             kC = kN;
@@ -442,13 +496,24 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             kNN = kN < 0 ? -1 : next_active(kN);
             if constexpr (HL) list_load_hl(kNN < 0 ? kNc : kNN, rawi, rawo);
             else list_load(kNN < 0 ? kNc : kNN, rawi, rawo);
+#ifdef B2M_STAMPS
+            if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
+            { unsigned long long t3; B2M_STAMP(t3); fs_adv += t3 - fs_t2; }
+            }
+#endif
         }
         // hand-issued loads: the last round's prefetches are still in flight and the compiler, which cannot see them, is about
         // to reuse their destination registers (addresses of the write-out!): drain them first
         if constexpr (HL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
+    }
 
+#ifdef B2M_STAMPS
+            if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
+    B2M_STAMP(fs_walk);
+            }
+#endif
     // ---- write the strip (rows of the strip are 16-byte aligned: coalesced vector stores)
     if constexpr (WPB > 1) {
         __syncthreads();
@@ -488,6 +553,11 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         return;
     }
     if (!F16 && a.stats) tile_column_sums(a, Cs, tile, row0, col0, lane);
+#ifdef B2M_STAMPS
+            if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
+    B2M_STAMP(fs_stat);
+            }
+#endif
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         const int64_t grow = row0 + row;
@@ -507,6 +577,17 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             for (int u = 0; u < 4; ++u) if (col + u < a.cout) dst[u] = v[u];
         }
     }
+#ifdef B2M_STAMPS
+    if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
+        unsigned long long fs_end; B2M_STAMP(fs_end);
+        if (lane == 0) {
+            atomicAdd(&g_stamps[0], fs_pro - fs_begin); atomicAdd(&g_stamps[1], fs_loop); atomicAdd(&g_stamps[2], fs_flush);
+            atomicAdd(&g_stamps[3], fs_adv); atomicAdd(&g_stamps[4], fs_end - fs_walk); atomicAdd(&g_stamps[5], fs_end - fs_begin);
+            atomicAdd(&g_stamps[6], fs_vis); atomicAdd(&g_stamps[7], 1ull); atomicAdd(&g_stamps[8], fs_stat - fs_walk);
+            atomicAdd(&g_stamps[9], fs_init - fs_begin);
+        }
+    }
+#endif
     B2M_CLOCK_END(0);
 }
 #undef tile_column_sums
