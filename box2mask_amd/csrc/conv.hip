@@ -108,6 +108,44 @@ extern "C" int b2m_debug_clocks(unsigned long long* out8, int reset) {
 #define B2M_CLOCK_END(slot) do { } while (0)
 #endif
 
+// The shader clock the chip holds under fp32-MFMA load (bench.py: before and after the bracketed roofline passes, so that a
+// fraction of the 2.4 GHz peak can be read against the clock the lease actually ran at).  Three waves per SIMD run `iters`
+// blocks of 12 v_mfma_f32_16x16x4_f32 (the convolution kernels' block); every wave stamps s_memtime (shader cycles) and
+// s_memrealtime (100 MHz) around its loop: out[0] += cycles, out[1] += ticks, out[2] += waves.
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* out, int iters, float seed) {
+    f32x4 acc[3];
+    float av[4], bv[12];
+    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) av[i] = seed + threadIdx.x * 1e-3f + i;
+    for (int i = 0; i < 12; ++i) bv[i] = seed * 0.5f + threadIdx.x * 2e-3f - i;
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i % 3]) : "v"(av[i / 3]), "v"(bv[i]));
+    }
+    asm volatile("s_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+    float sink = 0.f;
+    for (int i = 0; i < 3; ++i) sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], c1 - c0); atomicAdd(&out[1], r1 - r0); atomicAdd(&out[2], 1ull);
+        if (sink == 12345.678f) out[3] = 1ull;                 // (keeps the MFMAs alive)
+    }
+}
+extern "C" int b2m_clock_probe(unsigned long long* out4, int32_t iters, void* stream) {
+    B2M_CHECK_ARG(out4 && iters >= 1 && iters <= (1 << 20), "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    B2M_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(unsigned long long), st));
+    clock_probe_kernel<<<768, 256, 0, st>>>(out4, iters, 1.0f);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
 // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  Consecutive
 // tiles are neighbours in space (Morton row order) and gather largely the same input rows, so an XCD should work on
 // CONTIGUOUS runs of the work -- with the plain order the same rows were fetched into up to 8 L2s (PMC: L2-miss
@@ -649,7 +687,6 @@ __global__ __launch_bounds__(256, 4) void conv_stem_kernel(ConvArgs a) {
 }
 
 #include "conv_fwd_flow.h"
-#include "conv_fwd_coop.h"
 #include "conv_1x1.h"
 
 static int env_flag(const char* name, int dflt);
@@ -962,6 +999,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
         if (depth >= 2 && !ident && fast && KC == 16 && split_ok && a.fast32 && nc % ncs == 0 && (nc / ncs) % depth == 0 &&
             nc / ncs >= depth) {
             const int wpb = nslice == 1 ? 1 : 4;
+            B2M_CHECK_ARG(items0 < (1ll << 31), "too many (tile, strip) items");      // (32-bit index arithmetic in the kernel)
             a.chain = (wpb == 1 && env_flag("B2M_CONV_CHAIN", 1)) ? 1 : 0;
             // the workgroup that writes a (tile, strip) sees its final values: un-split maps, or exactly 4 slices
             // combined in LDS and stored plainly
@@ -983,27 +1021,6 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
             }
             const int dbg = env_flag("B2M_PIPE_DBG", 0);      // diagnostic builds, wrong results: tools/pipe_breakdown.py
             const int hl = env_flag("B2M_CONV_HANDLOADS", 1);     // hand-issued operand loads, absent row groups masked (conv_fwd_flow.h)
-            // un-split maps with enough tiles: four tiles per workgroup, their pair lists cut into units of <= 64 pairs
-            // (conv_fwd_coop.h); not in deterministic mode (the waves' flushes into the shared strip are ordered by a lock)
-            if (hl && depth == 2 && !dbg && wpb == 1 && K <= 32 && n_in < (1 << 23) && nc % 2 == 0 &&
-                a.ntiles >= env_flag("B2M_CONV_COOP_MIN_TILES", 512) && !env_flag("B2M_DETERMINISTIC", 0) && env_flag("B2M_CONV_COOP", 0)) {
-                const int64_t nst = cdiv64(a.ntiles, 4);
-                a.nwg = nst * a.nstrips;
-                a.xcd_start = nullptr; a.tile_order = nullptr; a.wg_per_tile = 0;
-                const XcdOrder co = xcd_order(a.nwg, xcd_tiles > 0 ? (int64_t)1 << 40 : 0);
-                a.xcd_per = co.chunk;
-                const int cdbg = env_flag("B2M_COOP_DBG", 0);
-                if (cdbg == 1 && TW == 3) conv_fwd_coop_kernel<3, 1><<<co.grid, 256, 0, st>>>(a);
-                else if (cdbg == 2 && TW == 3) conv_fwd_coop_kernel<3, 0, 1><<<co.grid, 256, 0, st>>>(a);
-                else if (cdbg == 3 && TW == 3) conv_fwd_coop_kernel<3, 1, 1><<<co.grid, 256, 0, st>>>(a);
-                else if (cdbg == 1) conv_fwd_coop_kernel<2, 1><<<co.grid, 256, 0, st>>>(a);
-                else if (cdbg == 2) conv_fwd_coop_kernel<2, 0, 1><<<co.grid, 256, 0, st>>>(a);
-                else if (cdbg == 3) conv_fwd_coop_kernel<2, 1, 1><<<co.grid, 256, 0, st>>>(a);
-                else if (TW == 3) conv_fwd_coop_kernel<3><<<co.grid, 256, 0, st>>>(a);
-                else conv_fwd_coop_kernel<2><<<co.grid, 256, 0, st>>>(a);
-                B2M_LAUNCH_CHECK();
-                return B2M_OK;
-            }
             if (hl && depth == 2 && dbg == 32 && wpb == 1 && TW == 3) {       // diagnostic: the walk twice per wave
                 conv_fwd_flow_kernel<2, 3, 32, 1, 1><<<fo.grid, 64, 0, st>>>(a);
                 B2M_LAUNCH_CHECK();
@@ -1519,8 +1536,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
         const int64_t base = kbase + (int64_t)ti * B2M_TILE + 16 * g;      // wave-uniform
         const int32_t* pin = a.rb_in + base;
         const uint8_t* pout = a.rb_out + base;
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(r_in) : "v"((uint32_t)i * 4u), "s"(pin) : "memory");
-        asm volatile("global_load_ubyte %0, %1, %2" : "=v"(r_out) : "v"((uint32_t)i), "s"(pout) : "memory");
+        // (destinations as IN/OUT operands, like the operand loads: the registers stay allocated up to the statement that
+        // waits for them, whatever hipcc moves in between)
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(r_in) : "v"((uint32_t)i * 4u), "s"(pin) : "memory");
+        asm volatile("global_load_ubyte %0, %1, %2" : "+v"(r_out) : "v"((uint32_t)i), "s"(pout) : "memory");
     };
     // the word of pair 4s + q for k-step s
     auto words = [&](int r_in, int r_out, uint32_t (&w)[4]) {
@@ -1570,7 +1589,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     // prologue: list + operands of slot 0, list of slot 1, list load of slot 2
     int tiC = __builtin_ctzll(live), gC = 0;
     uint32_t wC[4], wN[4];
-    int rawi, rawo;
+    int rawi = 0, rawo = 0;
     int tiN = tiC, gN = gC;
     bool hasN = advance(tiN, gN);
     {

@@ -135,8 +135,9 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         cb = NC / a.ncs * cslice; ce = cb + NC / a.ncs;
         lead = sl == 0;
     }
-    int64_t tile = item / a.nstrips;
-    const int strip = (int)(item % a.nstrips);
+    // (32-bit: a launch has < 2^31 items -- the 64-bit division is ~200 scalar instructions at the head of every wave)
+    int64_t tile = (int64_t)((uint32_t)item / (uint32_t)a.nstrips);
+    const int strip = (int)((uint32_t)item % (uint32_t)a.nstrips);
     if (tile >= a.ntiles) return;             // the whole workgroup leaves (its waves share the item)
     B2M_CLOCK_BEGIN();
 #ifdef B2M_STAMPS
@@ -149,6 +150,10 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     const int64_t ldr = a.ntiles * B2M_TILE;
     const int64_t row0 = tile * B2M_TILE;
 
+    // the pair counts of the tile's offsets: issued first, their round trip runs beside the strip init
+    int cnt0 = 0, cnt1 = 0;
+    if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
+    if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
     // ---- init the strip: 0 | Y (accumulate) | + bias
     for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
@@ -174,10 +179,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     B2M_STAMP(fs_init);
             }
 #endif
-    // ---- active offsets (K <= 128): lane k holds the pair count of offset k / k + 64
-    int cnt0 = 0, cnt1 = 0;
-    if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
-    if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
+    // ---- active offsets (K <= 128): lane k holds the pair count of offset k / k + 64 (loaded above the strip init)
     uint64_t m0 = __ballot(cnt0 > 0), m1 = __ballot(cnt1 > 0);
     if constexpr (WPB > 1) {                  // keep the active offsets whose rank among the active ones is ours
         const int r0 = prefix_popc(m0), r1 = __builtin_popcountll(m0) + prefix_popc(m1);
@@ -244,8 +246,10 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             const int64_t base = (int64_t)(e & 127) * ldr + row0;          // wave-uniform
             const int32_t* pin = a.rb_in + base;
             const uint8_t* pout = a.rb_out + base;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(r_in) : "v"(lane4), "s"(pin) : "memory");
-            asm volatile("global_load_ubyte %0, %1, %2" : "=v"(r_out) : "v"((uint32_t)lane), "s"(pout) : "memory");
+            // (destinations as IN/OUT operands, like the operand loads: the registers stay allocated up to the statement
+            // that waits for them, whatever hipcc moves in between)
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(r_in) : "v"(lane4), "s"(pin) : "memory");
+            asm volatile("global_load_ubyte %0, %1, %2" : "+v"(r_out) : "v"((uint32_t)lane), "s"(pout) : "memory");
         };
         auto list_words = [&](int r_in, int r_out, uint32_t (&w)[NG]) {
             const uint32_t word = r_in < 0 ? ((uint32_t)B2M_TILE << 24) : ((uint32_t)r_in | ((uint32_t)r_out << 24));
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
 
         // ---- prologue: lists of the first three offsets, operands of the first D steps
         uint32_t wC[NG], wN[NG];
-        int rawi, rawo;
+        int rawi = 0, rawo = 0;
         int kN = next_active(kC);
         int kNc = kN < 0 ? kC : kN;
         int kNN = kN < 0 ? -1 : next_active(kN);

@@ -777,7 +777,7 @@ extern "C" int b2m_radix_argsort(const uint64_t* keys, int64_t n, uint64_t bit_m
 }
 
 extern "C" int b2m_hilbert_keys(const int32_t* coords, int64_t n, int32_t bits, int64_t* keys, void* stream) {
-    B2M_CHECK_ARG(coords && keys && n >= 0 && bits >= 1 && bits <= 16, "bad arguments (1 <= bits <= 16)");
+    B2M_CHECK_ARG(n >= 0 && (n == 0 || (coords && keys)) && bits >= 1 && bits <= 16, "bad arguments (1 <= bits <= 16)");
     if (n == 0) return B2M_OK;
     hilbert_keys_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, (hipStream_t)stream>>>(coords, n, bits, keys);
     B2M_LAUNCH_CHECK();

@@ -214,6 +214,21 @@ def training_epoch() -> int:
 invalidate_half_images = note_training_pass
 
 
+def _after_optimizer_step(optimizer, args, kwargs):
+    note_training_pass()
+
+
+# Parameters also change where no training-mode pass of this package comes first: `eval pass, optimizer.step(), eval pass`
+# (the step belongs to a backward pass from before the first eval pass), or a raw-pointer / fused update that bumps no version
+# counter.  Every torch optimizer step therefore advances the epoch too (one global post-step hook, an integer increment);
+# parallel.GradAllReduce.broadcast_parameters, which writes through `p.data`, calls note_training_pass itself.
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(_after_optimizer_step)
+except ImportError:          # (torch < 2.0 has no global hook: the training-mode pass is the only signal there)
+    pass
+
+
 
 def weight_pack_h(weight, c1: int, c2: int):
     """Half image of a layer's forward weights for b2m_conv_fwd_h (include/b2m.h), cached on the tensor's version counter and
@@ -388,6 +403,7 @@ class _SparseConv(torch.autograd.Function):
                      logical_cin=c1 if x1.shape[1] != c1 else None)
         ctx.save_for_backward(x1, x2, weight, bias)
         ctx.rb_f, ctx.rb_b, ctx.mirror, ctx.c1 = rb_f, rb_b, mirror, c1
+        ctx.src1, ctx.src2 = _node_id(in1), _node_id(in2)     # the nodes the data gradients are made for (`_own`)
         if passthrough:
             # The inputs come back as second / third outputs: whoever else consumes them (the residual branch of a
             # BasicBlock, its 1x1 shortcut) takes THESE, so their gradients arrive here, in one call with dy, and the data
@@ -410,18 +426,18 @@ class _SparseConv(torch.autograd.Function):
         dx1 = dx2 = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = packed_weights.get(weight, True, ctx.mirror, 0, c1)
-            acc = _accumulation_target(p1, x1.shape[0], c1)
+            acc = _accumulation_target(p1, x1.shape[0], c1, id(ctx))
             dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1, out=acc, accumulate=acc is not None)
             if p1 is not None and acc is None:
                 dx1 = dx1 + p1
-            _own(dx1)
+            _own(dx1, ctx.src1)
         if x2 is not None and ctx.needs_input_grad[1]:
             wt = packed_weights.get(weight, True, ctx.mirror, c1, x2.shape[1])
-            acc = _accumulation_target(p2, x2.shape[0], x2.shape[1])
+            acc = _accumulation_target(p2, x2.shape[0], x2.shape[1], id(ctx))
             dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1], out=acc, accumulate=acc is not None)
             if p2 is not None and acc is None:
                 dx2 = dx2 + p2
-            _own(dx2)
+            _own(dx2, ctx.src2)
         if ctx.needs_input_grad[2]:
             # the weight's slot in the model's gradient arena (zeroed once per pass, adopted by autograd as .grad), else a
             # zero-filled tensor of the weight's own shape
@@ -455,26 +471,33 @@ class _SparseConv(torch.autograd.Function):
         return dx1, dx2, dw, db, None, None, None, None, None, None
 
 
-def _own(t):
-    """Mark a gradient tensor this package produced itself and returns to autograd for exactly ONE input (a data
-    gradient, BatchNorm's dx / residual gradient): nobody else holds it, so a later data-gradient kernel may add onto it
-    in place."""
+def _node_id(t) -> int:
+    """Identity of the backward node that will receive the gradient of forward tensor `t` (0: a leaf / no graph)."""
+    fn = getattr(t, 'grad_fn', None) if t is not None else None
+    return id(fn) if fn is not None else 0
+
+
+def _own(t, target: int):
+    """Mark a gradient tensor this package produced itself for exactly ONE input, with the backward node it is meant for
+    (`target` = _node_id of that input, taken in forward): nobody else holds it, so THAT node's data-gradient kernel may add
+    onto it in place."""
     if t is not None:
-        t._b2m_own = True
+        t._b2m_own = target
     return t
 
 
-def _accumulation_target(g, n: int, c: int):
+def _accumulation_target(g, n: int, c: int, node: int):
     """The gradient of a passed-through input, if the data gradient may be added onto it in place: a dense fp32 (n, c)
-    tensor that owns its memory AND was produced by one of this package's backward operators for this input alone
-    (`_own`).  A gradient that comes from a torch operator may be the same TensorImpl another branch still holds
-    (AddBackward0 hands one tensor to both inputs): adding in place would corrupt that branch, so those are summed out of
-    place.  Limit of the mark: it is an attribute of the tensor object and survives a torch operator that forwards the SAME
-    tensor (AddBackward0 again): a model that puts a torch elementwise add on FEATURE tensors between two operators of this
-    package must run with B2M_CONV_PASSTHROUGH=0.  SelectionNet has no such add (every add is fused into BatchNorm)."""
+    tensor that owns its memory AND was produced by one of this package's backward operators for THIS node's output alone
+    (`_own` carries the id of the node the gradient was made for; `node` = id of the convolution's own backward node).
+    A gradient that went through a torch operator first is not accepted even when it is the very tensor object this
+    package produced: AddBackward0 hands ONE tensor to both of its inputs, the mark then names the add node, not this
+    one, and adding in place would corrupt the other branch -- such gradients are summed out of place
+    (tests/test_gpu_determinism.py::test_torch_add_between_two_convolutions).  The mark is consumed here."""
     if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n, c) or not g.is_contiguous() or g._base is not None:
         return None
-    if not getattr(g, '_b2m_own', False):
+    mark = g.__dict__.pop('_b2m_own', None)
+    if mark is None or mark == 0 or mark != node:
         return None
     return g
 
@@ -544,6 +567,7 @@ class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, sync,
                 count_key=None, tile_stats=None):
+        ctx.src_x, ctx.src_res = _node_id(x), _node_id(residual)      # the nodes dx / dres are made for (`_own`)
         x = _f32c(x)
         n, c = x.shape
         dev = x.device
@@ -652,8 +676,8 @@ class _BatchNorm(torch.autograd.Function):
                 dbeta = g.sum(0)
                 invstd = torch.rsqrt(ctx.eval_var + ctx.eval_eps)
                 dgamma = ((g * x).sum(0) - dbeta * ctx.eval_mean) * invstd
-            return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                    None, None, None, None, None, _own(gres), None, None, None, None)
+            return (_own(dx, ctx.src_x), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                    None, None, None, None, None, _own(gres, ctx.src_res), None, None, None, None)
         # parameter gradients in buffers of their own: autograd adopts such a tensor as .grad, a view would be cloned
         dbeta, dgamma = grad_slot(beta), grad_slot(gamma)
         if dbeta is None or dgamma is None:
@@ -669,15 +693,15 @@ class _BatchNorm(torch.autograd.Function):
             dist.all_reduce(xchg, op=dist.ReduceOp.SUM, group=group)
             _call('b2m_bn_small_bwd_phase', 2, *args, None, None, dx.data_ptr(), dx.stride(0), _ptr(dres),
                   dres.stride(0) if dres is not None else 0, xchg.data_ptr(), ctx.count_dev.data_ptr())
-            return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                    None, None, None, None, None, _own(dres), None, None, None, None)
+            return (_own(dx, ctx.src_x), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                    None, None, None, None, None, _own(dres, ctx.src_res), None, None, None, None)
         if ctx.small and dy.stride(0) % 4 == 0 and group is None:
             _call('b2m_bn_small_bwd', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
                   x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), relu, _ptr(mscale), _ptr(mshift),
                   dbeta.data_ptr(), dgamma.data_ptr(), dx.data_ptr(), dx.stride(0), _ptr(dres),
                   dres.stride(0) if dres is not None else 0)
-            return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                    None, None, None, None, None, _own(dres), None, None, None, None)
+            return (_own(dx, ctx.src_x), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                    None, None, None, None, None, _own(dres, ctx.src_res), None, None, None, None)
         partial = torch.empty(2 * c * _RED_BLOCKS, dtype=torch.float64, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         _call('b2m_bn_bwd_reduce', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
@@ -692,8 +716,8 @@ class _BatchNorm(torch.autograd.Function):
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), gsums.data_ptr(),
               count, _ptr(ctx.count_dev), relu, _ptr(mscale), _ptr(mshift), dx.data_ptr(), dx.stride(0), _ptr(dres),
               dres.stride(0) if dres is not None else 0)
-        return (_own(dx), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, _own(dres), None, None, None, None)
+        return (_own(dx, ctx.src_x), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                None, None, None, None, None, _own(dres, ctx.src_res), None, None, None, None)
 
 
 def bn_pair() -> bool:
@@ -712,6 +736,7 @@ class _BatchNormPair(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xa, ga, ba, rma, rva, xb, gb, bb, rmb, rvb, training, mom_a, eps_a, mom_b, eps_b, relu, sync,
                 tile_stats_a=None, tile_stats_b=None):
+        ctx.src_a, ctx.src_b = _node_id(xa), _node_id(xb)
         xa, xb = _f32c(xa), _f32c(xb)
         n, c = xa.shape
         assert xb.shape == (n, c)
@@ -781,13 +806,13 @@ class _BatchNormPair(torch.autograd.Function):
         if not ctx.training:
             g = dy if not relu else dy * (y > 0)
             outs = []
-            for x, gam, scale, (rm, rv, eps), ig, ib in ((xa, ga, mean_a, ctx.eval_stats[0:3], 1, 2),
-                                                          (xb, gb, mean_b, ctx.eval_stats[3:6], 6, 7)):
+            for x, gam, scale, (rm, rv, eps), ig, ib, src in ((xa, ga, mean_a, ctx.eval_stats[0:3], 1, 2, ctx.src_a),
+                                                               (xb, gb, mean_b, ctx.eval_stats[3:6], 6, 7, ctx.src_b)):
                 dgam = dbet = None
                 if need[ig] or need[ib]:
                     dbet = g.sum(0)
                     dgam = ((g * x).sum(0) - dbet * rm) * torch.rsqrt(rv + eps)
-                outs.append((_own(g * scale.reshape(1, -1)), dgam if need[ig] else None, dbet if need[ib] else None))
+                outs.append((_own(g * scale.reshape(1, -1), src), dgam if need[ig] else None, dbet if need[ib] else None))
             (dxa, dga, dba), (dxb, dgb, dbb) = outs
             return (dxa, dga, dba, None, None, dxb, dgb, dbb, None, None) + (None,) * 9
         dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
@@ -817,8 +842,8 @@ class _BatchNormPair(torch.autograd.Function):
               inv_b.data_ptr(), _ptr(gb), gsums.data_ptr(), ctx.count, _ptr(ctx.count_dev), relu, dxa.data_ptr(),
               dxa.stride(0), dxb.data_ptr(), dxb.stride(0), dba.data_ptr(), dga.data_ptr(), dbb.data_ptr(), dgb.data_ptr(),
               sums.data_ptr())
-        return (_own(dxa), dga if need[1] else None, dba if need[2] else None, None, None,
-                _own(dxb), dgb if need[6] else None, dbb if need[7] else None, None, None) + (None,) * 9
+        return (_own(dxa, ctx.src_a), dga if need[1] else None, dba if need[2] else None, None, None,
+                _own(dxb, ctx.src_b), dgb if need[6] else None, dbb if need[7] else None, None, None) + (None,) * 9
 
 
 def batch_norm_pair(xa, bn_a, xb, bn_b, training, relu=True, sync=False, count_key=None):

@@ -286,12 +286,6 @@ class Model:
             out['semantics_mIoU'] = _LazyMean(argmax, gt_sem)
         return out
 
-    def sync_gradients(self):
-        """Kept for callers of the first release: the data-parallel gradient mean (DDP's job in the reference,
-        model.py:24) now completes by itself when `backward()` returns, so this is a no-op."""
-        if self._dp is not None:
-            self._dp.all_reduce_mean()
-
     def get_prediction(self, batch, with_grad=False, to_cpu=True, min_size=True, get_all=False):
         return self.detection_model.get_prediction(batch, with_grad=with_grad, to_cpu=to_cpu, min_size=min_size)
 

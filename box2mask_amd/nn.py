@@ -96,8 +96,11 @@ class MinkowskiConvolution(_ConvBase):
         x1, x2 = _sources(x)
         if fuse is not None:
             bn, residual, relu = fuse
-            assert self.bias is None and not passthrough
+            if passthrough:
+                raise ValueError('fuse= and passthrough= exclude each other (inference has no gradients to pass through)')
             scale, shift = bn.eval_affine()
+            if self.bias is not None:       # BN(conv + b) = conv * scale + (shift + scale * b): the bias folds into the shift
+                shift = shift + scale * self.bias.detach().reshape(-1).to(scale.dtype)
             if self.kernel_volume == 1:
                 # (the half kernel walks rulebooks only: a 1x1 layer brings the identity map of its level)
                 rb, n_out, level = (m.rulebook_identity(l) if x1.dtype == torch.float16 else None), x1.shape[0], None
@@ -141,8 +144,9 @@ class MinkowskiConvolutionTranspose(_ConvBase):
         rb_f, rb_b = m.rulebook_up(l), m.rulebook_down(l)
         if fuse is not None:             # inference: see MinkowskiConvolution.forward
             bn, residual, relu = fuse
-            assert self.bias is None
             scale, shift = bn.eval_affine()
+            if self.bias is not None:       # (as above: the bias folds into the shift)
+                shift = shift + scale * self.bias.detach().reshape(-1).to(scale.dtype)
             return x.new(F_.conv_affine(x1, x2, self.kernel, rb_f, rb_f.n_out, scale, shift, residual, relu), level=l)
         y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out,
                            collect_stats=self.training and self.bias is None)

@@ -146,6 +146,10 @@ class GradAllReduce:
         # reference's DDP broadcasts module buffers too, torch's `broadcast_buffers=True` default; model.py:24)
         for b in self.buffers:
             dist.broadcast(b.data, src=src, group=self.group)
+        # written through `.data`: no version counter moved -- what inference caches from the parameters / statistics
+        # (packed and half weight images, eval-mode BatchNorm affine maps) is rebuilt on its next use
+        from . import functional as F_
+        F_.note_training_pass()
 
     def all_reduce_mean(self):
         """Explicit form for callers without hooks (overlap=False): all-reduce now.  With hooks the work was done

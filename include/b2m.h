@@ -248,6 +248,12 @@ int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const
                    const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                    int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace, void* stream);
 
+/* Measurement aid (bench.py `roofline.clock_mhz`; no counterpart in the reference): the shader clock the device holds
+ * under fp32-MFMA load.  768 workgroups x 4 waves run `iters` blocks of 12 v_mfma_f32_16x16x4_f32; every wave stamps
+ * s_memtime (shader cycles) and s_memrealtime (100 MHz ticks) around its loop.  out4 (device, zeroed by the call):
+ * [0] sum of cycles, [1] sum of ticks, [2] waves; clock = out4[0] / out4[1] * 100 MHz. */
+int b2m_clock_probe(unsigned long long* out4, int32_t iters, void* stream);
+
 /* ---------------------------------------------------------------- batch norm / elementwise (fp32, HBM-bound) */
 
 /* Column sums for BatchNorm: stats[0:c] = sum x, stats[c:2c] = sum x^2 (double), deterministic

@@ -133,3 +133,42 @@ def test_passthrough_inputs_give_the_same_gradients(monkeypatch):
     assert g1.keys() == g0.keys() and len(g1) > 250
     worst = max(float((g1[n] - g0[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-12) for n in g0)
     assert worst < 2e-4, worst
+
+
+def test_torch_add_between_two_convolutions(monkeypatch):
+    """A torch elementwise add on FEATURE tensors between two convolutions of this package (`box2mask_amd.nn` used as "ME" by
+    a model other than SelectionNet).  AddBackward0 hands ONE gradient tensor to both of its inputs; one of them is the
+    passed-through input of a convolution whose data-gradient kernel adds onto such gradients in place.  The mark that
+    permits the in-place add names the backward node a gradient was made for (functional._own), so the tensor that went
+    through the add is summed out of place and the other branch keeps its gradient: every gradient equals the run without
+    passed-through inputs."""
+    from box2mask_amd import functional as F_, synth
+    from box2mask_amd.sparse import CoordinateManager
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    b = synth.make_batch(2, seed0=3, target_voxels=6000, pts_per_m2=8000.0)
+    m = CoordinateManager(b['vox_coords'].cuda(), reorder=True)
+    rb = m.rulebook_same(0, 3)
+    n, c = rb.n_out, 32
+
+    def run(passthrough):
+        torch.manual_seed(11)
+        a = torch.randn(n, c, device='cuda', requires_grad=True)
+        ws = [torch.nn.Parameter(torch.randn(27, c, c, device='cuda') * 0.05) for _ in range(4)]
+        r1, r2 = torch.randn(n, c, device='cuda'), torch.randn(n, c, device='cuda')
+        conv = lambda x, w, **kw: F_.sparse_conv(x, None, w, None, rb, rb, True, n, **kw)
+        h = conv(a, ws[0])
+        t = conv(a, ws[3])      # (made BEFORE the convolution below: the engine then runs that one's backward first, and an
+        #                         in-place add onto the shared gradient would be read by this branch)
+        if passthrough:
+            y1, hp, _ = conv(h, ws[1], passthrough=True)      # the other consumers of h take the alias hp
+        else:
+            y1, hp = conv(h, ws[1]), h
+        z = torch.add(hp, t)                                   # a torch operator between two package convolutions
+        v = conv(z, ws[2])
+        ((y1 * r1).sum() + (v * r2).sum()).backward()
+        torch.cuda.synchronize()
+        return [a.grad.clone()] + [w.grad.clone() for w in ws]
+    g1 = run(True)
+    g0 = run(False)
+    for x1, x0 in zip(g1, g0):
+        assert float((x1 - x0).abs().max()) <= 1e-5 * max(float(x0.abs().max()), 1e-12)

@@ -204,6 +204,43 @@ def test_eval_between_training_steps_sees_the_new_statistics(monkeypatch):
     assert max(_rel(fused[h], first[h]) for h in cfg.network_heads) > 1e-3      # the state did move
 
 
+def test_eval_after_an_optimizer_step_without_a_training_pass_in_between(monkeypatch):
+    """backward, EVAL pass, optimizer.step(), eval pass: the step belongs to a backward pass from before the first eval pass, so
+    no training-mode pass separates the two inference passes -- the fused optimizer bumps no version counter, and the second
+    pass must still run on the stepped weights (every torch optimizer step advances functional's training epoch).  The same
+    for parameters written through `.data` by GradAllReduce.broadcast_parameters (here: its single-rank equivalent, a copy
+    through `.data` followed by the invalidation it performs).  Reference: a fresh model loaded with the final state."""
+    from box2mask_amd import functional as F_
+    model, batch, cfg = _model_and_batch(n_vox=4000, bs=2)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, fused=True)
+    predict = lambda m: m.get_prediction(batch, with_grad=False, to_cpu=True, min_size=False)
+    model.train()
+    opt.zero_grad()
+    model.compute_loss(batch, 150)['optimization_loss'].backward()
+    model.eval()
+    before = predict(model)                      # caches built from the un-stepped weights
+    opt.step()
+    after = predict(model)
+    fresh, _, _ = _model_and_batch(n_vox=4000, bs=2)
+    fresh.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    fresh.eval()
+    want = predict(fresh)
+    for h in cfg.network_heads:
+        assert _rel(after[h], want[h]) < 1e-5, (h, _rel(after[h], want[h]))
+    assert max(_rel(after[h], before[h]) for h in cfg.network_heads) > 1e-4          # the step did move the outputs
+    # parameters replaced through .data (what a broadcast from another rank does), then the invalidation broadcast_parameters ends with
+    torch.manual_seed(5)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data.copy_(p.data + 0.05 * torch.randn_like(p.data) * p.data.abs().mean())
+    F_.note_training_pass()
+    moved = predict(model)
+    fresh.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    want = predict(fresh)
+    for h in cfg.network_heads:
+        assert _rel(moved[h], want[h]) < 1e-5, (h, _rel(moved[h], want[h]))
+
+
 def test_inference_passes_follow_load_state_dict(monkeypatch):
     """Two inference passes with a load_state_dict in between (no training pass: the packed weight images of the first pass
     are kept by default) -- the second one runs on the loaded weights: the copies bump the parameters' version counters and
