@@ -58,12 +58,21 @@ class LaunchTimer:
             cin = (meta_in or {}).get('cin', args[2] + args[5])
             meta = dict(cin=cin, cout=args[16], K=args[8], n_out=args[13], rb_cnt=args[12], n_in=args[6],
                         acc=int(args[17]))
+        elif name == 'b2m_conv_up':
+            # x1, ldx1, c1, x2, ldx2, c2, n_coarse, wp, K, bias, rb_in, rb_out, rb_cnt (the DOWN rulebook), y, ldy, cout, n_fine, acc
+            # (counted with b2m_conv_fwd; a call the kernel declined -- *ran == 0 -- is followed by b2m_conv_fwd and not recorded)
+            meta = dict(cin=args[2] + args[5], cout=args[15], K=args[8], n_out=args[6], rb_cnt=args[12], n_in=args[6],
+                        acc=int(args[17]), ran=(meta_in or {}).get('ran'), n_fine=args[16])
         else:   # b2m_conv_wgrad: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
             meta = dict(cin=args[2], cout=args[6], K=args[11], n_out=args[10], rb_cnt=args[9], n_in=args[3])
 
         meta['step'] = self.step_id
 
         def done():
+            if name == 'b2m_conv_up':
+                ran = meta.pop('ran', None)
+                if ran is not None and not ran.value:
+                    return
             e.record()
             self.records.append((name, _Pair(s, e), None, meta))
         return done
@@ -222,7 +231,7 @@ def main():
     # (b2m_conv_fwd: `roofline_timed_region`, as it ran), and K more steps AFTER the H2D-inclusive repeat run with the side
     # stream off and all three kernels bracketed (`roofline`, `roofline_wgrad`, `roofline_bn_apply`: every kernel alone on
     # the chip, which is what a roofline fraction is about).
-    timer = LaunchTimer(['b2m_conv_fwd', 'b2m_conv_fwd_stats'])
+    timer = LaunchTimer(['b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_up'])
     _lib.set_hook(timer.hook)
 
     # Model.prefetch: the NEXT batch's sparse tensor (Morton order, coordinate hash, 7 strided + 16 kernel maps) is built
@@ -333,7 +342,7 @@ def main():
     timed_records = timer.records
     timer.records = []
     timer._drained = 0
-    timer.names = {'b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_wgrad', 'b2m_bn_apply'}
+    timer.names = {'b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_up', 'b2m_conv_wgrad', 'b2m_bn_apply'}
     prev_wgrad_stream = os.environ.get('B2M_WGRAD_STREAM')        # (a user-set value is restored afterwards)
     os.environ['B2M_WGRAD_STREAM'] = '0'
     _lib.reload_env()
@@ -374,7 +383,7 @@ def main():
         if name == 'b2m_bn_apply':
             hbm['ms'] += ms; hbm['bytes'] += meta['bytes']; hbm['launches'] += 1
             continue
-        if name == 'b2m_conv_fwd_stats':
+        if name in ('b2m_conv_fwd_stats', 'b2m_conv_up'):
             name = 'b2m_conv_fwd'
         P = pairs_of(meta, cache, rb_lookup)
         flops = 2.0 * P * meta['cin'] * meta['cout']
@@ -394,7 +403,7 @@ def main():
         for name, s_, e_, meta in timer.records:
             if name == 'b2m_bn_apply':
                 continue
-            key = ('conv_fwd' if name == 'b2m_conv_fwd_stats' else name[4:], meta['K'], meta['cin'], meta['cout'], meta['n_out'])
+            key = ('conv_fwd' if name == 'b2m_conv_fwd_stats' else name[4:], meta['K'], meta['cin'], meta['cout'], meta.get('n_fine', meta['n_out']))
             d = shapes.setdefault(key, [0.0, 0.0, 0])
             d[0] += s_.elapsed_time(e_); d[1] += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']; d[2] += 1
         print('%-11s %4s %4s %4s %9s %6s %9s %8s' % ('kernel', 'K', 'cin', 'cout', 'n_out', 'calls', 'ms/step', 'TFLOP/s'), file=sys.stderr)
@@ -443,8 +452,8 @@ def main():
     # the heaviest layer shapes of the dominant kernel, each with its own fraction (same isolated-kernel pass)
     shp = {}
     for name, s_, e_, meta in timer.records:
-        if name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats'):
-            d_ = shp.setdefault((meta['K'], meta['cin'], meta['cout'], meta['n_out']), [0.0, 0.0, 0])
+        if name in ('b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_up'):
+            d_ = shp.setdefault((meta['K'], meta['cin'], meta['cout'], meta.get('n_fine', meta['n_out'])), [0.0, 0.0, 0])
             d_[0] += s_.elapsed_time(e_); d_[1] += 2.0 * pairs_of(meta, cache, rb_lookup) * meta['cin'] * meta['cout']; d_[2] += 1
     roofline['top_shapes'] = [
         {'K': k_[0], 'cin': k_[1], 'cout': k_[2], 'rows': k_[3], 'launches_per_step': v_[2] // max(args.steps, 1),
@@ -846,16 +855,23 @@ def _inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=1
 
     def hook(name, a, meta_in=None):
         launches[name] = launches.get(name, 0) + 1
-        if name not in ('b2m_conv_fwd_affine', 'b2m_conv_fwd', 'b2m_conv_fwd_h'):
+        if name not in ('b2m_conv_fwd_affine', 'b2m_conv_fwd', 'b2m_conv_fwd_h', 'b2m_conv_up'):
             return None
         s_ = torch.cuda.Event(enable_timing=True); e_ = torch.cuda.Event(enable_timing=True)
         cin = (meta_in or {}).get('cin', a[2] + a[5])
         # b2m_conv_fwd_affine: x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, ...
-        meta = dict(cin=cin, cout=a[15], K=a[8], n_out=a[12], rb_cnt=a[11], half=name == 'b2m_conv_fwd_h') if name != 'b2m_conv_fwd' else \
-            dict(cin=cin, cout=a[16], K=a[8], n_out=a[13], rb_cnt=a[12])
+        if name == 'b2m_conv_up':        # ..., n_coarse, wp, K, bias, rb_in, rb_out, rb_cnt (DOWN rulebook), y, ldy, cout, n_fine, ...
+            meta = dict(cin=cin, cout=a[15], K=a[8], n_out=a[6], rb_cnt=a[12], half=False)
+        elif name != 'b2m_conv_fwd':
+            meta = dict(cin=cin, cout=a[15], K=a[8], n_out=a[12], rb_cnt=a[11], half=name == 'b2m_conv_fwd_h')
+        else:
+            meta = dict(cin=cin, cout=a[16], K=a[8], n_out=a[13], rb_cnt=a[12])
+        ran = (meta_in or {}).get('ran')
         s_.record()
 
         def done():
+            if name == 'b2m_conv_up' and ran is not None and not ran.value:      # declined: b2m_conv_fwd(_affine) follows
+                return
             e_.record()
             rec.append((s_, e_, meta))
         return done

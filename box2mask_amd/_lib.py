@@ -41,6 +41,7 @@ PROTOTYPES = {
     'b2m_weight_pack_h': [P, I64, I32, I32, I32, I32, P, P],
     'b2m_conv_fwd_stats': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P, P, P],
     'b2m_clock_probe': [P, I32, P],
+    'b2m_conv_up': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, P, I64, I32, I64, I32, P, P, P, I64, I32, P, P],
     'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
     'b2m_weight_pack_run': [P, I32, I64, P],
     'b2m_conv_wgrad': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P, P],

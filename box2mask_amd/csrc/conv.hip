@@ -1124,6 +1124,66 @@ extern "C" int b2m_conv_fwd_affine(const float* x1, int64_t ldx1, int32_t c1, co
     return conv_fwd_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, nullptr, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, 0, nullptr,
                          nullptr, stream, &ep, fused);
 }
+// Transposed k2s2 convolution (and the data gradient of the strided one) in scatter form: conv_fwd_flow_kernel<.., UP>
+// over the map's DOWN rulebook (tiled over the n_coarse input rows; rb_in = fine row, rb_out = coarse row inside the tile).
+// *ran = 0: the shape is not one the kernel takes (odd channel counts, a handful of tiles) -- nothing was launched and the
+// caller runs b2m_conv_fwd on the UP rulebook instead.
+extern "C" int b2m_conv_up(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2, int64_t n_coarse,
+                           const float* wp, int32_t K, const float* bias, const int32_t* rb_in, const uint8_t* rb_out,
+                           const int32_t* rb_cnt, float* y, int64_t ldy, int32_t cout, int64_t n_fine, int32_t accumulate,
+                           const float* scale, const float* shift, const float* res, int64_t ld_res, int32_t relu,
+                           int32_t* ran, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(ran, "ran is NULL");
+    *ran = 0;
+    B2M_CHECK_ARG(x1 && wp && y && rb_in && rb_out && rb_cnt && c1 > 0 && c2 >= 0 && cout > 0 && K >= 1 && K <= 128, "bad pointers/sizes");
+    B2M_CHECK_ARG(c2 == 0 || x2 != nullptr, "x2 is NULL");
+    B2M_CHECK_ARG(ldy >= cout && ldx1 >= c1 && (c2 == 0 || ldx2 >= c2), "leading dimension too small");
+    B2M_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale and shift come together");
+    if (n_coarse <= 0 || n_fine <= 0) { *ran = 1; return B2M_OK; }
+    const int cin = c1 + c2;
+    const int TW = conv_tw(cout, K);
+    ConvArgs a;
+    a.x1 = x1; a.ldx1 = ldx1; a.c1 = c1; a.x2 = x2; a.ldx2 = ldx2; a.c2 = c2;
+    a.wp = wp; a.K = K; a.bias = bias;
+    a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
+    a.n_out = n_coarse; a.ntiles = cdiv64(n_coarse, B2M_TILE);
+    a.y = y; a.ldy = ldy; a.cout = cout; a.accumulate = accumulate;
+    a.stats = nullptr; a.chain = 0;
+    a.ep_scale = scale; a.ep_shift = shift; a.ep_res = res; a.ld_res = ld_res; a.ep_relu = relu;
+    a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr;
+    a.nstrips = (cout + 16 * TW - 1) / (16 * TW);
+    a.vec_store = 1; a.nslice = 1; a.ncs = 1; a.wg_combine = 0; a.zeros = nullptr;
+    const int nc = cin / 16;
+    const int64_t n_max = n_coarse > n_fine ? n_coarse : n_fine;
+    const bool ok = c1 % 16 == 0 && c2 % 16 == 0 && nc >= 2 && nc % 2 == 0 && cout % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 &&
+                    ldx1 % 4 == 0 && (c2 == 0 || ldx2 % 4 == 0) && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)x2 % 16) == 0 &&
+                    ((uintptr_t)wp % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) &&
+                    (!scale || (!accumulate && !bias && ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0 &&
+                                (!res || (ld_res % 4 == 0 && ld_res >= cout && ((uintptr_t)res % 16) == 0)))) &&
+                    n_max < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_coarse * ldx1 * 4 < (1ll << 32) &&
+                    n_coarse * ldx2 * 4 < (1ll << 32) &&
+                    a.ntiles * a.nstrips >= env_flag("B2M_CONV_UP_MIN_ITEMS", 1024) && !env_flag("B2M_PIPE_DBG", 0) &&
+                    env_flag("B2M_CONV_UP", 1);
+    if (!ok) return B2M_OK;
+    a.fast32 = 1;
+    a.nwg = a.ntiles * a.nstrips;
+    B2M_CHECK_ARG(a.nwg < (1ll << 31), "too many (tile, strip) items");
+    const int64_t xcd_tiles = env_flag("B2M_XCD", 1) ? (1 << 30) : 0;
+    XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips);
+    a.xcd_per = fo.chunk;
+    if (a.ntiles >= B2M_BALANCE_MIN_TILES && xcd_tiles > 0 && env_flag("B2M_XCD_BALANCE", 1)) {
+        a.xcd_start = rb_cnt + (int64_t)K * a.ntiles;
+        a.tile_order = env_flag("B2M_XCD_ORDER", 1) ? a.xcd_start + 16 + a.ntiles : nullptr;
+        a.wg_per_tile = a.nstrips;
+        fo.grid = (unsigned)(8 * B2M_XCD_CAP(a.ntiles) * a.wg_per_tile);
+    }
+    if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 1, 1, 0, 1><<<fo.grid, 64, 0, st>>>(a);
+    else conv_fwd_flow_kernel<2, 2, 0, 1, 1, 0, 1><<<fo.grid, 64, 0, st>>>(a);
+    B2M_LAUNCH_CHECK();
+    *ran = 1;
+    return B2M_OK;
+}
 // ------------------------------------------------------------------ half activations (inference)
 // Packed HALF weight image of b2m_conv_fwd_h: blocks [k][strip][chunk] of TW pieces, piece t = [lane][E halfs] with E = 8
 // (chunks of CK = 32 input channels, v_mfma_f32_16x16x32_f16) or 4 (CK = 16, v_mfma_f32_16x16x16_f16): lane (i, q) of piece t

@@ -106,9 +106,17 @@ __device__ __forceinline__ void store_half4(const ConvArgs& a, f32x4 v, int64_t 
 // accumulate, no BatchNorm column sums; at most 4 slices (the combine of more is an fp32 atomic into Y).
 // F16 = 2: 16 input channels per step (8-byte loads, v_mfma_f32_16x16x16_f16) for the layers whose 32-channel chunks cannot be
 // dealt to the D steps of a round (32 input channels: one chunk per offset).
-template <int D, int TW, int DBG = 0, int WPB = 1, int HL = 0, int F16 = 0>
-__global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
+// UP = 1 (round 5): TRANSPOSED k2s2 maps in scatter form (b2m_conv_up).  Every fine row has exactly one (parent, offset) pair, so
+// tiled over the fine (output) rows an offset of a tile has ~8 pairs: one half-empty row group per visit, 30 ... 45 TFLOP/s.
+// Here the wave walks the map's DOWN rulebook -- tiled over the COARSE rows: up to 64 pairs per (tile, offset) --
+// with the roles of its two row numbers exchanged: the gathered rows are the tile's own coarse rows (row0 + rb_out), and
+// the result of pair j is stored straight to fine row rb_in[j] of Y (each fine row is written exactly once per launch: no
+// LDS strip, no flush, no write-out; accumulate = one fire-and-forget fp32 atomic per element onto the gradient already
+// there, a single addition per element and therefore deterministic).
+template <int D, int TW, int DBG = 0, int WPB = 1, int HL = 0, int F16 = 0, int UP = 0>
+__global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
     static_assert(!F16 || HL, "the half variant exists with hand-issued loads only");
+    static_assert(!UP || (HL && WPB == 1 && !F16), "the scatter form: fp32, un-split, hand-issued loads");
     constexpr int KS = 4;                     // k-steps per 16-channel chunk == floats per lane per gathered row
     constexpr int ESZ = F16 ? 2 : 4;          // bytes per activation element
     constexpr int CSH = F16 == 1 ? 5 : 4;     // log2(input channels per step): 64 bytes of a row (F16 = 2: 32 bytes, see below)
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     constexpr int LW = 64 * TW * KS;          // floats per packed weight block
     constexpr int PITCH = SW + 4;             // strip row pitch in floats: 16-byte multiples that do not alias banks
     constexpr int STRIP = B2M_TILE * PITCH;   // 13 KiB per wave (TW = 3): twelve waves per CU
-    __shared__ float smem[WPB * STRIP];
+    __shared__ float smem[UP ? 4 : WPB * STRIP];
     const int lane = threadIdx.x & 63;
     const int wave = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
     if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
     // ---- init the strip: 0 | Y (accumulate) | + bias
-    for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
+    for (int e = lane; !UP && e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int64_t grow = row0 + row;
@@ -252,7 +260,8 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
             asm volatile("global_load_ubyte %0, %1, %2" : "+v"(r_out) : "v"((uint32_t)lane), "s"(pout) : "memory");
         };
         auto list_words = [&](int r_in, int r_out, uint32_t (&w)[NG]) {
-            const uint32_t word = r_in < 0 ? ((uint32_t)B2M_TILE << 24) : ((uint32_t)r_in | ((uint32_t)r_out << 24));
+            // (UP: a padded slot gathers the tile's first row and is marked by the fine row 0xFFFFFF: nothing is stored for it)
+            const uint32_t word = r_in < 0 ? (UP ? 0x00FFFFFFu : ((uint32_t)B2M_TILE << 24)) : ((uint32_t)r_in | ((uint32_t)r_out << 24));
 #pragma unroll
             for (int g = 0; g < NG; ++g) w[g] = (uint32_t)__builtin_amdgcn_ds_bpermute((16 * g + i) << 2, (int)word);
         };
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
         };
         // `present` (wave-uniform): the step that will consume this buffer has row group g
         auto gather = [&](int j, int g, const char* src, uint32_t ld4, uint32_t word, bool present) {
-            const uint32_t off = __umul24(word & 0xFFFFFFu, ld4) + q16;
+            const uint32_t off = __umul24(UP ? (uint32_t)row0 + (word >> 24) : (word & 0xFFFFFFu), ld4) + q16;
             if constexpr (HL) {
                 const uint64_t em = present ? ~0ull : 1ull;                 // absent group: one lane fetches, the rest keep stale registers
                 if constexpr (F16 == 2)
@@ -461,7 +470,27 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g < GC) {
-                    if constexpr (!(DBG & 1)) {
+                    if constexpr (UP) {
+                        const uint32_t frow = wC[g] & 0xFFFFFFu;            // the fine row this pair's result belongs to
+                        if (frow != 0xFFFFFFu) {
+#pragma unroll
+                            for (int t = 0; t < TW; ++t) {
+                                const int col = col0 + 16 * t + 4 * q;
+                                if (col + 3 < a.cout) {
+                                    f32x4 v = acc[g][t];
+                                    if (a.bias) v += *(const f32x4*)(a.bias + col);
+                                    float* dst = a.y + (int64_t)frow * a.ldy + col;
+                                    if (a.accumulate) {
+#pragma unroll
+                                        for (int u = 0; u < 4; ++u) atomicAdd(dst + u, v[u]);
+                                    } else {
+                                        if (a.ep_scale) v = conv_epilogue(a, v, (int64_t)frow, col);
+                                        *(f32x4*)dst = v;
+                                    }
+                                }
+                            }
+                        }
+                    } else if constexpr (!(DBG & 1)) {
                         const uint32_t orow = wC[g] >> 24;
                         if (orow < B2M_TILE) {
                             float* rowp = Cs + orow * PITCH + 4 * q;
@@ -518,6 +547,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2) ? 4 : 3) void conv_fw
     B2M_STAMP(fs_walk);
             }
 #endif
+    if constexpr (UP) return;                 // (everything is in Y already)
     // ---- write the strip (rows of the strip are 16-byte aligned: coalesced vector stores)
     if constexpr (WPB > 1) {
         __syncthreads();

@@ -177,6 +177,20 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
     else:
         assert rb.K == K and rb.n_out == n_out
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
+    if rb is not None and rb.scatter is not None and n_out > 0 and x1.shape[0] > 0:
+        # a transposed k2s2 map: scatter form over the DOWN rulebook where the kernel takes the shape (b2m_conv_up); no per-tile
+        # column sums there (tile_stats stays empty: the BatchNorm behind it reads the output)
+        sc = rb.scatter
+        assert sc.K == K and sc.n_out == x1.shape[0]
+        ran = ctypes.c_int32(0)
+        m_up = {'ran': ran}
+        if logical_cin is not None:
+            m_up['cin'] = logical_cin
+        _call('b2m_conv_up', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2, x1.shape[0],
+              wp.data_ptr(), K, _ptr(bias), sc.rb_in.data_ptr(), sc.rb_out.data_ptr(), sc.rb_cnt.data_ptr(), out.data_ptr(),
+              out.stride(0), cout, n_out, 1 if accumulate else 0, None, None, None, 0, 0, ctypes.byref(ran), meta=m_up)
+        if ran.value:
+            return out
     if tile_stats is not None and rb is not None and n_out > 0:
         ntiles = (n_out + 63) // 64
         ts = torch.empty((ntiles, 2, cout), dtype=torch.float64, device=x1.device)
@@ -308,6 +322,15 @@ def conv_affine(x1, x2, weight, rb: Rulebook | None, n_out: int, scale, shift, r
         residual = _f32c(residual)
     if n_out == 0:
         return out
+    if rb is not None and rb.scatter is not None and x1.shape[0] > 0:          # transposed k2s2 map: scatter form (b2m_conv_up)
+        sc = rb.scatter
+        ran = ctypes.c_int32(0)
+        _call('b2m_conv_up', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2, x1.shape[0],
+              wp.data_ptr(), K, None, sc.rb_in.data_ptr(), sc.rb_out.data_ptr(), sc.rb_cnt.data_ptr(), out.data_ptr(),
+              out.stride(0), cout, n_out, 0, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
+              residual.stride(0) if residual is not None else 0, 1 if relu else 0, ctypes.byref(ran), meta={'ran': ran})
+        if ran.value:
+            return out
     fused = ctypes.c_int32(0)
     _call('b2m_conv_fwd_affine', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2,
           x1.shape[0], wp.data_ptr(), K, rbi, rbo, rbc, n_out, out.data_ptr(), out.stride(0), cout, scale.data_ptr(),

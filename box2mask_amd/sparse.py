@@ -52,6 +52,7 @@ class Rulebook:
                       self.rb_cnt.data_ptr(), None)
         self.nbr = nbr if keep_table else None
         self._pairs = None
+        self.scatter = None        # an UP rulebook: the DOWN rulebook of the same map (CoordinateManager._stride_tables)
 
     @property
     def pairs(self) -> int:
@@ -201,6 +202,8 @@ class CoordinateManager:
                   child.data_ptr(), child.shape[1], up.data_ptr(), up.shape[1])
         self._rb[('down', level)] = Rulebook(child, 8, nc, nf, self.keep_tables)
         self._rb[('up', level)] = Rulebook(up, 8, nf, nc, self.keep_tables)
+        # the transposed map in scatter form walks the DOWN rulebook (functional.conv_raw -> b2m_conv_up)
+        self._rb[('up', level)].scatter = self._rb[('down', level)]
 
     def tensors(self):
         """Every device tensor this manager (and its kernel maps) owns -- for `record_stream` when the manager was built

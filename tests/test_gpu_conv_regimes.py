@@ -352,3 +352,64 @@ def test_stem_kernel_and_its_tile_stats(maps, monkeypatch, stem):
         assert torch.equal(y, y_old), 'the two stem kernels differ'
     else:
         assert ts is None
+
+
+# ------------------------------------------------------------------ 4. transposed k2s2 maps in scatter form (b2m_conv_up)
+def _updown_cases():
+    from test_gpu_ops import CONV_CASES
+    return [c for c in CONV_CASES if c[0] in ('up', 'down')]
+
+
+@pytest.mark.parametrize('kind,level,cins,cout,bias', _updown_cases())
+def test_transposed_maps_in_scatter_form_vs_oracle(maps, monkeypatch, kind, level, cins, cout, bias):
+    """Forward of the transposed convolution and data gradient of the strided one walk the DOWN rulebook with the roles of its
+    row numbers exchanged (conv_fwd_flow_kernel<.., UP>); by default only from 1024 (tile, strip) items on -- forced here on
+    the small maps.  (/root/reference/models/detection_net.py:52-129.)"""
+    from test_gpu_ops import _conv_case
+    monkeypatch.setenv('B2M_CONV_UP_MIN_ITEMS', '1')
+    _conv_case(maps, kind, level, cins, cout, bias)
+
+
+def test_scatter_form_equals_the_fine_row_tiling_bit_for_bit(monkeypatch):
+    """b2m_conv_up against b2m_conv_fwd over the UP rulebook on the same operands: every output element is ONE offset's sum over
+    the input channels, accumulated in the same chunk order by both -- equal bits, with and without a second source, bias,
+    accumulate (one atomic add per element onto the tensor already there) and the inference epilogue (scale, shift, residual,
+    ReLU); the hook proves which kernel ran."""
+    from box2mask_amd import _lib, functional as F_, synth
+    from box2mask_amd.sparse import CoordinateManager
+    b = synth.make_batch(2, seed0=11, target_voxels=20000, pts_per_m2=8000.0)
+    m = CoordinateManager(b['vox_coords'].cuda(), reorder=True)
+    rb = m.rulebook_up(0)
+    nf, nc = rb.n_out, rb.n_in
+    assert rb.scatter is m.rulebook_down(0) and nc == rb.scatter.n_out
+    torch.manual_seed(3)
+    ran = []
+
+    def hook(name, args, meta):
+        if name == 'b2m_conv_up':
+            return lambda: ran.append(meta['ran'].value)
+        return None
+    for c1, c2, co in ((96, 0, 96), (64, 32, 128), (32, 0, 32)):
+        x1 = torch.randn(nc, c1, device='cuda'); x2 = torch.randn(nc, c2, device='cuda') if c2 else None
+        w = torch.randn(8, c1 + c2, co, device='cuda') * 0.1
+        bias = torch.randn(1, co, device='cuda'); y0 = torch.randn(nf, co, device='cuda')
+        scale = torch.rand(co, device='cuda') + 0.5; shift = torch.randn(co, device='cuda'); res = torch.randn(nf, co, device='cuda')
+        wp = F_.weight_pack(w)
+        outs = {}
+        for form in ('scatter', 'tiled'):
+            monkeypatch.setenv('B2M_CONV_UP', '1' if form == 'scatter' else '0')
+            monkeypatch.setenv('B2M_CONV_UP_MIN_ITEMS', '1')
+            _lib.reload_env()
+            del ran[:]
+            _lib.set_hook(hook)
+            try:
+                outs[form] = (F_.conv_raw(x1, x2, wp, 8, None, rb, nf, co),
+                              F_.conv_raw(x1, x2, wp, 8, bias, rb, nf, co, out=y0.clone(), accumulate=True),
+                              F_.conv_affine(x1, x2, w, rb, nf, scale, shift, res, True),
+                              F_.conv_affine(x1, x2, w, rb, nf, scale, shift, None, False))
+            finally:
+                _lib.set_hook(None)
+            torch.cuda.synchronize()
+            assert ran == ([1, 1, 1, 1] if form == 'scatter' else [0, 0, 0, 0]), (form, ran)
+        for a, b_ in zip(outs['scatter'], outs['tiled']):
+            assert torch.equal(a, b_), float((a - b_).abs().max())
