@@ -265,6 +265,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    from box2mask_amd import functional as F_
+    cstat = F_.collective_stats
+    cstat.update(syncbn=0, grad_buckets=0, bytes=0)
     t_start = time.perf_counter()
     for _ in range(args.steps):
         losses = step()
@@ -274,6 +277,22 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     timer.enabled = False
+    # collectives of the timed steps (N > 1; zeros for a single process), and two more steps with an event pair around every
+    # SyncBN all-reduce: what the latency-bound exchanges cost on this fabric (they are blocking on the compute stream)
+    collectives = {'syncbn_all_reduces_per_step': cstat['syncbn'] / args.steps, 'gradient_buckets_per_step': cstat['grad_buckets'] / args.steps,
+                   'bytes_per_step': cstat['bytes'] // args.steps}
+    if world > 1:
+        cstat['timing'] = True
+        cstat['events'] = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        cstat['timing'] = False
+        ev = cstat['events']
+        ms = sorted(s_.elapsed_time(e_) for s_, e_ in ev)
+        collectives.update(syncbn_ms_per_step=round(sum(ms) / 2, 3), syncbn_median_us=round(ms[len(ms) // 2] * 1e3, 1) if ms else None,
+                           syncbn_timed_per_step=len(ms) // 2)
+        cstat['events'] = []
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -500,7 +519,8 @@ def main():
                    'scene_gen_s': round(gen_s, 1), 'setup_steps': SETUP_STEPS,
                    'prefetch': ('next batch: coordinate + kernel maps on a second stream during the step'
                                 if PREFETCH else 'off'),
-                   'steps_executed': SETUP_STEPS + args.warmup + 4 * args.steps + 3},
+                   'collectives': collectives,
+                   'steps_executed': SETUP_STEPS + args.warmup + 4 * args.steps + 3 + (2 if world > 1 else 0)},
         'roofline': roofline, 'roofline_timed_region': roofline_timed, 'roofline_wgrad': roofline_wgrad,
         # an HBM-bound kernel of the path, same live HIP-event method: BatchNorm apply (+residual, +ReLU) streams
         # 2-3 tensors per launch; small deep-level layers (launch-latency bound) are part of the average

@@ -1163,7 +1163,7 @@ extern "C" int b2m_conv_up(const float* x1, int64_t ldx1, int32_t c1, const floa
                                 (!res || (ld_res % 4 == 0 && ld_res >= cout && ((uintptr_t)res % 16) == 0)))) &&
                     n_max < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_coarse * ldx1 * 4 < (1ll << 32) &&
                     n_coarse * ldx2 * 4 < (1ll << 32) &&
-                    a.ntiles * a.nstrips >= env_flag("B2M_CONV_UP_MIN_ITEMS", 1024) && !env_flag("B2M_PIPE_DBG", 0) &&
+                    a.ntiles * a.nstrips >= env_flag("B2M_CONV_UP_MIN_ITEMS", 450) && !env_flag("B2M_PIPE_DBG", 0) &&
                     env_flag("B2M_CONV_UP", 1);
     if (!ok) return B2M_OK;
     a.fast32 = 1;

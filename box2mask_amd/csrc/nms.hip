@@ -146,12 +146,13 @@ __global__ void detection_loss_final_kernel(const double* __restrict__ o, double
         total += (double)w_sc * bce;
         res[3] = (float)bce; res[4] = (float)(o[3] / F);
         const double ca = o[5] - o[3] * o[3] / F, cb = o[6] - o[4] * o[4] / F, cab = o[7] - o[3] * o[4] / F;
-        // Pearson r of (IoU, score logit).  The centred sums can come out a rounding error below zero for (nearly) constant
-        // inputs: clamp before the root; a zero variance has no correlation -- NaN, as scipy.stats.pearsonr gives for
-        // constant input (/root/reference/models/model.py:88; a logging value only)
+        // Pearson r of (IoU, score logit), a logging value (/root/reference/models/model.py:88).  The centred sums can come out a
+        // rounding error below zero for (nearly) constant inputs: clamped before the root (a negative product gave NaN -> +-inf
+        // through the floor below).  Zero variance -- all IoUs 0 at a fresh initialisation -- reads 0 here, as model._pearsonr
+        // does; scipy.stats.pearsonr returns NaN with a warning for such input
         const double va = ca > 0.0 ? ca : 0.0, vb = cb > 0.0 ? cb : 0.0;
         const double den = sqrt(va * vb);
-        res[5] = den > 0.0 ? (float)(cab / den) : __builtin_nanf("");
+        res[5] = den > 1e-300 ? (float)(cab / den) : 0.f;
     }
     if (has_sem) {
         const double ce = o[8] / *n_valid;

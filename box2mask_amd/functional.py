@@ -566,6 +566,27 @@ def sparse_conv(x1, x2, weight, bias, rb_f, rb_b, mirror, n_out, collect_stats=F
 # ----------------------------------------------------------------------------- batch norm
 _RED_BLOCKS = 4096
 
+# Collectives of the data-parallel path, counted (and, when bench.py asks, timed with HIP events on the current stream): one
+# blocking, latency-bound all-reduce per SyncBN layer and direction, a few large asynchronous ones for the gradient buckets
+# (parallel.GradAllReduce).  `collective_stats['timing']` = True makes every SyncBN all-reduce carry an event pair.
+collective_stats = {'syncbn': 0, 'grad_buckets': 0, 'bytes': 0, 'timing': False, 'events': []}
+
+
+def _sync_all_reduce(t, group):
+    """A SyncBN statistics exchange: SUM over the ranks, in place, blocking on the current stream."""
+    st = collective_stats
+    st['syncbn'] += 1
+    st['bytes'] += t.numel() * t.element_size()
+    if st['timing'] and t.is_cuda:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        e.record()
+        st['events'].append((s, e))
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 
 def _sync_group():
     return dist.group.WORLD if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
@@ -579,7 +600,7 @@ def merge_bn_sums(local_sums: torch.Tensor, local_count: float, group=None):
     count is consumed there (b2m_bn_finalize / b2m_bn_bwd_apply read it through a pointer), no host sync."""
     packed = torch.cat([local_sums, local_sums.new_tensor([float(local_count)])])
     if group is not None:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        _sync_all_reduce(packed, group)
     return packed[:-1], packed[-1:]
 
 
@@ -612,7 +633,7 @@ class _BatchNorm(torch.autograd.Function):
             y = torch.empty_like(x)
             stats = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
             _call('b2m_bn_small_fwd_stats', x.data_ptr(), x.stride(0), n, c, stats.data_ptr())
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+            _sync_all_reduce(stats, group)
             count_dev = stats[2 * c:]
             _call('b2m_bn_small_fwd_apply', stats.data_ptr(), x.data_ptr(), x.stride(0), n, c, _ptr(gamma), _ptr(beta), eps,
                   momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
@@ -649,7 +670,7 @@ class _BatchNorm(torch.autograd.Function):
                 else:
                     _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), stats.data_ptr())
                 stats[2 * c:].fill_(float(n))
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+                _sync_all_reduce(stats, group)
                 count_dev = stats[2 * c:]
                 _call('b2m_bn_finalize', stats.data_ptr(), 0.0, count_dev.data_ptr(), c, _ptr(gamma), _ptr(beta), eps,
                       momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
@@ -713,7 +734,7 @@ class _BatchNorm(torch.autograd.Function):
             args = (dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(), x.stride(0), n, c,
                     mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), relu, _ptr(mscale), _ptr(mshift))
             _call('b2m_bn_small_bwd_phase', 1, *args, dbeta.data_ptr(), dgamma.data_ptr(), None, 0, None, 0, xchg.data_ptr(), None)
-            dist.all_reduce(xchg, op=dist.ReduceOp.SUM, group=group)
+            _sync_all_reduce(xchg, group)
             _call('b2m_bn_small_bwd_phase', 2, *args, None, None, dx.data_ptr(), dx.stride(0), _ptr(dres),
                   dres.stride(0) if dres is not None else 0, xchg.data_ptr(), ctx.count_dev.data_ptr())
             return (_own(dx, ctx.src_x), dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
@@ -734,7 +755,7 @@ class _BatchNorm(torch.autograd.Function):
         group = _sync_group() if ctx.sync else None
         if group is not None:
             gsums = sums.clone()
-            dist.all_reduce(gsums, op=dist.ReduceOp.SUM, group=group)
+            _sync_all_reduce(gsums, group)
         _call('b2m_bn_bwd_apply', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0,
               x.data_ptr(), x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), gsums.data_ptr(),
               count, _ptr(ctx.count_dev), relu, _ptr(mscale), _ptr(mshift), dx.data_ptr(), dx.stride(0), _ptr(dres),
@@ -797,7 +818,7 @@ class _BatchNormPair(torch.autograd.Function):
                     else:
                         _call('b2m_bn_stats', x.data_ptr(), x.stride(0), n, c, partial.data_ptr(), dst)
                 stats[4 * c:].fill_(float(n))
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+                _sync_all_reduce(stats, group)
                 count_dev = stats[4 * c:]
                 for j, (x, g, b, rm, rv, mom, eps, mean, inv, sc, sh, ts) in enumerate(sides):
                     _call('b2m_bn_finalize', stats.data_ptr() + 8 * 2 * c * j, 0.0, count_dev.data_ptr(), c, _ptr(g), _ptr(b),
@@ -859,7 +880,7 @@ class _BatchNormPair(torch.autograd.Function):
             # dx needs the sums over ALL ranks; the parameter gradients are written from this rank's own sums (they are
             # averaged over the ranks with every other gradient afterwards)
             gsums = sums.clone()
-            dist.all_reduce(gsums, op=dist.ReduceOp.SUM, group=group)
+            _sync_all_reduce(gsums, group)
         _call('b2m_bn_bwd_apply2', dy.data_ptr(), dy.stride(0), y.data_ptr(), y.stride(0), xa.data_ptr(), xa.stride(0),
               xb.data_ptr(), xb.stride(0), n, c, mean_a.data_ptr(), inv_a.data_ptr(), _ptr(ga), mean_b.data_ptr(),
               inv_b.data_ptr(), _ptr(gb), gsums.data_ptr(), ctx.count, _ptr(ctx.count_dev), relu, dxa.data_ptr(),

@@ -110,6 +110,9 @@ class GradAllReduce:
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
             in_place = False
         self._flat[bi] = (flat, in_place)
+        from . import functional as F_
+        F_.collective_stats['grad_buckets'] += 1
+        F_.collective_stats['bytes'] += flat.numel() * flat.element_size()
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _finalize(self):

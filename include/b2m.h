@@ -241,10 +241,10 @@ int b2m_conv_fwd_h(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int
  * rb_out = coarse row inside its tile), up to 64 pairs per (tile, offset) instead of the ~8 the fine-row tiling gives.
  * Replaces [ME] MinkowskiConvolutionTranspose forward (detection_net.py:96-129) and the data gradient of the strided
  * MinkowskiConvolution (detection_net.py:52-91) where b2m_conv_fwd over the UP rulebook served before.  Every fine row has
- * exactly one pair: plain 16-byte stores, or (accumulate != 0) one fp32 atomic add per element onto Y.  scale / shift (+ res)
+ * exactly one pair: plain 16-byte stores, or (accumulate != 0) a 16-byte read-modify-write of Y (one writer per row).  scale / shift (+ res)
  * (+ relu): the inference epilogue of b2m_conv_fwd_affine (accumulate == 0, bias == NULL).  wp: the packed image b2m_conv_fwd
  * takes.  *ran = 1 if the kernel ran, 0 if the shape is not one it takes (the caller then uses b2m_conv_fwd): whole 16-channel
- * input chunks in even number, cout % 4 == 0, 16-byte aligned operands, < 2^24 rows, at least B2M_CONV_UP_MIN_ITEMS (1024)
+ * input chunks in even number, cout % 4 == 0, 16-byte aligned operands, < 2^24 rows, at least B2M_CONV_UP_MIN_ITEMS (450)
  * (tile, strip) items. */
 int b2m_conv_up(const float* x1, int64_t ldx1, int32_t c1, const float* x2, int64_t ldx2, int32_t c2, int64_t n_coarse,
                 const float* wp, int32_t K, const float* bias, const int32_t* rb_in, const uint8_t* rb_out,

@@ -363,7 +363,7 @@ def _updown_cases():
 @pytest.mark.parametrize('kind,level,cins,cout,bias', _updown_cases())
 def test_transposed_maps_in_scatter_form_vs_oracle(maps, monkeypatch, kind, level, cins, cout, bias):
     """Forward of the transposed convolution and data gradient of the strided one walk the DOWN rulebook with the roles of its
-    row numbers exchanged (conv_fwd_flow_kernel<.., UP>); by default only from 1024 (tile, strip) items on -- forced here on
+    row numbers exchanged (conv_fwd_flow_kernel<.., UP>); by default only from 450 (tile, strip) items on -- forced here on
     the small maps.  (/root/reference/models/detection_net.py:52-129.)"""
     from test_gpu_ops import _conv_case
     monkeypatch.setenv('B2M_CONV_UP_MIN_ITEMS', '1')
@@ -373,7 +373,7 @@ def test_transposed_maps_in_scatter_form_vs_oracle(maps, monkeypatch, kind, leve
 def test_scatter_form_equals_the_fine_row_tiling_bit_for_bit(monkeypatch):
     """b2m_conv_up against b2m_conv_fwd over the UP rulebook on the same operands: every output element is ONE offset's sum over
     the input channels, accumulated in the same chunk order by both -- equal bits, with and without a second source, bias,
-    accumulate (one atomic add per element onto the tensor already there) and the inference epilogue (scale, shift, residual,
+    accumulate (a read-modify-write of the tensor already there) and the inference epilogue (scale, shift, residual,
     ReLU); the hook proves which kernel ran."""
     from box2mask_amd import _lib, functional as F_, synth
     from box2mask_amd.sparse import CoordinateManager
