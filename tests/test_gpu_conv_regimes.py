@@ -69,14 +69,31 @@ def maps():
     return m, h
 
 
-def _regime_cases():
+# CONV_CASES of test_gpu_ops a regime is run on -- the cases whose launches the switch can change (round 5: every regime
+# used to run on the same nine cases, 144 tests of which a third repeated the default path under a switch their kernels do
+# not read):   0 k3 32->32 | 1 k3 96->96 | 2 k3 (96|32)->96 | 3 k3 L1 64->128 | 4 k3 L1 (256|128)->256 | 5 k5 6->32 |
+#              6 down 32->32 | 8 up 96->96 | 9 up L1 128->96
+_ALL = [0, 1, 2, 3, 4, 5, 6, 8, 9]
+_SPLIT = [1, 3, 4, 6, 9]            # switches of the split-K path: the level-1 maps (always split at this size) + one of each level-0 kind
+_WGRAD = [0, 1, 2, 3, 5, 6, 8]      # weight-gradient switches: every block shape (2x2, 3x3, 4x4, two sources, the stem, K = 8)
+_ORDER = [1, 2, 5, 8]               # dispatch-order switches: one case per rulebook kind
+REGIME_CASES = {
+    'unsplit': _ALL, 'unsplit_three_steps_in_flight': [0, 1, 2, 4, 8], 'unsplit_compiler_tracked_loads': _ALL,
+    'split_compiler_tracked_loads': _SPLIT, 'unsplit_32_column_strips': [1, 2, 4, 8, 9], 'atomic_combine': _SPLIT,
+    'no_chunk_slices': _SPLIT, 'many_slices': _SPLIT, 'wgrad_plain': _WGRAD, 'wgrad_compiler_tracked_loads': _WGRAD,
+    'wgrad_hand_issued_loads_square_blocks_only': _WGRAD, 'wgrad_64_tile_chunks': _WGRAD, 'wgrad_one_offset_per_workgroup': [0, 5, 6],
+    'no_xcd_order': _ORDER, 'xcd_equal_tile_counts': _ORDER, 'unsplit_64bit': _ALL,
+}
+
+
+def _regime_matrix():
     from test_gpu_ops import CONV_CASES
-    pick = [0, 1, 2, 3, 4, 5, 6, 8, 9]          # every rulebook kind: k3 (1 and 2 sources), k5, down, up
-    return [CONV_CASES[i] for i in pick]
+    assert set(REGIME_CASES) == set(REGIMES)
+    return [pytest.param(r, *CONV_CASES[i], id='%s-%s-L%d-%s-%d' % ((r,) + CONV_CASES[i][:2] + ('+'.join(map(str, CONV_CASES[i][2])), CONV_CASES[i][3])))
+            for r in sorted(REGIMES) for i in REGIME_CASES[r]]
 
 
-@pytest.mark.parametrize('regime', sorted(REGIMES))
-@pytest.mark.parametrize('kind,level,cins,cout,bias', _regime_cases())
+@pytest.mark.parametrize('regime,kind,level,cins,cout,bias', _regime_matrix())
 def test_conv_forced_regime(maps, monkeypatch, regime, kind, level, cins, cout, bias):
     """The C library reads its switches at every call, so each regime is forced on the small maps."""
     from test_gpu_ops import _conv_case

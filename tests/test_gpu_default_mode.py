@@ -66,7 +66,7 @@ def test_default_mode_gradients_match_oracle_affine_batchnorm(monkeypatch):
     model = Model(cfg, *synth.scannet_tables())
     net = model.detection_model
     # scenes large enough that levels 0-1 run un-split, levels 2.. the split maps, and the weight gradients several chunks
-    batches = [synth.make_batch(5, seed0=300 + 10 * r, target_voxels=(4000, 6000, 2500)[r], pts_per_m2=8000.0) for r in range(3)]
+    batches = [synth.make_batch(5, seed0=300 + 10 * r, target_voxels=(3000, 4500, 2000)[r], pts_per_m2=8000.0) for r in range(3)]
     # running statistics := statistics of batch 0 (momentum 1), affine parameters away from (1, 0): a normalising,
     # non-trivial affine BatchNorm
     with torch.no_grad():
@@ -129,7 +129,7 @@ def test_default_mode_train_batchnorm_many_scenes(monkeypatch):
     valid, _, _, is_fg = synth.scannet_tables()
     torch.manual_seed(2)
     net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6]).cuda().train()
-    batch = synth.make_batch(32, seed0=500, target_voxels=1500, pts_per_m2=6000.0)
+    batch = synth.make_batch(32, seed0=500, target_voxels=1100, pts_per_m2=6000.0)
     S_ = batch['input_location'].shape[0]
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     torch.manual_seed(1)
@@ -176,7 +176,7 @@ def test_default_and_deterministic_mode_on_a_block_chain(monkeypatch):
     from box2mask_amd import functional as F_
     from oracle import sparse_ref as S
     from torch import nn
-    b = synth.make_batch(3, seed0=70, target_voxels=30000, pts_per_m2=8000.0)
+    b = synth.make_batch(3, seed0=70, target_voxels=20000, pts_per_m2=8000.0)
 
     class Chain(nn.Module):
         def __init__(self):

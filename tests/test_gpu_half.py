@@ -42,8 +42,20 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('res,relu,affine', [(False, True, True), (True, True, True), (False, False, True), (False, False, False)])
-@pytest.mark.parametrize('kind,level,cins,cout', CASES)
+# every layer shape with the trunk's usual epilogue (BatchNorm + ReLU); the other epilogues -- residual, no ReLU, no affine map: code
+# after the walk, the same for every shape -- on one case per kernel form (48- / 32-column strips, split map, k2s2 both ways, 1x1,
+# 16-channel chunks).  Round 5: was 19 x 4.
+_EPILOGUES = [(True, True, True), (False, False, True), (False, False, False)]
+_EPILOGUE_CASES = [0, 1, 4, 6, 10, 12, 14, 18]
+
+
+def _half_matrix():
+    out = [pytest.param(*c, False, True, True) for c in CASES]
+    out += [pytest.param(*CASES[i], *e) for i in _EPILOGUE_CASES for e in _EPILOGUES]
+    return out
+
+
+@pytest.mark.parametrize('kind,level,cins,cout,res,relu,affine', _half_matrix())
 def test_half_layer_equals_fp32_kernel_on_half_rounded_operands(maps, monkeypatch, kind, level, cins, cout, res, relu, affine):
     from box2mask_amd import functional as F_
     m = maps
