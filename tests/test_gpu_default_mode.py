@@ -66,7 +66,7 @@ def test_default_mode_gradients_match_oracle_affine_batchnorm(monkeypatch):
     model = Model(cfg, *synth.scannet_tables())
     net = model.detection_model
     # scenes large enough that levels 0-1 run un-split, levels 2.. the split maps, and the weight gradients several chunks
-    batches = [synth.make_batch(5, seed0=300 + 10 * r, target_voxels=(3000, 4500, 2000)[r], pts_per_m2=8000.0) for r in range(3)]
+    batches = [synth.make_batch(5, seed0=300 + 10 * r, target_voxels=(4000, 6000, 2500)[r], pts_per_m2=8000.0) for r in range(3)]
     # running statistics := statistics of batch 0 (momentum 1), affine parameters away from (1, 0): a normalising,
     # non-trivial affine BatchNorm
     with torch.no_grad():

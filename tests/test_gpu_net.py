@@ -244,7 +244,8 @@ def test_training_trajectory_matches_oracle(monkeypatch):
     rows, so the batch statistics are well conditioned and the trajectories stay together (with 8 scenes -- 8 rows at level
     7 -- rounding noise and ReLU sign flips were amplified into the gradient direction: the fp32 oracle drifted 1.4 % from
     the fp64 one in three steps and the device 1 ... 4 % depending on which kernel summed the first layer's statistics).
-    Same first loss, every later loss within 1.5 % of the fp64 oracle, and it trains."""
+    Same first loss, every later loss within 1.5 % of the fp64 oracle (or 1.5 x the fp32 oracle's own distance from it), and
+    it trains."""
     from box2mask_amd.detection_net import SelectionNet
     from box2mask_amd import nn as ME
     from oracle import unet_ref, sparse_ref
@@ -299,8 +300,10 @@ def test_training_trajectory_matches_oracle(monkeypatch):
     print('losses device', dev, 'oracle32', o32, 'oracle64', o64)
     assert abs(dev[0] - o64[0]) <= 1e-5 * abs(o64[0])
     assert all(x > y for x, y in zip(dev, dev[1:])) and o64[-1] < o64[0]       # it trains, every step
-    for a, c in zip(dev, o64):
-        assert abs(a - c) <= 0.015 * abs(c), (dev, o32, o64)
+    # the yardstick is the fp32 CPU oracle's OWN distance from the fp64 one at that step (the same arithmetic in another
+    # summation order; round 5: 1.8 % at step 3 of this batch, the device 1.5 %): within 1.5 % or 1.5 x that distance
+    for a, b32, c in zip(dev, o32, o64):
+        assert abs(a - c) <= max(0.015 * abs(c), 1.5 * abs(b32 - c)), (dev, o32, o64)
 
 
 @pytest.mark.gpu
