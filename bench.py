@@ -277,21 +277,20 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     timer.enabled = False
-    # collectives of the timed steps (N > 1; zeros for a single process), and two more steps with an event pair around every
+    # collectives of the timed steps (N > 1; zeros for a single process), and one more step with an event pair around every
     # SyncBN all-reduce: what the latency-bound exchanges cost on this fabric (they are blocking on the compute stream)
     collectives = {'syncbn_all_reduces_per_step': cstat['syncbn'] / args.steps, 'gradient_buckets_per_step': cstat['grad_buckets'] / args.steps,
                    'bytes_per_step': cstat['bytes'] // args.steps}
     if world > 1:
         cstat['timing'] = True
         cstat['events'] = []
-        for _ in range(2):
-            step()
+        step()
         torch.cuda.synchronize()
         cstat['timing'] = False
         ev = cstat['events']
         ms = sorted(s_.elapsed_time(e_) for s_, e_ in ev)
-        collectives.update(syncbn_ms_per_step=round(sum(ms) / 2, 3), syncbn_median_us=round(ms[len(ms) // 2] * 1e3, 1) if ms else None,
-                           syncbn_timed_per_step=len(ms) // 2)
+        collectives.update(syncbn_ms_per_step=round(sum(ms), 3), syncbn_median_us=round(ms[len(ms) // 2] * 1e3, 1) if ms else None,
+                           syncbn_timed=len(ms))
         cstat['events'] = []
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -520,7 +519,7 @@ def main():
                    'prefetch': ('next batch: coordinate + kernel maps on a second stream during the step'
                                 if PREFETCH else 'off'),
                    'collectives': collectives,
-                   'steps_executed': SETUP_STEPS + args.warmup + 4 * args.steps + 3 + (2 if world > 1 else 0)},
+                   'steps_executed': SETUP_STEPS + args.warmup + 4 * args.steps + 3 + (1 if world > 1 else 0)},
         'roofline': roofline, 'roofline_timed_region': roofline_timed, 'roofline_wgrad': roofline_wgrad,
         # an HBM-bound kernel of the path, same live HIP-event method: BatchNorm apply (+residual, +ReLU) streams
         # 2-3 tensors per launch; small deep-level layers (launch-latency bound) are part of the average

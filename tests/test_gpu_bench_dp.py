@@ -26,4 +26,8 @@ def test_bench_two_ranks_rehearsal():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
     assert d['value'] > 0 and d['scaling'] == 'weak' and 'votes_to_masks' not in d
+    # the collectives of a step are counted (and the SyncBN exchanges timed): what an 8-GPU lease will show first
+    c = d['config']['collectives']
+    assert c['syncbn_all_reduces_per_step'] >= 100 and c['gradient_buckets_per_step'] >= 1 and c['syncbn_ms_per_step'] > 0
+    assert c['syncbn_timed'] == c['syncbn_all_reduces_per_step']
     assert abs(d['value'] - 4 * d['steps'] / (d['ms_per_step'] * d['steps'] / 1e3)) < 0.02 * d['value']
