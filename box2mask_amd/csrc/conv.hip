@@ -987,14 +987,13 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
         B2M_LAUNCH_CHECK();
         return B2M_OK;
     }
-    // Real rulebook, whole 16-channel chunks, 32-bit addressable: the flat-pipeline kernel (conv_fwd_flow.h), D steps
-    // deep (B2M_CONV_PIPE = depth, 0 = off) -- un-split maps with one wave per workgroup, split maps with the four
+    // Real rulebook, whole 16-channel chunks, 32-bit addressable: the flat-pipeline kernel (conv_fwd_flow.h), two steps
+    // in flight (B2M_CONV_PIPE=0: off) -- un-split maps with one wave per workgroup, split maps with the four
     // waves of a workgroup as four slices that combine in LDS.
     {
         const int nc = cin / 16;
-        int depth = env_flag("B2M_CONV_PIPE", 2);
-        if (depth > 3) depth = 3;
-        if (depth == 3 && (nc / ncs) % 3 != 0) depth = 2;
+        // (round 5: the three-steps-in-flight form of the fp32 kernel -- B2M_CONV_PIPE=3, measured +-0.3 % in rounds 2 and 4 -- is gone)
+        const int depth = env_flag("B2M_CONV_PIPE", 2) ? 2 : 0;
         const bool split_ok = nslice == 1 || (a.wg_combine && env_flag("B2M_CONV_FLOW_SPLIT", 1));
         if (depth >= 2 && !ident && fast && KC == 16 && split_ok && a.fast32 && nc % ncs == 0 && (nc / ncs) % depth == 0 &&
             nc / ncs >= depth) {
@@ -1038,18 +1037,9 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 return B2M_OK;
             }
             if (wpb == 4) {
-                if (depth == 2) {
-                    if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4><<<fo.grid, 256, 0, st>>>(a);
-                    else conv_fwd_flow_kernel<2, 2, 0, 4><<<fo.grid, 256, 0, st>>>(a);
-                } else {
-                    if (TW == 3) conv_fwd_flow_kernel<3, 3, 0, 4><<<fo.grid, 256, 0, st>>>(a);
-                    else conv_fwd_flow_kernel<3, 2, 0, 4><<<fo.grid, 256, 0, st>>>(a);
-                }
-            } else if (dbg && TW == 3 && depth == 2) {
-                // (diagnostic: B2M_PIPE_LDS extra bytes of dynamic LDS per workgroup cap the waves resident per CU)
-                const size_t xl = (size_t)env_flag("B2M_PIPE_LDS", 0);
-                if (dbg == 16) { conv_fwd_flow_kernel<2, 3><<<fo.grid, 64, xl, st>>>(a); B2M_LAUNCH_CHECK(); return B2M_OK; }
-                if (dbg == 22) { conv_fwd_flow_kernel<2, 3, 6><<<fo.grid, 64, xl, st>>>(a); B2M_LAUNCH_CHECK(); return B2M_OK; }
+                if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4><<<fo.grid, 256, 0, st>>>(a);
+                else conv_fwd_flow_kernel<2, 2, 0, 4><<<fo.grid, 256, 0, st>>>(a);
+            } else if (dbg && TW == 3) {          // diagnostic builds of tools/pipe_breakdown.py (wrong results)
                 switch (dbg) {
                     case 1: conv_fwd_flow_kernel<2, 3, 1><<<fo.grid, 64, 0, st>>>(a); break;
                     case 2: conv_fwd_flow_kernel<2, 3, 2><<<fo.grid, 64, 0, st>>>(a); break;
@@ -1057,12 +1047,9 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                     case 8: conv_fwd_flow_kernel<2, 3, 8><<<fo.grid, 64, 0, st>>>(a); break;
                     default: conv_fwd_flow_kernel<2, 3, 6><<<fo.grid, 64, 0, st>>>(a); break;
                 }
-            } else if (depth == 2) {
+            } else {
                 if (TW == 3) conv_fwd_flow_kernel<2, 3><<<fo.grid, 64, 0, st>>>(a);
                 else conv_fwd_flow_kernel<2, 2><<<fo.grid, 64, 0, st>>>(a);
-            } else {
-                if (TW == 3) conv_fwd_flow_kernel<3, 3><<<fo.grid, 64, 0, st>>>(a);
-                else conv_fwd_flow_kernel<3, 2><<<fo.grid, 64, 0, st>>>(a);
             }
             B2M_LAUNCH_CHECK();
             return B2M_OK;

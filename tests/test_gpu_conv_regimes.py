@@ -39,7 +39,6 @@ def _close(a, b, what, tol=TOL):
 # ------------------------------------------------------------------ 1. forced dispatch regimes
 REGIMES = {
     'unsplit': {'B2M_CONV_TARGET': '0'},
-    'unsplit_three_steps_in_flight': {'B2M_CONV_TARGET': '0', 'B2M_CONV_PIPE': '3'},
     'unsplit_compiler_tracked_loads': {'B2M_CONV_TARGET': '0', 'B2M_CONV_HANDLOADS': '0'},
     'split_compiler_tracked_loads': {'B2M_CONV_HANDLOADS': '0'},
     'unsplit_32_column_strips': {'B2M_CONV_TARGET': '0', 'B2M_CONV_TW3': '0'},
@@ -78,7 +77,7 @@ _SPLIT = [1, 3, 4, 6, 9]            # switches of the split-K path: the level-1 
 _WGRAD = [0, 1, 2, 3, 5, 6, 8]      # weight-gradient switches: every block shape (2x2, 3x3, 4x4, two sources, the stem, K = 8)
 _ORDER = [1, 2, 5, 8]               # dispatch-order switches: one case per rulebook kind
 REGIME_CASES = {
-    'unsplit': _ALL, 'unsplit_three_steps_in_flight': [0, 1, 2, 4, 8], 'unsplit_compiler_tracked_loads': _ALL,
+    'unsplit': _ALL, 'unsplit_compiler_tracked_loads': _ALL,
     'split_compiler_tracked_loads': _SPLIT, 'unsplit_32_column_strips': [1, 2, 4, 8, 9], 'atomic_combine': _SPLIT,
     'no_chunk_slices': _SPLIT, 'many_slices': _SPLIT, 'wgrad_plain': _WGRAD, 'wgrad_compiler_tracked_loads': _WGRAD,
     'wgrad_hand_issued_loads_square_blocks_only': _WGRAD, 'wgrad_64_tile_chunks': _WGRAD, 'wgrad_one_offset_per_workgroup': [0, 5, 6],

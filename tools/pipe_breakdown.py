@@ -17,7 +17,7 @@ def t(n=5):
     for _ in range(n): F_.conv_raw(x, None, wp, 27, None, rb, rb.n_out, 96)
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n
 for rnd in range(2):
-    for name, env in [('old kernel', {'B2M_CONV_PIPE': '0'}), ('flow', {}), ('flow depth 3', {'B2M_CONV_PIPE': '3'}),
+    for name, env in [('old kernel', {'B2M_CONV_PIPE': '0'}), ('flow', {}),
                       ('flow -flush', {'B2M_PIPE_DBG': '1'}), ('flow -gathers', {'B2M_PIPE_DBG': '2'}),
                       ('flow -weights', {'B2M_PIPE_DBG': '4'}), ('flow -gathers -weights', {'B2M_PIPE_DBG': '6'})]:
         for k in ('B2M_CONV_PIPE', 'B2M_PIPE_DBG'): os.environ.pop(k, None)
