@@ -934,7 +934,10 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     // 6144 rather than one wave per SIMD slot (4096): a map with ~4.3k items ran 1.05 rounds of waves at 50 TFLOP/s;
     // as 4 in-LDS-combined slices it runs at 61
     // B2M_DETERMINISTIC=1: never split (the split-K combine of more than 4 slices adds with fp32 atomics)
-    const int64_t target = env_flag("B2M_DETERMINISTIC", 0) ? 0 : env_flag("B2M_CONV_TARGET", 6144);
+    // (round 5: layers with one or two 16-channel chunks -- the 32-channel blocks of level 1, 4.5 k items at the benchmark's
+    // size -- have so little work per (offset, slice) that the split costs more than the second round of waves: 52 -> 56
+    // TFLOP/s un-split; they split only below 4096 items)
+    const int64_t target = env_flag("B2M_DETERMINISTIC", 0) ? 0 : env_flag("B2M_CONV_TARGET", cin <= 32 ? 4096 : 6144);
     if (items0 < target && K > 1) {
         nslice = (int)cdiv64(target, items0);
         if (nslice > 16) nslice = 16;
