@@ -1813,10 +1813,11 @@ static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& 
             // (real rulebooks only: an identity map has every pair of a tile but the last one's -- nothing to mask, and the
             // A/B says so: 128 -> 96 on 1.2 M rows 94.0 against 95.3 TFLOP/s)
             if (a.rb_in && NJ >= 2 && (a.handloads >= 2 || (a.handloads == 1 && MI == NJ && MI >= 3))) {
+                const size_t xl = (size_t)env_flag("B2M_WGRAD_LDS", 0);      // diagnostic: extra LDS per workgroup caps the resident waves
                 switch (NJ) {
-                    case 2: conv_wgrad_flow_kernel<MI, 2, 1><<<grid, 256, 0, st>>>(a); break;
-                    case 3: conv_wgrad_flow_kernel<MI, 3, 1><<<grid, 256, 0, st>>>(a); break;
-                    default: conv_wgrad_flow_kernel<MI, 4, 1><<<grid, 256, 0, st>>>(a); break;
+                    case 2: conv_wgrad_flow_kernel<MI, 2, 1><<<grid, 256, xl, st>>>(a); break;
+                    case 3: conv_wgrad_flow_kernel<MI, 3, 1><<<grid, 256, xl, st>>>(a); break;
+                    default: conv_wgrad_flow_kernel<MI, 4, 1><<<grid, 256, xl, st>>>(a); break;
                 }
                 return;
             }

@@ -119,8 +119,7 @@ def test_default_mode_gradients_match_oracle_affine_batchnorm(monkeypatch):
 def test_default_mode_train_batchnorm_many_scenes(monkeypatch):
     """Train-mode BatchNorm, default mode, 32 small scenes: the deepest level keeps >= 32 rows, so the batch statistics
     are well conditioned.  With the ReLU decisions shared, every parameter gradient against the fp64 oracle <= 1e-3
-    (observed 8e-5); the same gradients against the fp64 oracle WITHOUT that help are printed for the record (per cent
-    level: sign flips, tests/_parity.py -- the fp32 CPU oracle is as far from the fp64 one)."""
+    (observed 8e-5)."""
     _default_env(monkeypatch)
     from box2mask_amd.detection_net import SelectionNet
     from box2mask_amd import nn as ME
@@ -141,24 +140,22 @@ def test_default_mode_train_batchnorm_many_scenes(monkeypatch):
         out = net(sin, batch['pooling_ids'].cuda(), S_)
     sum((out[h].F * gws[h].cuda()).sum() for h in HEADS).backward()
     hier = sparse_ref.Hierarchy(batch['vox_coords'].numpy())
-    p64, o64 = _oracle_grads(sd, batch, gws, cfg, True, torch.float64, hier)
+    # ONE fp64 oracle pass, with the device's ReLU decisions replayed (and checked against the oracle's own: tests/_parity.py).
+    # (Rounds 3-4 ran a second, unshared pass only to print the per-cent-level figures it gives; tools/debug_default_mode.py still does.)
     with monkeypatch.context() as mp:
         rec.replay(sin.manager, hier, S_, mp)
         pm, om = _oracle_grads(sd, batch, gws, cfg, True, torch.float64, hier)
     print('%d replayed ReLUs, largest disagreeing fraction %.2e, largest |x|/rms of a disagreeing element %.2e'
           % ((len(rec.checks),) + rec.summary()))
     for h in HEADS:
-        assert _rel(out[h].F, o64[h]) < 1e-3, (h, _rel(out[h].F, o64[h]))
-    rows = []
-    for name, prm in net.named_parameters():
-        rows.append((_rel(prm.grad, pm[name].grad), _rel(prm.grad, p64[name].grad), name))
-    e_m = sorted(r[0] for r in rows); e_gpu = sorted(r[1] for r in rows)
+        assert _rel(out[h].F, om[h]) < 1e-3, (h, _rel(out[h].F, om[h]))
+    rows = sorted(((_rel(prm.grad, pm[name].grad), name) for name, prm in net.named_parameters()), reverse=True)
+    e_m = sorted(r[0] for r in rows)
     q = lambda v, f: v[min(int(f * len(v)), len(v) - 1)]
-    print('gradient error vs fp64 (shared ReLU decisions | unshared): median %.3e | %.3e, p90 %.3e | %.3e, max %.3e | %.3e'
-          % (q(e_m, .5), q(e_gpu, .5), q(e_m, .9), q(e_gpu, .9), e_m[-1], e_gpu[-1]))
-    for r in sorted(rows, reverse=True)[:5]:
-        print('   worst: shared %.3e unshared %.3e %s' % r)
-    assert e_m[-1] < 1e-3, sorted(rows, reverse=True)[:5]
+    print('gradient error vs fp64 (shared ReLU decisions): median %.3e, p90 %.3e, max %.3e' % (q(e_m, .5), q(e_m, .9), e_m[-1]))
+    for r in rows[:5]:
+        print('   worst: %.3e %s' % r)
+    assert e_m[-1] < 1e-3, rows[:5]
 
 
 def test_default_and_deterministic_mode_on_a_block_chain(monkeypatch):
@@ -248,6 +245,10 @@ def test_default_and_deterministic_mode_on_a_block_chain(monkeypatch):
         # no synchronize: read on the current stream
         y_in, dx_in = y.detach()[inv].cpu(), sin.F.grad[inv].cpu()      # back to input row order
         g = {n: q.grad.cpu() for n, q in net.named_parameters()}
+        if mode == 'default again':          # (the second default run: against the first one, not a third oracle pass)
+            assert _rel(y_in, outputs['default']) < 1e-4
+            outputs[mode] = y_in
+            continue
         with monkeypatch.context() as mp:
             it = rec.replay(sin.manager, hier, -1, mp)
             oy, odx, og = oracle(sd, feats, gy, hier)
