@@ -41,6 +41,7 @@ PROTOTYPES = {
     'b2m_weight_pack_h': [P, I64, I32, I32, I32, I32, P, P],
     'b2m_conv_fwd_stats': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P, P, P],
     'b2m_clock_probe': [P, I32, P],
+    'b2m_xchg_allreduce': [P, I32, P, I32, I32, C.c_uint64, P, P, P],
     'b2m_conv_up': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, P, I64, I32, I64, I32, P, P, P, I64, I32, P, P],
     'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
     'b2m_weight_pack_run': [P, I32, I64, P],
@@ -104,6 +105,9 @@ PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_
          'b2m_weight_pack_plan_size': (C.c_int32, []),
          'b2m_rulebook_cnt_size': (C.c_int64, [I32, I64]),
          'b2m_radix_argsort_scratch': (C.c_int64, [I64]),
+         'b2m_xchg_size': (C.c_int64, []), 'b2m_xchg_max_doubles': (C.c_int32, []), 'b2m_xchg_max_ranks': (C.c_int32, []),
+         'b2m_xchg_alloc': (C.c_int, [C.POINTER(C.c_void_p), P]), 'b2m_xchg_open': (C.c_int, [P, C.POINTER(C.c_void_p)]),
+         'b2m_xchg_close': (C.c_int, [P]), 'b2m_xchg_free': (C.c_int, [P]),
          'b2m_weight_pack_plan': (C.c_int64, [I32, P, P, P, P, P, P, P, P, P, P, P])}
 
 _lib = None

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libb2m_hip.so')
-SOURCES = ['coords.hip', 'conv.hip', 'norm.hip', 'nms.hip', 'voxelize.hip']
+SOURCES = ['coords.hip', 'conv.hip', 'norm.hip', 'nms.hip', 'voxelize.hip', 'xchg.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics', '-Wall',
          '-Wno-unused-function']

@@ -569,22 +569,30 @@ _RED_BLOCKS = 4096
 # Collectives of the data-parallel path, counted (and, when bench.py asks, timed with HIP events on the current stream): one
 # blocking, latency-bound all-reduce per SyncBN layer and direction, a few large asynchronous ones for the gradient buckets
 # (parallel.GradAllReduce).  `collective_stats['timing']` = True makes every SyncBN all-reduce carry an event pair.
-collective_stats = {'syncbn': 0, 'grad_buckets': 0, 'bytes': 0, 'timing': False, 'events': []}
+collective_stats = {'syncbn': 0, 'grad_buckets': 0, 'bytes': 0, 'timing': False, 'events': [], 'ipc': 0}
+ipc_exchange = None        # parallel.IpcExchange of the data-parallel group (B2M_SYNCBN_IPC=1; set by Model.__init__)
 
 
 def _sync_all_reduce(t, group):
-    """A SyncBN statistics exchange: SUM over the ranks, in place, blocking on the current stream."""
+    """A SyncBN statistics exchange: SUM over the ranks, in place, blocking on the current stream -- through the device-side
+    mailbox exchange when one is set up for this group (parallel.IpcExchange), else torch.distributed."""
     st = collective_stats
     st['syncbn'] += 1
     st['bytes'] += t.numel() * t.element_size()
+    x = ipc_exchange
+    if x is not None and x.usable(t) and (group is None or group is x.group or x.group is None):
+        st['ipc'] += 1
+        reduce = lambda: x.all_reduce_(t)
+    else:
+        reduce = lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     if st['timing'] and t.is_cuda:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        reduce()
         e.record()
         st['events'].append((s, e))
     else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        reduce()
 
 
 

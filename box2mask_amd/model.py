@@ -18,6 +18,11 @@ from .iou_nms import semIOU
 from .util import to_bbs_min_max_
 
 
+def dist_world() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def _pearsonr(a: torch.Tensor, b: torch.Tensor):
     """Pearson correlation on the device (scipy.stats.pearsonr at model.py:170,191 is logging only;
     computing it here removes two blocking D2H copies per step).  Returns a 0-dim tensor (`.item()` works)."""
@@ -66,6 +71,11 @@ class Model:
             self._dp = GradAllReduce(list(self.detection_model.parameters()), arena=self._arena,
                                      buffers=list(self.detection_model.buffers()))
             self._dp.broadcast_parameters()
+            # B2M_SYNCBN_IPC=1 (opt-in, one node): the SyncBN statistics go through mailboxes mapped between the ranks instead of
+            # through the collective library -- one one-workgroup launch per exchange (parallel.IpcExchange)
+            from . import parallel, functional as F_
+            if parallel.syncbn_ipc_enabled() and dist_world() > 1 and F_.ipc_exchange is None:
+                F_.ipc_exchange = parallel.IpcExchange(device=torch.device(device) if device is not None else None)
         self.BCEWithLogitsLoss = torch.nn.BCEWithLogitsLoss().to(device)
         self.semantics_loss = torch.nn.CrossEntropyLoss(ignore_index=-100).to(device)
         self._id2idx_dev = None

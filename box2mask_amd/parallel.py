@@ -45,6 +45,75 @@ def init_distributed(backend: str | None = None):
     return rank, world
 
 
+class IpcExchange:
+    """The SyncBN statistics exchange inside one node without the collective library (include/b2m.h: b2m_xchg_*): every rank
+    owns a mailbox in device memory, mapped into its peers through HIP IPC; an exchange is ONE one-workgroup launch that writes
+    this rank's doubles into every mailbox, waits (bounded) for the peers' and adds up in rank order.  Opt-in: B2M_SYNCBN_IPC=1
+    (functional._sync_all_reduce takes it for float64 device tensors of <= b2m_xchg_max_doubles() elements; everything else and
+    every gradient bucket stays on torch.distributed).  Set-up is collective: every rank of `group` constructs it at the same
+    point (Model.__init__ under cfg.multigpu does).  Exercised with two processes on ONE GPU (tests/test_gpu_dp.py); ranks on
+    different GPUs need peer-visible mailboxes (b2m_xchg_alloc asks for fine-grained memory) -- no lease of the build pool had two."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > lib.b2m_xchg_max_ranks():
+            raise _lib.B2MError('IpcExchange: at most %d ranks' % lib.b2m_xchg_max_ranks())
+        self.max_n = int(lib.b2m_xchg_max_doubles())
+        self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self._lib = lib
+        buf, handle = C.c_void_p(), C.create_string_buffer(64)
+        if lib.b2m_xchg_alloc(C.byref(buf), handle) != 0:
+            raise _lib.B2MError('b2m_xchg_alloc failed: ' + lib.b2m_last_error().decode())
+        self._own = buf.value
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw), group=group)
+        ptrs, self._opened = [], []
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                ptrs.append(self._own)
+                continue
+            p = C.c_void_p()
+            if lib.b2m_xchg_open(C.create_string_buffer(h, 64), C.byref(p)) != 0:
+                raise _lib.B2MError('b2m_xchg_open failed: ' + lib.b2m_last_error().decode())
+            ptrs.append(p.value); self._opened.append(p.value)
+        self.peers = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.epoch = 0
+        dist.barrier(group=group)              # every mailbox is mapped everywhere before the first exchange
+
+    def usable(self, t: torch.Tensor) -> bool:
+        return t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and 1 <= t.numel() <= self.max_n
+
+    def all_reduce_(self, t: torch.Tensor):
+        """SUM over the ranks, in place, on the current stream (every rank calls it for the same exchange in the same order)."""
+        from . import _lib
+        self.epoch += 1
+        _lib.call('b2m_xchg_allreduce', t.data_ptr(), t.numel(), self.peers.data_ptr(), self.rank, self.world, self.epoch,
+                  t.data_ptr(), self.err.data_ptr())
+
+    def check(self):
+        """Raises if an exchange gave up waiting for a peer (host read: call it at a step boundary, not per layer)."""
+        from . import _lib
+        if int(self.err.item()) != 0:
+            raise _lib.B2MError('IpcExchange: a rank did not arrive within the wait bound; the statistics of that exchange are invalid')
+
+    def close(self):
+        for p in self._opened:
+            self._lib.b2m_xchg_close(p)
+        self._opened = []
+        if self._own:
+            self._lib.b2m_xchg_free(self._own)
+            self._own = None
+
+
+def syncbn_ipc_enabled() -> bool:
+    return os.environ.get('B2M_SYNCBN_IPC', '0') == '1'
+
+
 def shard_scenes(n_scenes: int, rank: int, world: int):
     """Scene indices of this rank (DistributedSampler semantics without shuffling,
     /root/reference/models/dataloader.py:334-341): rank r takes scenes r, r+world, ..."""

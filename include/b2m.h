@@ -264,6 +264,26 @@ int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const
                    const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                    int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace, void* stream);
 
+/* ---------------------------------------------------------------- SyncBN statistics exchange inside one node (opt-in)
+ * Device-side all-reduce (SUM) of n <= b2m_xchg_max_doubles() doubles between <= b2m_xchg_max_ranks() ranks whose MAILBOXES
+ * (b2m_xchg_size() bytes of device memory each) are mapped into one another through HIP IPC: one launch of one workgroup
+ * writes this rank's values into slot [rank] of every mailbox, raises its flag there, waits (bounded: ~7 s, then *err = 1) for
+ * every flag of its own mailbox and adds the slots in rank order.  Replaces, for the 2c + 1 ... 3c doubles of a SyncBN layer
+ * (/root/reference/models/model.py:25), the collective library's all-reduce.  Set-up per rank: b2m_xchg_alloc -> own mailbox + a
+ * 64-byte IPC handle; the handles travel over the process group; b2m_xchg_open maps a peer's mailbox; `peers_dev` is a device
+ * array of `world` mailbox addresses in rank order (own mailbox at [rank]).  `epoch` counts the exchanges of the group from 1
+ * (every rank passes the same value); out may alias vals.  Exercised with two processes on one GPU; across GPUs the mailboxes
+ * need peer-visible memory (fine-grained, which b2m_xchg_alloc asks for first). */
+int64_t b2m_xchg_size(void);
+int32_t b2m_xchg_max_doubles(void);
+int32_t b2m_xchg_max_ranks(void);
+int b2m_xchg_alloc(void** buf, void* handle64);
+int b2m_xchg_open(const void* handle64, void** ptr);
+int b2m_xchg_close(void* ptr);
+int b2m_xchg_free(void* buf);
+int b2m_xchg_allreduce(const double* vals, int32_t n, const void* const* peers_dev, int32_t rank, int32_t world,
+                       uint64_t epoch, double* out, int32_t* err, void* stream);
+
 /* Measurement aid (bench.py `roofline.clock_mhz`; no counterpart in the reference): the shader clock the device holds
  * under fp32-MFMA load.  768 workgroups x 4 waves run `iters` blocks of 12 v_mfma_f32_16x16x4_f32; every wave stamps
  * s_memtime (shader cycles) and s_memrealtime (100 MHz ticks) around its loop.  out4 (device, zeroed by the call):

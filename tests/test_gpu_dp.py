@@ -39,9 +39,13 @@ def _worker(rank, world, port, q, backend='gloo', env=None):
     g = torch.cat([p.grad.reshape(-1)[:64].cpu() for p in list(model.parameters())[:6]])
     # every BatchNorm parameter gradient and a slice of every convolution's (compared between execution modes)
     named = {n: p.grad.reshape(-1)[:256].cpu().numpy() for n, p in model.detection_model.named_parameters() if p.grad is not None}
+    from box2mask_amd import functional as F_
+    if F_.ipc_exchange is not None:
+        F_.ipc_exchange.check()                  # no exchange gave up waiting for its peer
     q.put((rank, {'pred': {k: v.detach().cpu().numpy() for k, v in pred.items()}, 'grad': g.numpy(), 'named': named,
                   'loss': float(losses['optimization_loss'].item()), 'scenes': mine,
-                  'rm': model.state_dict()['bn0.bn.running_mean'].cpu().numpy()}))
+                  'rm': model.state_dict()['bn0.bn.running_mean'].cpu().numpy(),
+                  'ipc': F_.collective_stats['ipc'], 'syncbn': F_.collective_stats['syncbn']}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -128,3 +132,21 @@ def _two_rank_check(backend):
     # both ranks hold the same (mean) gradients after the all-reduce
     assert np.allclose(res[0]['grad'], res[1]['grad'], rtol=1e-5, atol=1e-7)
     assert n0 > 0 and np.isfinite(res[0]['loss']) and np.isfinite(res[1]['loss'])
+
+
+@pytest.mark.timeout(900)
+def test_syncbn_statistics_through_ipc_mailboxes_two_ranks():
+    """B2M_SYNCBN_IPC=1: every SyncBN statistics exchange of the step (forward and backward, single layers, pairs, the small-map
+    half-kernels) goes through the device-side mailbox exchange (b2m_xchg_allreduce: two processes on this one GPU, their
+    mailboxes mapped into each other through HIP IPC) instead of torch.distributed -- and gives the SAME BITS: the sum of two
+    ranks' doubles is one addition either way.  The gradient buckets stay on torch.distributed."""
+    ref = _run_two_ranks('gloo')
+    ipc = _run_two_ranks('gloo', env={'B2M_SYNCBN_IPC': '1'})
+    for r in (0, 1):
+        assert ref[r]['ipc'] == 0 and ipc[r]['ipc'] == ipc[r]['syncbn'] > 100, (ref[r]['ipc'], ipc[r]['ipc'], ipc[r]['syncbn'])
+        assert ipc[r]['loss'] == ref[r]['loss']
+        for k in ref[r]['pred']:
+            assert np.array_equal(ipc[r]['pred'][k], ref[r]['pred'][k]), k
+        for n in ref[r]['named']:
+            assert np.array_equal(ipc[r]['named'][n], ref[r]['named'][n]), n
+        assert np.array_equal(ipc[r]['rm'], ref[r]['rm'])
