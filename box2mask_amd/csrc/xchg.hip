@@ -15,7 +15,7 @@
 #include "b2m_common.h"
 #include <string.h>
 
-#define XCHG_SLOT 1024            // doubles per rank and exchange
+#define XCHG_SLOT 2048            // doubles per rank and exchange (the paired BatchNorm of a 256-channel block sends 4c + 1 = 1025)
 #define XCHG_MAX_RANKS 16
 struct XchgMailbox {
     double slots[2][XCHG_MAX_RANKS][XCHG_SLOT];

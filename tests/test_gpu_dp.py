@@ -140,8 +140,9 @@ def test_syncbn_statistics_through_ipc_mailboxes_two_ranks():
     half-kernels) goes through the device-side mailbox exchange (b2m_xchg_allreduce: two processes on this one GPU, their
     mailboxes mapped into each other through HIP IPC) instead of torch.distributed -- and gives the SAME BITS: the sum of two
     ranks' doubles is one addition either way.  The gradient buckets stay on torch.distributed."""
-    ref = _run_two_ranks('gloo')
-    ipc = _run_two_ranks('gloo', env={'B2M_SYNCBN_IPC': '1'})
+    # (B2M_DETERMINISTIC=1: ordered reductions everywhere else, so that two runs of the step give the same bits at all)
+    ref = _run_two_ranks('gloo', env={'B2M_DETERMINISTIC': '1'})
+    ipc = _run_two_ranks('gloo', env={'B2M_DETERMINISTIC': '1', 'B2M_SYNCBN_IPC': '1'})
     for r in (0, 1):
         assert ref[r]['ipc'] == 0 and ipc[r]['ipc'] == ipc[r]['syncbn'] > 100, (ref[r]['ipc'], ipc[r]['ipc'], ipc[r]['syncbn'])
         assert ipc[r]['loss'] == ref[r]['loss']
