@@ -83,6 +83,7 @@ PROTOTYPES = {
     'b2m_set_ious': [P, P, I64, P, P],
     # include/b2m_prepare.h
     'b2m_vox_shift': [P, I64, P, P, P],
+    'b2m_unique_insert_async': [P, I64, P, I64, P, P, P, P],
     'b2m_vox_keys': [P, I64, P, F64, P, P, P],
     'b2m_sort_u64': [P, I64, P],
     'b2m_unique_rank': [P, I64, P, P, I64, P, I64, P, P],

@@ -140,9 +140,8 @@ __global__ void unique_insert_kernel(const uint64_t* __restrict__ in, int64_t n,
 
 static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
-extern "C" int64_t b2m_unique_insert(const uint64_t* in, int64_t n, uint64_t* tkeys, int64_t cap, int32_t* slot_of,
-                                     uint64_t* ukeys, int32_t* n_unique, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int unique_insert_launch(const uint64_t* in, int64_t n, uint64_t* tkeys, int64_t cap, int32_t* slot_of, uint64_t* ukeys,
+                                int32_t* n_unique, hipStream_t st) {
     B2M_CHECK_ARG(in && tkeys && slot_of && ukeys && n_unique && n >= 0 && n < (1ll << 31), "bad arguments");
     B2M_CHECK_ARG(pow2(cap) && cap >= 2 * n && cap < (1ll << 31), "cap must be a power of two >= 2n");
     B2M_HIP(hipMemsetAsync(tkeys, 0xFF, cap * sizeof(uint64_t), st));
@@ -151,10 +150,23 @@ extern "C" int64_t b2m_unique_insert(const uint64_t* in, int64_t n, uint64_t* tk
         unique_insert_kernel<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(in, n, tkeys, cap - 1, slot_of, ukeys, n_unique);
         B2M_LAUNCH_CHECK();
     }
+    return B2M_OK;
+}
+extern "C" int64_t b2m_unique_insert(const uint64_t* in, int64_t n, uint64_t* tkeys, int64_t cap, int32_t* slot_of,
+                                     uint64_t* ukeys, int32_t* n_unique, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = unique_insert_launch(in, n, tkeys, cap, slot_of, ukeys, n_unique, st);
+    if (rc != B2M_OK) return rc;
     int32_t h = 0;
     B2M_HIP(hipMemcpyAsync(&h, n_unique, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     B2M_HIP(hipStreamSynchronize(st));
     return (int64_t)h;
+}
+// the same without the host read: the count stays in *n_unique on the device (prepare.voxelize_scenes reads the counts of all
+// scenes of a batch at once)
+extern "C" int b2m_unique_insert_async(const uint64_t* in, int64_t n, uint64_t* tkeys, int64_t cap, int32_t* slot_of,
+                                       uint64_t* ukeys, int32_t* n_unique, void* stream) {
+    return unique_insert_launch(in, n, tkeys, cap, slot_of, ukeys, n_unique, (hipStream_t)stream);
 }
 
 // ---- bitonic sort of uint64 keys, ascending; n is a power of two (caller pads with 0xFF..FF)

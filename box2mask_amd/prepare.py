@@ -28,9 +28,9 @@ def _dev(x, dtype, device):
     return t.to(device=device, dtype=dtype).contiguous()
 
 
-def _unique_inverse(keys: torch.Tensor):
-    """np.unique(keys, return_inverse=True) for non-negative int64 keys on the device.
-    Returns (sorted unique keys (padded buffer), n_unique, inverse int64, table keys, table vals, cap)."""
+def _unique_begin(keys: torch.Tensor):
+    """First half of np.unique(keys, return_inverse=True) for non-negative int64 keys on the device: the hash insert, WITHOUT the
+    host read of the number of distinct keys (it stays in `n_unique` on the device)."""
     dev = keys.device
     n = keys.shape[0]
     cap = _pow2(max(2 * n, 16))
@@ -39,11 +39,24 @@ def _unique_inverse(keys: torch.Tensor):
     slot_of = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     ukeys = torch.full((_pow2(max(n, 2)),), -1, dtype=torch.int64, device=dev)       # 2^64-1 = padding, sorts last
     n_unique = torch.empty(1, dtype=torch.int32, device=dev)
-    nu = _lib.call_ret('b2m_unique_insert', ptr(keys), n, ptr(tkeys), cap, ptr(slot_of), ptr(ukeys), ptr(n_unique))
-    _lib.call('b2m_sort_u64', ptr(ukeys), _pow2(max(nu, 2)))
-    inverse = torch.empty(n, dtype=torch.int64, device=dev)
-    _lib.call('b2m_unique_rank', ptr(ukeys), nu, ptr(tkeys), ptr(tvals), cap, ptr(slot_of), n, ptr(inverse))
-    return ukeys, int(nu), inverse, tkeys, tvals, cap
+    _lib.call('b2m_unique_insert_async', ptr(keys), n, ptr(tkeys), cap, ptr(slot_of), ptr(ukeys), ptr(n_unique))
+    return dict(n=n, cap=cap, tkeys=tkeys, tvals=tvals, slot_of=slot_of, ukeys=ukeys, n_unique=n_unique)
+
+
+def _unique_finish(u: dict, nu: int):
+    """Second half, once the count is on the host: sort of the distinct keys, ranks, inverse.
+    Returns (sorted unique keys (padded buffer), n_unique, inverse int64, table keys, table vals, cap)."""
+    _lib.call('b2m_sort_u64', ptr(u['ukeys']), _pow2(max(nu, 2)))
+    inverse = torch.empty(u['n'], dtype=torch.int64, device=u['ukeys'].device)
+    _lib.call('b2m_unique_rank', ptr(u['ukeys']), nu, ptr(u['tkeys']), ptr(u['tvals']), u['cap'], ptr(u['slot_of']), u['n'],
+              ptr(inverse))
+    return u['ukeys'], int(nu), inverse, u['tkeys'], u['tvals'], u['cap']
+
+
+def _unique_inverse(keys: torch.Tensor):
+    """np.unique(keys, return_inverse=True) for non-negative int64 keys on the device (one host read: the count)."""
+    u = _unique_begin(keys)
+    return _unique_finish(u, int(u['n_unique'].item()))
 
 
 def voxelize_scene(scene: dict, voxel_size: float, use_normals_input: bool = True, device=None,
@@ -55,62 +68,88 @@ def voxelize_scene(scene: dict, voxel_size: float, use_normals_input: bool = Tru
 
     scene: {'positions' (P,3), 'colors' (P,3), 'normals' (P,3), 'segments' (P,)} numpy or torch (float64 / int64,
     as dataprocessing/scannet.py:412 provides them).  Returns the reference's item keys."""
+    return voxelize_scenes([scene], voxel_size, use_normals_input, device, do_segment_pooling)[0]
+
+
+def voxelize_scenes(scenes, voxel_size: float, use_normals_input: bool = True, device=None,
+                    do_segment_pooling: bool = True) -> list:
+    """voxelize_scene for all scenes of a batch with TWO host reads per batch (round 5; one scene used to cost four): every
+    scene's kernels of a stage are queued before the stage's small results -- the voxel counts with the range / segment-id
+    checks, then the segment counts -- come back in one copy.  Same kernels, same order per scene: the same bits."""
     _lib.require_gpu()
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-    pos = _dev(scene['positions'], torch.float64, dev)
-    assert pos.dim() == 2 and pos.shape[1] == 3, 'positions must be (P,3)'
-    P = pos.shape[0]
-    if P == 0:
-        raise ValueError('voxelize_scene: empty scene')
-    colors = _dev(scene['colors'], torch.float64, dev)
-    normals = _dev(scene['normals'], torch.float64, dev) if use_normals_input else None
-    segments = _dev(scene['segments'], torch.int64, dev).reshape(-1)
-    assert colors.shape == (P, 3) and segments.shape == (P,) and (normals is None or normals.shape == (P, 3))
-
-    shift = torch.empty(1, dtype=torch.float64, device=dev)
-    scratch = torch.empty(1, dtype=torch.int64, device=dev)
-    _lib.call('b2m_vox_shift', ptr(pos), P, ptr(shift), ptr(scratch))
-    keys = torch.empty(P, dtype=torch.int64, device=dev)
-    bad = torch.empty(1, dtype=torch.int32, device=dev)
-    _lib.call('b2m_vox_keys', ptr(pos), P, ptr(shift), float(voxel_size), ptr(keys), ptr(bad))
-    ukeys, N, vox2point, tkeys, tvals, cap = _unique_inverse(keys)          # synchronises
-    if int(bad.item()):
-        raise ValueError('voxelize_scene: %d points fall outside 2^21 voxels per axis (or are NaN)' % int(bad.item()))
-    coords = torch.empty((N, 4), dtype=torch.int32, device=dev)
-    _lib.call('b2m_vox_decode', ptr(ukeys), N, 0, ptr(coords))
-    best = torch.empty(N, dtype=torch.int64, device=dev)
-    point2vox = torch.empty(N, dtype=torch.int32, device=dev)
-    _lib.call('b2m_vox_nearest', ptr(pos), P, ptr(shift), float(voxel_size), ptr(tkeys), ptr(tvals), cap, N,
-              ptr(best), ptr(point2vox))
-    feats = torch.empty((N, 6 if use_normals_input else 3), dtype=torch.float32, device=dev)
-    vox_segments = torch.empty(N, dtype=torch.int64, device=dev)
-    _lib.call('b2m_vox_gather', ptr(point2vox), N, ptr(colors), ptr(normals), ptr(segments), ptr(feats),
-              ptr(vox_segments))
-
-    # ---- segments (dataloader.py:106-120)
-    if int(segments.min().item()) < 0:
-        raise ValueError('voxelize_scene: negative segment ids')
-    useg, S, seg2vox, seg_tkeys, seg_tvals, seg_cap = _unique_inverse(vox_segments)
-    sums = torch.empty(3 * S, dtype=torch.int64, device=dev)
-    counts = torch.empty(S, dtype=torch.int32, device=dev)
-    middle = torch.empty((S, 3), dtype=torch.float64, device=dev)
-    _lib.call('b2m_seg_centroid', ptr(coords), ptr(seg2vox), N, S, float(voxel_size), ptr(shift), ptr(sums),
-              ptr(counts), ptr(middle))
-    seg2point = seg2vox[vox2point]
-    item = {
-        'scene': scene, 'vox_coords': coords, 'vox2point': vox2point, 'point2vox': point2vox.long(),
-        'vox_segments': vox_segments, 'vox_features': feats, 'seg2vox': seg2vox, 'seg2point': seg2point,
-        'pred2point': seg2point, 'input_location': middle, 'unique_vox_segments': useg[:S],
-        'voxel_shift': shift, 'voxel_size': float(voxel_size), 'do_segment_pooling': bool(do_segment_pooling),
-        '_device_scene': {'positions': pos, 'segments': segments}, '_segment_table': (seg_tkeys, seg_tvals, seg_cap),
-    }
-    if not do_segment_pooling:
-        # :98-105: no segment keys; unique_vox_segments stays (the box supervision recomputes it, :131-132)
-        for k in ('seg2vox', 'seg2point'):
-            del item[k]
-        item['input_location'] = vox_world_coords(item)
-        item['pred2point'] = vox2point
-    return item
+    st = []
+    # ---- stage A: keys and the voxel hash of every scene
+    for scene in scenes:
+        pos = _dev(scene['positions'], torch.float64, dev)
+        assert pos.dim() == 2 and pos.shape[1] == 3, 'positions must be (P,3)'
+        P = pos.shape[0]
+        if P == 0:
+            raise ValueError('voxelize_scene: empty scene')
+        colors = _dev(scene['colors'], torch.float64, dev)
+        normals = _dev(scene['normals'], torch.float64, dev) if use_normals_input else None
+        segments = _dev(scene['segments'], torch.int64, dev).reshape(-1)
+        assert colors.shape == (P, 3) and segments.shape == (P,) and (normals is None or normals.shape == (P, 3))
+        shift = torch.empty(1, dtype=torch.float64, device=dev)
+        scratch = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.call('b2m_vox_shift', ptr(pos), P, ptr(shift), ptr(scratch))
+        keys = torch.empty(P, dtype=torch.int64, device=dev)
+        bad = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.call('b2m_vox_keys', ptr(pos), P, ptr(shift), float(voxel_size), ptr(keys), ptr(bad))
+        u = _unique_begin(keys)
+        st.append(dict(scene=scene, pos=pos, P=P, colors=colors, normals=normals, segments=segments, shift=shift, bad=bad, u=u,
+                       seg_min=segments.min()))
+    # one read: voxel counts, out-of-range points, smallest segment id of every scene
+    head = torch.stack([torch.stack([s['u']['n_unique'][0].long(), s['bad'][0].long(), s['seg_min']]) for s in st]).cpu().tolist()
+    for s, (nu, nbad, smin) in zip(st, head):
+        if nbad:
+            raise ValueError('voxelize_scene: %d points fall outside 2^21 voxels per axis (or are NaN)' % nbad)
+        if smin < 0:
+            raise ValueError('voxelize_scene: negative segment ids')
+        s['N'] = int(nu)
+    # ---- stage B: voxel rows, nearest points, features; the segment hash
+    for s in st:
+        P, pos, shift = s['P'], s['pos'], s['shift']
+        ukeys, N, vox2point, tkeys, tvals, cap = _unique_finish(s['u'], s['N'])
+        coords = torch.empty((N, 4), dtype=torch.int32, device=dev)
+        _lib.call('b2m_vox_decode', ptr(ukeys), N, 0, ptr(coords))
+        best = torch.empty(N, dtype=torch.int64, device=dev)
+        point2vox = torch.empty(N, dtype=torch.int32, device=dev)
+        _lib.call('b2m_vox_nearest', ptr(pos), P, ptr(shift), float(voxel_size), ptr(tkeys), ptr(tvals), cap, N,
+                  ptr(best), ptr(point2vox))
+        feats = torch.empty((N, 6 if use_normals_input else 3), dtype=torch.float32, device=dev)
+        vox_segments = torch.empty(N, dtype=torch.int64, device=dev)
+        _lib.call('b2m_vox_gather', ptr(point2vox), N, ptr(s['colors']), ptr(s['normals']), ptr(s['segments']), ptr(feats),
+                  ptr(vox_segments))
+        s.update(vox2point=vox2point, coords=coords, point2vox=point2vox, feats=feats, vox_segments=vox_segments,
+                 useg=_unique_begin(vox_segments))          # segments (dataloader.py:106-120)
+    seg_counts = torch.cat([s['useg']['n_unique'] for s in st]).cpu().tolist()          # the second (and last) read
+    # ---- stage C: segment ranks and centroids
+    items = []
+    for s, S in zip(st, seg_counts):
+        N, coords, shift, vox2point = s['N'], s['coords'], s['shift'], s['vox2point']
+        useg, S, seg2vox, seg_tkeys, seg_tvals, seg_cap = _unique_finish(s['useg'], int(S))
+        sums = torch.empty(3 * S, dtype=torch.int64, device=dev)
+        counts = torch.empty(S, dtype=torch.int32, device=dev)
+        middle = torch.empty((S, 3), dtype=torch.float64, device=dev)
+        _lib.call('b2m_seg_centroid', ptr(coords), ptr(seg2vox), N, S, float(voxel_size), ptr(shift), ptr(sums),
+                  ptr(counts), ptr(middle))
+        seg2point = seg2vox[vox2point]
+        item = {
+            'scene': s['scene'], 'vox_coords': coords, 'vox2point': vox2point, 'point2vox': s['point2vox'].long(),
+            'vox_segments': s['vox_segments'], 'vox_features': s['feats'], 'seg2vox': seg2vox, 'seg2point': seg2point,
+            'pred2point': seg2point, 'input_location': middle, 'unique_vox_segments': useg[:S],
+            'voxel_shift': shift, 'voxel_size': float(voxel_size), 'do_segment_pooling': bool(do_segment_pooling),
+            '_device_scene': {'positions': s['pos'], 'segments': s['segments']}, '_segment_table': (seg_tkeys, seg_tvals, seg_cap),
+        }
+        if not do_segment_pooling:
+            # :98-105: no segment keys; unique_vox_segments stays (the box supervision recomputes it, :131-132)
+            for k in ('seg2vox', 'seg2point'):
+                del item[k]
+            item['input_location'] = vox_world_coords(item)
+            item['pred2point'] = vox2point
+        items.append(item)
+    return items
 
 
 def vox_world_coords(item: dict) -> torch.Tensor:

@@ -29,6 +29,10 @@ int b2m_vox_keys(const double* pos, int64_t n_pts, const double* shift, double v
  * returns the number of distinct keys (or a negative error code). */
 int64_t b2m_unique_insert(const uint64_t* in, int64_t n, uint64_t* tkeys, int64_t cap, int32_t* slot_of,
                           uint64_t* ukeys, int32_t* n_unique, void* stream);
+/* The same without the host read: no synchronisation, the count stays in *n_unique on the device (a caller that prepares several
+ * scenes reads all counts at once: box2mask_amd.prepare.voxelize_scenes). */
+int b2m_unique_insert_async(const uint64_t* in, int64_t n, uint64_t* tkeys, int64_t cap, int32_t* slot_of,
+                          uint64_t* ukeys, int32_t* n_unique, void* stream);
 
 /* In-place ascending bitonic sort of n_pad keys (power of two; pad with 2^64-1). */
 int b2m_sort_u64(uint64_t* keys, int64_t n_pad, void* stream);

@@ -377,3 +377,26 @@ def test_segment_mode_and_oriented_boxes_on_a_large_scene():
     want = R.s3dis_association(sc['positions'], sc['segments'], lab, ref2['unique_vox_segments'], False, True)
     for a, b in zip(got, want):
         assert np.array_equal(a.cpu().numpy(), b)
+
+
+def test_scenes_voxelised_together_equal_one_by_one():
+    """prepare.voxelize_scenes queues every scene's kernels of a stage before the stage's counts come back in ONE copy (two host
+    reads per batch instead of four per scene): every tensor of every item equals voxelize_scene's, bit for bit; a scene with a
+    point out of range or a negative segment id is still refused (dataloader.py:61-123)."""
+    from box2mask_amd import prepare, synth
+    scenes = [synth.make_scene(300 + i, target_voxels=(3000, 9000, 1500)[i], points_only=True) for i in range(3)]
+    together = prepare.voxelize_scenes(scenes, 0.02)
+    for sc, it in zip(scenes, together):
+        one = prepare.voxelize_scene(sc, 0.02)
+        assert set(one) == set(it)
+        for k, v in one.items():
+            if torch.is_tensor(v):
+                assert v.dtype == it[k].dtype and torch.equal(v, it[k]), k
+    bad = dict(scenes[1], segments=np.where(np.arange(len(scenes[1]['segments'])) == 5, -3, scenes[1]['segments']))
+    with pytest.raises(ValueError):
+        prepare.voxelize_scenes([scenes[0], bad], 0.02)
+    far = dict(scenes[0], positions=np.concatenate([scenes[0]['positions'], [[1e9, 0.0, 0.0]]]),
+               colors=np.concatenate([scenes[0]['colors'], [[0.0, 0.0, 0.0]]]), normals=np.concatenate([scenes[0]['normals'], [[0.0, 0.0, 1.0]]]),
+               segments=np.concatenate([scenes[0]['segments'], [0]]))
+    with pytest.raises(ValueError):
+        prepare.voxelize_scenes([far, scenes[2]], 0.02)
