@@ -150,6 +150,9 @@ def main():
     ap.add_argument('--features', default='f32', choices=['f32', 'f16'],
                     help="f16 adds the `inference_f16` object: the batch-size-1 inference leg with the HALF trunk (activations in "
                          "HBM as IEEE half, f16 MFMA, fp32 accumulation; BASELINE configs[4]).  Never the headline, never the default")
+    ap.add_argument('--side-passes', type=int, default=1,
+                    help='0 skips the H2D-inclusive and the read-every-loss repeats of the timed steps (value_incl_h2d / value_sync_per_step '
+                         'become null): the two-rank rehearsal of the test suite')
     ap.add_argument('--workload', default='scannet', choices=['scannet', 's3dis', 'arkit'],
                     help='scannet = BASELINE configs[1] (the headline); s3dis / arkit = configs[4] / [5], own lines under profiles/, '
                          'never the headline')
@@ -314,25 +317,27 @@ def main():
             keep_host = PREFETCH and k in ('vox_coords', 'vox_features')
             batch[k] = pinned[k] if keep_host else pinned[k].to(dev, non_blocking=True)
         return step()
-    if PREFETCH:
-        next_batch[0] = dict(batch, **{k: pinned[k] for k in ('vox_coords', 'vox_features', 'fg_instances')})
-    step_h2d()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t_h = time.perf_counter()
-    for _ in range(args.steps):
+    elapsed_h2d = elapsed_sync = None
+    if args.side_passes:
+        if PREFETCH:
+            next_batch[0] = dict(batch, **{k: pinned[k] for k in ('vox_coords', 'vox_features', 'fg_instances')})
         step_h2d()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed_h2d = time.perf_counter() - t_h
-    if world > 1:
-        t = torch.tensor([elapsed_h2d], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_h2d = float(t.item())
-    batch.update(dev_batch)
-    next_batch[0] = None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_h = time.perf_counter()
+        for _ in range(args.steps):
+            step_h2d()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed_h2d = time.perf_counter() - t_h
+        if world > 1:
+            t = torch.tensor([elapsed_h2d], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_h2d = float(t.item())
+        batch.update(dev_batch)
+        next_batch[0] = None
 
     # ---- the same K steps with every loss read on the host in every iteration, as the reference's loop does
     # (/root/reference/models/training.py:170-174: `.item()` of each entry of the loss dict): the host cannot run ahead
@@ -340,21 +345,22 @@ def main():
     def step_sync():
         ld = step()
         return {k_: (v_.item() if hasattr(v_, 'item') else float(v_)) for k_, v_ in ld.items()}
-    step_sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t_y = time.perf_counter()
-    for _ in range(args.steps):
+    if args.side_passes:
         step_sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed_sync = time.perf_counter() - t_y
-    if world > 1:
-        t = torch.tensor([elapsed_sync], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_sync = float(t.item())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_y = time.perf_counter()
+        for _ in range(args.steps):
+            step_sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed_sync = time.perf_counter() - t_y
+        if world > 1:
+            t = torch.tensor([elapsed_sync], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_sync = float(t.item())
 
     # ---- K more steps, one stream, every conv / BN-apply launch bracketed: the kernels' own durations
     timed_records = timer.records
@@ -505,9 +511,9 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         # the same steps with the batch arriving in pinned host memory (PCIe copy inside the timed region)
-        'value_incl_h2d': round(scenes / elapsed_h2d, 3), 'h2d_mb_per_step': round(h2d_bytes / 1e6, 1),
+        'value_incl_h2d': round(scenes / elapsed_h2d, 3) if elapsed_h2d else None, 'h2d_mb_per_step': round(h2d_bytes / 1e6, 1),
         # every loss `.item()`-ed in every iteration, as training.py:170-174 does (the host cannot run ahead)
-        'value_sync_per_step': round(scenes / elapsed_sync, 3),
+        'value_sync_per_step': round(scenes / elapsed_sync, 3) if elapsed_sync else None,
         # /root/reference/README.md:102 quotes "~48GB GPURAM" for this batch size on MinkowskiEngine
         'peak_mem_gb': round(peak_mem_gb, 2),
         'config': {'workload': workload['name'],
@@ -519,7 +525,7 @@ def main():
                    'prefetch': ('next batch: coordinate + kernel maps on a second stream during the step'
                                 if PREFETCH else 'off'),
                    'collectives': collectives,
-                   'steps_executed': SETUP_STEPS + args.warmup + 4 * args.steps + 3 + (1 if world > 1 else 0)},
+                   'steps_executed': SETUP_STEPS + args.warmup + (4 if args.side_passes else 2) * args.steps + (3 if args.side_passes else 1) + (1 if world > 1 else 0)},
         'roofline': roofline, 'roofline_timed_region': roofline_timed, 'roofline_wgrad': roofline_wgrad,
         # an HBM-bound kernel of the path, same live HIP-event method: BatchNorm apply (+residual, +ReLU) streams
         # 2-3 tensors per launch; small deep-level layers (launch-latency bound) are part of the average

@@ -18,7 +18,7 @@ def test_bench_two_ranks_rehearsal():
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-                        '--batch-size', '2', '--target-voxels', '20000', '--cpu-baseline', '0'],
+                        '--batch-size', '2', '--target-voxels', '20000', '--cpu-baseline', '0', '--side-passes', '0'],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
