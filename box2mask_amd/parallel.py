@@ -94,6 +94,8 @@ class IpcExchange:
         self.epoch += 1
         _lib.call('b2m_xchg_allreduce', t.data_ptr(), t.numel(), self.peers.data_ptr(), self.rank, self.world, self.epoch,
                   t.data_ptr(), self.err.data_ptr())
+        if self.epoch % 4096 == 0:         # (every ~25 training steps: one host read, so that a peer that went away is noticed)
+            self.check()
 
     def check(self):
         """Raises if an exchange gave up waiting for a peer (host read: call it at a step boundary, not per layer)."""
