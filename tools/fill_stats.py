@@ -44,19 +44,29 @@ def hilbert(c, nbits=12):
     return np.argsort(k, kind='stable')
 import os
 ORDER = os.environ.get('ORDER', 'hilbert')             # ORDER=morton: the Z-order of rounds 1-3
-print('row order:', ORDER)
-c = c[hilbert(c) if ORDER == 'hilbert' else morton(c)]
-for lvl in range(4):
-    ts = 1<<lvl
-    nbr = np.asarray(S.kernel_map_same(c, 3, ts))
-    K, N = nbr.shape
-    for T in (64, 128):
-        nt = (N + T - 1)//T
-        pad = nt*T - N
-        v = np.concatenate([nbr >= 0, np.zeros((K,pad),bool)],1).reshape(K, nt, T).sum(2)
-        act = v > 0
-        g = (v + 15)//16
-        print('level', lvl, 'N', N, 'T', T, 'pairs/row %.1f'%(v.sum()/N), 'avg cnt/active %.1f'%v[act].mean(), 'active/tile %.1f'%act.sum(0).mean(),
-              'useful %.3f'%(v.sum()/ (16*g.sum())), 'G hist', np.round(np.bincount(g[act].ravel(), minlength=T//16+1)/act.sum(),2))
-    c = S.stride_coords(c, ts)[0].astype(np.int64)
-    c = c[hilbert(c) if ORDER == 'hilbert' else morton(c)]
+def order_of(c):
+    return hilbert(c) if ORDER == 'hilbert' else morton(c)
+
+
+def main():
+    global c
+    print('row order:', ORDER)
+    c = c[order_of(c)]
+    for lvl in range(4):
+        ts = 1<<lvl
+        nbr = np.asarray(S.kernel_map_same(c, 3, ts))
+        K, N = nbr.shape
+        for T in (64, 128):
+            nt = (N + T - 1)//T
+            pad = nt*T - N
+            v = np.concatenate([nbr >= 0, np.zeros((K,pad),bool)],1).reshape(K, nt, T).sum(2)
+            act = v > 0
+            g = (v + 15)//16
+            print('level', lvl, 'N', N, 'T', T, 'pairs/row %.1f'%(v.sum()/N), 'avg cnt/active %.1f'%v[act].mean(), 'active/tile %.1f'%act.sum(0).mean(),
+                  'useful %.3f'%(v.sum()/ (16*g.sum())), 'G hist', np.round(np.bincount(g[act].ravel(), minlength=T//16+1)/act.sum(),2))
+        c = S.stride_coords(c, ts)[0].astype(np.int64)
+        c = c[hilbert(c) if ORDER == 'hilbert' else morton(c)]
+
+
+if __name__ == '__main__':
+    main()
