@@ -163,7 +163,27 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
     if (lane < a.K) cnt0 = a.rb_cnt[(int64_t)lane * a.ntiles + tile];
     if (lane + 64 < a.K) cnt1 = a.rb_cnt[(int64_t)(lane + 64) * a.ntiles + tile];
     // ---- init the strip: 0 | Y (accumulate) | + bias
-    for (int e = lane; !UP && e < B2M_TILE * (SW / 4); e += 64) {
+    // accumulate (a data gradient added onto the gradient already there): ALL of the tile's rows of Y are requested before the first
+    // one is stored -- round 5; the general loop below waits for its four scalar loads in every one of its 8 / 12 rounds, twelve
+    // dependent memory round trips at the head of the wave
+    constexpr int NIT = B2M_TILE * (SW / 4) / 64;
+    const bool vec_acc = !UP && !F16 && a.accumulate && a.nslice == 1 && a.vec_store && !a.bias && col0 + SW <= a.cout;
+    if (vec_acc) {
+        f32x4 pre[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = lane + 64 * it;
+            const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
+            const int64_t grow = row0 + row;
+            pre[it] = grow < a.n_out ? *(const f32x4*)(a.y + grow * a.ldy + col0 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = lane + 64 * it;
+            *(f32x4*)&Cs[(e / (SW / 4)) * PITCH + (e % (SW / 4)) * 4] = pre[it];
+        }
+    }
+    for (int e = lane; !UP && !vec_acc && e < B2M_TILE * (SW / 4); e += 64) {
         const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int64_t grow = row0 + row;

@@ -53,7 +53,11 @@ for name, rb, K, c1, c2, co in cases:
     fl = 2.0 * P * (c1 + c2) * co
     dy = torch.randn(n_out, co, device='cuda'); dw = torch.zeros_like(w)
     xs = x1 if c2 == 0 else torch.cat([x1, x2], 1)
-    f_fwd = lambda: F_.conv_raw(x1, x2, wp, K, None, rb, n_out, co)
+    if os.environ.get('ACC') == '1':       # the data-gradient form: accumulate onto a tensor that is already there
+        y_acc = torch.randn(n_out, co, device='cuda')
+        f_fwd = lambda: F_.conv_raw(x1, x2, wp, K, None, rb, n_out, co, out=y_acc, accumulate=True)
+    else:
+        f_fwd = lambda: F_.conv_raw(x1, x2, wp, K, None, rb, n_out, co)
     f_wg = lambda: F_.wgrad_raw(xs, dy, rb, K, dw, 0)
 
     def f_both():          # data-gradient-shaped launch and weight gradient side by side on two streams, as in the backward pass
