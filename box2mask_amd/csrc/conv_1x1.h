@@ -88,6 +88,16 @@ __global__ __launch_bounds__(64, SPW == 3 ? 2 : 3) void conv_1x1_kernel(ConvArgs
     for (int g = 0; g < NG; ++g) {
         const int64_t grow = row0 + 16 * g + i;
         if (grow >= a.n_out) continue;
+        // accumulate: the row's old values of ALL column blocks are requested before the first store (round 5: a load behind a
+        // store to the same array cannot be moved in front of it by the compiler -- NB dependent round trips per row group)
+        f32x4 old[NB];
+        if (a.accumulate && a.vec_store) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int col = col0 + 16 * b + 4 * q;
+                old[b] = col + 3 < a.cout ? *(const f32x4*)(a.y + grow * a.ldy + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int col = col0 + 16 * b + 4 * q;
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(64, SPW == 3 ? 2 : 3) void conv_1x1_kernel(ConvArgs
 #pragma unroll
                     for (int u = 0; u < 4; ++u) v[u] += a.bias[col + u];
                 }
-                if (a.accumulate) v += *(const f32x4*)dst;
+                if (a.accumulate) v += old[b];
                 if (a.ep_scale) v = conv_epilogue(a, v, grow, col);
                 *(f32x4*)dst = v;
             } else {
