@@ -487,6 +487,24 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
             const bool chained = WPB == 1 && kC < 128 && kN >= 0 && kN < 128;
             if (!chained) {
             asm volatile("s_nop 15" ::: "memory");        // MFMA result -> VALU read: >= 11 wait states (8-pass MFMA)
+            // scatter form with 32-column strips (registers to spare), accumulate: the old values of ALL row groups are requested
+            // before the first store -- one memory round trip per visit instead of one per row group
+            constexpr bool UPB = UP && TW == 2;
+            f32x4 oldall[UPB ? NG : 1][TW];
+            if constexpr (UPB) {
+                if (a.accumulate) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const uint32_t frow = wC[g] & 0xFFFFFFu;
+                        if (g < GC && frow != 0xFFFFFFu) {
+#pragma unroll
+                            for (int t = 0; t < TW; ++t)
+                                if (col0 + 16 * t + 4 * q + 3 < a.cout)
+                                    oldall[g][t] = *(const f32x4*)(a.y + (int64_t)frow * a.ldy + col0 + 4 * q + 16 * t);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g < GC) {
@@ -499,8 +517,10 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
                             f32x4 old[TW];
                             if (a.accumulate) {
 #pragma unroll
-                                for (int t = 0; t < TW; ++t)
-                                    if (col0 + 16 * t + 4 * q + 3 < a.cout) old[t] = *(const f32x4*)(dst0 + 16 * t);
+                                for (int t = 0; t < TW; ++t) {
+                                    if constexpr (UPB) old[t] = oldall[g][t];
+                                    else if (col0 + 16 * t + 4 * q + 3 < a.cout) old[t] = *(const f32x4*)(dst0 + 16 * t);
+                                }
                             }
 #pragma unroll
                             for (int t = 0; t < TW; ++t) {
