@@ -1028,6 +1028,11 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 B2M_LAUNCH_CHECK();
                 return B2M_OK;
             }
+            if (hl && depth == 2 && dbg == 8 && wpb == 1 && TW == 3) {        // diagnostic: every load, flush and list step, no MFMA
+                conv_fwd_flow_kernel<2, 3, 8, 1, 1><<<fo.grid, 64, 0, st>>>(a);    // (hand-issued loads cannot be optimised away)
+                B2M_LAUNCH_CHECK();
+                return B2M_OK;
+            }
             if (hl && depth == 2 && !dbg) {
                 if (wpb == 4) {
                     if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4, 1><<<fo.grid, 256, 0, st>>>(a);
@@ -1682,7 +1687,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
                 for (int m = 0; m < MI; ++m)
 #pragma unroll
                     for (int nn = 0; nn < NJ; ++nn)
+#ifdef B2M_WGRAD_NOMFMA      // diagnostic build (wrong results): what the loop costs without its MFMAs -- the operands stay consumed
+                        asm volatile("" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
+#else
                         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
+#endif
             }
             asm volatile("" ::: "memory");                       // the refill stays behind the MFMAs that read the registers
             gather(s, tiN, wN[s]);

@@ -19,9 +19,24 @@ def t(n=5):
 for rnd in range(2):
     for name, env in [('old kernel', {'B2M_CONV_PIPE': '0'}), ('flow', {}),
                       ('flow -flush', {'B2M_PIPE_DBG': '1'}), ('flow -gathers', {'B2M_PIPE_DBG': '2'}),
-                      ('flow -weights', {'B2M_PIPE_DBG': '4'}), ('flow -gathers -weights', {'B2M_PIPE_DBG': '6'})]:
-        for k in ('B2M_CONV_PIPE', 'B2M_PIPE_DBG'): os.environ.pop(k, None)
+                      ('flow -weights', {'B2M_PIPE_DBG': '4'}), ('flow -gathers -weights', {'B2M_PIPE_DBG': '6'}),
+                      ('flow compiler loads', {'B2M_CONV_HANDLOADS': '0'}),
+                      ('flow compiler loads -MFMAs', {'B2M_CONV_HANDLOADS': '0', 'B2M_PIPE_DBG': '8'}),
+                      ('flow -MFMAs (loads kept)', {'B2M_PIPE_DBG': '8'})]:
+        for k in ('B2M_CONV_PIPE', 'B2M_PIPE_DBG', 'B2M_CONV_HANDLOADS'): os.environ.pop(k, None)
         os.environ.update(env)
         _lib.reload_env()
         ms = t()
         print('%-26s %.3f ms  %.1f TFLOP/s' % (name, ms, fl / ms / 1e9))
+# the half inference kernel on the same map (a sixteenth of the MFMA cycles, half the bytes)
+for k in ('B2M_CONV_PIPE', 'B2M_PIPE_DBG', 'B2M_CONV_HANDLOADS'): os.environ.pop(k, None)
+_lib.reload_env()
+xh = x.half()
+def th(n=5):
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    F_.conv_affine_h(xh, None, w, rb, rb.n_out); s.record()
+    for _ in range(n): F_.conv_affine_h(xh, None, w, rb, rb.n_out)
+    e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n
+for rnd in range(2):
+    ms = th()
+    print('%-26s %.3f ms  %.1f TFLOP/s' % ('half kernel', ms, fl / ms / 1e9))
