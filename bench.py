@@ -63,7 +63,8 @@ class LaunchTimer:
             # (counted with b2m_conv_fwd; a call the kernel declined -- *ran == 0 -- is followed by b2m_conv_fwd and not recorded)
             meta = dict(cin=args[2] + args[5], cout=args[15], K=args[8], n_out=args[6], rb_cnt=args[12], n_in=args[6],
                         acc=int(args[17]), ran=(meta_in or {}).get('ran'), n_fine=args[16])
-        else:   # b2m_conv_wgrad: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
+        else:   # b2m_conv_wgrad / b2m_conv_wgrad_tr: x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, ...
+            # (_tr: the weight gradient of a transposed map over its DOWN rulebook -- the same pairs, the operands' roles exchanged)
             meta = dict(cin=args[2], cout=args[6], K=args[11], n_out=args[10], rb_cnt=args[9], n_in=args[3])
 
         meta['step'] = self.step_id
@@ -366,7 +367,7 @@ def main():
     timed_records = timer.records
     timer.records = []
     timer._drained = 0
-    timer.names = {'b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_up', 'b2m_conv_wgrad', 'b2m_bn_apply'}
+    timer.names = {'b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_up', 'b2m_conv_wgrad', 'b2m_conv_wgrad_tr', 'b2m_bn_apply'}
     prev_wgrad_stream = os.environ.get('B2M_WGRAD_STREAM')        # (a user-set value is restored afterwards)
     os.environ['B2M_WGRAD_STREAM'] = '0'
     _lib.reload_env()
@@ -409,6 +410,8 @@ def main():
             continue
         if name in ('b2m_conv_fwd_stats', 'b2m_conv_up'):
             name = 'b2m_conv_fwd'
+        if name == 'b2m_conv_wgrad_tr':
+            name = 'b2m_conv_wgrad'
         P = pairs_of(meta, cache, rb_lookup)
         flops = 2.0 * P * meta['cin'] * meta['cout']
         # bytes any implementation moves: both feature matrices once, the weights once, the pair lists

@@ -46,6 +46,7 @@ PROTOTYPES = {
     'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
     'b2m_weight_pack_run': [P, I32, I64, P],
     'b2m_conv_wgrad': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P, P],
+    'b2m_conv_wgrad_tr': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P, P],
     'b2m_bn_stats': [P, I64, I64, I32, P, P, P],
     'b2m_bn_tilestats': [P, I64, I32, P, P, P],
     'b2m_bn_tilestats_finalize': [P, I64, I64, I32, P, P, P, P, F32, F32, P, P, P, P, P, P, P],

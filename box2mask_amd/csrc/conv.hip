@@ -1313,6 +1313,7 @@ struct WgradArgs {
                               // a single block would leave idle take the neighbouring offsets of the same tile chunk
     int kgroups;              // ceil(K / kpack)
     int handloads;            // conv_wgrad_flow_kernel<.., HL = 1> (B2M_WGRAD_HANDLOADS)
+    int swap;                 // b2m_conv_wgrad_tr: x is indexed by the tile's own rows (row0 + rb_out), dy by rb_in
 };
 // work item of a wave -> (offset k, block blk, tile range [t0, t1)); false: nothing to do.  A workgroup is (offset group,
 // block group, tile chunk); its 4 waves are 4 blocks of one offset (kpack = 1) or 4 / kpack blocks of kpack consecutive
@@ -1392,11 +1393,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         for (int s = 0; s < 4; ++s) {
             const int r = rin[s];
             const int64_t ro = row0 + ((o4 >> (8 * s)) & 255);
+            // (b2m_conv_wgrad_tr: x lives on the tile's rows, dy on the rows the pair list names)
+            const int64_t rx = a.swap ? ro : (int64_t)(r < 0 ? 0 : r), ry = a.swap ? (int64_t)(r < 0 ? 0 : r) : ro;
             if (a.fast32) {
                 // complete blocks, tensors below 2^31 bytes: ONE full-rate 24-bit multiply-add per gathered row gives
                 // the byte offset, the sub-tile offsets (64 B apart) become immediates of the loads
-                const uint32_t bx = __umul24((uint32_t)(r < 0 ? 0 : r), ldx4) + cxb;
-                const uint32_t by = __umul24((uint32_t)ro, lddy4) + cyb;
+                const uint32_t bx = __umul24((uint32_t)rx, ldx4) + cxb;
+                const uint32_t by = __umul24((uint32_t)ry, lddy4) + cyb;
                 const char* px = (const char*)a.x + bx;
                 const char* py = (const char*)a.dy + by;
                 if (r >= 0) {
@@ -1414,12 +1417,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int m = 0; m < MI; ++m) {
                     const int ci = ci0 + 16 * m + i;
-                    av[s][m] = (r >= 0 && ci < a.cin) ? a.x[(int64_t)r * a.ldx + ci] : 0.f;
+                    av[s][m] = (r >= 0 && ci < a.cin) ? a.x[rx * a.ldx + ci] : 0.f;
                 }
 #pragma unroll
                 for (int nn = 0; nn < NJ; ++nn) {
                     const int co = co0 + 16 * nn + i;
-                    bv[s][nn] = (r >= 0 && co < a.cout) ? a.dy[ro * a.lddy + co] : 0.f;
+                    bv[s][nn] = (r >= 0 && co < a.cout) ? a.dy[ry * a.lddy + co] : 0.f;
                 }
             }
         }
@@ -1542,7 +1545,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nchun
 //  * the load takes its destination as an IN/OUT operand, so the register is never free (as a plain output it is dead from
 //    its last use on -- and that use, the wait of a k-step without pairs, may have been skipped with the load still in
 //    flight: the next address computation landed in it, a GPU memory fault).
-template <int MI, int NJ, int HL = 0>
+// SWP = 1 (round 5, b2m_conv_wgrad_tr): x lives on the tile's rows, dy on the rows the pair list names -- a variant of its own: as a
+// run-time switch the select cost the 2 x 4 blocks a resident wave (81 VGPRs)
+template <int MI, int NJ, int HL = 0, int SWP = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     static_assert(!HL || (MI >= 2 && NJ >= 2), "hand-issued loads: blocks of 2..4 x 2..4 sub-tiles");
     const int lane = threadIdx.x & 63;
@@ -1620,8 +1625,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
     // operands of k-step s of the slot in tile ti (MI + NJ loads, always)
     auto gather = [&](int s, int ti, uint32_t word) {
         const uint32_t row0 = (uint32_t)((t0 + ti) * B2M_TILE);
-        const uint32_t bx = __umul24(word & 0xFFFFFFu, ldx4) + cxb;
-        const uint32_t by = __umul24(row0 + ((word >> 24) & 63u), lddy4) + cyb;
+        const uint32_t rlist = word & 0xFFFFFFu, rtile = row0 + ((word >> 24) & 63u);
+        const uint32_t bx = __umul24(SWP ? rtile : rlist, ldx4) + cxb;
+        const uint32_t by = __umul24(SWP ? rlist : rtile, lddy4) + cyb;
         const char* px = (const char*)a.x + bx;
         const char* py = (const char*)a.dy + by;
         if constexpr (HL) {
@@ -1823,6 +1829,14 @@ static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& 
             // A/B says so: 128 -> 96 on 1.2 M rows 94.0 against 95.3 TFLOP/s)
             if (a.rb_in && NJ >= 2 && (a.handloads >= 2 || (a.handloads == 1 && MI == NJ && MI >= 3))) {
                 const size_t xl = (size_t)env_flag("B2M_WGRAD_LDS", 0);      // diagnostic: extra LDS per workgroup caps the resident waves
+                if (a.swap) {
+                    switch (NJ) {
+                        case 2: conv_wgrad_flow_kernel<MI, 2, 1, 1><<<grid, 256, xl, st>>>(a); break;
+                        case 3: conv_wgrad_flow_kernel<MI, 3, 1, 1><<<grid, 256, xl, st>>>(a); break;
+                        default: conv_wgrad_flow_kernel<MI, 4, 1, 1><<<grid, 256, xl, st>>>(a); break;
+                    }
+                    return;
+                }
                 switch (NJ) {
                     case 2: conv_wgrad_flow_kernel<MI, 2, 1><<<grid, 256, xl, st>>>(a); break;
                     case 3: conv_wgrad_flow_kernel<MI, 3, 1><<<grid, 256, xl, st>>>(a); break;
@@ -1831,13 +1845,15 @@ static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& 
                 return;
             }
         }
-        switch (NJ) {
-            case 1: conv_wgrad_flow_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
-            case 2: conv_wgrad_flow_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
-            case 3: conv_wgrad_flow_kernel<MI, 3><<<grid, 256, 0, st>>>(a); break;
-            default: conv_wgrad_flow_kernel<MI, 4><<<grid, 256, 0, st>>>(a); break;
+        if (!a.swap) {          // (exchanged row roles exist in the hand-issued form and in the plain kernel below)
+            switch (NJ) {
+                case 1: conv_wgrad_flow_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
+                case 2: conv_wgrad_flow_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
+                case 3: conv_wgrad_flow_kernel<MI, 3><<<grid, 256, 0, st>>>(a); break;
+                default: conv_wgrad_flow_kernel<MI, 4><<<grid, 256, 0, st>>>(a); break;
+            }
+            return;
         }
-        return;
     }
     switch (NJ) {
         case 1: conv_wgrad_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
@@ -1874,19 +1890,42 @@ static int pick_blk(int c) {      // 16-column sub-tiles per wave block
 extern "C" int64_t b2m_conv_wgrad_workspace(int32_t K, int32_t cin, int32_t cout) {
     return (int64_t)B2M_WGRAD_DET_CHUNKS * K * cin * cout;
 }
+static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
+                           int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                           int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace,
+                           void* stream, int tr);
 extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
                               int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                               int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace,
                               void* stream) {
+    return conv_wgrad_impl(x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, dw, lddw, dw_kstride, workspace, stream, 0);
+}
+// The same reduction with the roles of the rulebook's two row numbers EXCHANGED: dW[k][ci][co] += sum x[tile*TILE + rb_out][ci] *
+// dy[rb_in][co] -- x has n_out rows (the rulebook's tiles), dy n_in rows.  What it is for: the weight gradient of a TRANSPOSED
+// k2s2 map over the map's DOWN rulebook (x = the layer's coarse input rows, dy = the gradient of its fine output rows): tiled over
+// the coarse rows an offset of a tile has up to 64 pairs, tiled over the fine rows ~8 -- half-empty 16-pair slots, two k-steps each
+// (35 TFLOP/s on the benchmark's level-1 / level-2 maps).
+extern "C" int b2m_conv_wgrad_tr(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
+                                 int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                                 int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace,
+                                 void* stream) {
+    return conv_wgrad_impl(x, ldx, cin, n_in, dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, dw, lddw, dw_kstride, workspace, stream, 1);
+}
+static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
+                           int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                           int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace,
+                           void* stream, int tr) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(x && dy && dw && cin > 0 && cout > 0 && K >= 1 && K <= 65535 && n_in >= 0, "bad pointers/sizes");
     B2M_CHECK_ARG((rb_in == nullptr) == (rb_out == nullptr) && (rb_in == nullptr) == (rb_cnt == nullptr),
                   "rulebook pointers must be all set or all NULL");
     B2M_CHECK_ARG(rb_in != nullptr || K == 1, "identity rulebook needs K == 1");
+    B2M_CHECK_ARG(!tr || rb_in != nullptr, "b2m_conv_wgrad_tr needs a rulebook");
     B2M_CHECK_ARG(ldx >= cin && lddy >= cout && lddw >= cout && dw_kstride >= (int64_t)cin * lddw,
                   "leading dimension too small");
     if (n_out == 0) return B2M_OK;
     WgradArgs a;
+    a.swap = tr;
     a.x = x; a.ldx = ldx; a.cin = cin; a.dy = dy; a.lddy = lddy; a.cout = cout;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE); a.K = K; a.dw = dw; a.lddw = lddw; a.dw_kstride = dw_kstride;
@@ -1894,7 +1933,7 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     if (!zeros_addr) B2M_HIP(hipGetSymbolAddress((void**)&zeros_addr, HIP_SYMBOL(g_zeros)));
     a.zeros = zeros_addr;
     // 1x1 layer with few output channels (the heads' last layers): a plain reduction, see wgrad_narrow_kernel
-    if (rb_in == nullptr && cout <= 32 && cout % 16 != 0 && cin <= 1024 && !workspace && n_in >= n_out && env_flag("B2M_WGRAD_NARROW", 1)) {
+    if (!tr && rb_in == nullptr && cout <= 32 && cout % 16 != 0 && cin <= 1024 && !workspace && n_in >= n_out && env_flag("B2M_WGRAD_NARROW", 1)) {
         const unsigned g = (unsigned)cdiv64(n_out, WGN_ROWS);
         if (cout <= 4) wgrad_narrow_kernel<4><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
         else if (cout <= 8) wgrad_narrow_kernel<8><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
@@ -1950,8 +1989,10 @@ extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t 
     // 24-bit multiply operands and 32-bit byte offsets: rows < 2^24, row pitch < 2^22 floats, tensors < 4 GiB
     // (blocks may overhang cin/cout as long as the row PITCH covers them: the extra columns only feed dW rows /
     // columns that are never written)
+    // (b2m_conv_wgrad_tr: x has the n_out rows of the tiles, dy the n_in rows the pair lists name)
+    const int64_t nx = tr ? n_out : n_in, ny = tr ? n_in : n_out;
     a.fast32 = (ldx >= (int64_t)a.nmb * 16 * MI && lddy >= (int64_t)a.nnb * 16 * NJ && n_out < (1 << 24) && n_in < (1 << 24) &&
-                ldx < (1 << 22) && lddy < (1 << 22) && n_out * lddy * 4 < (1ll << 32) && n_in * ldx * 4 < (1ll << 32) &&
+                ldx < (1 << 22) && lddy < (1 << 22) && ny * lddy * 4 < (1ll << 32) && nx * ldx * 4 < (1ll << 32) &&
                 env_flag("B2M_WGRAD_FAST32", 1)) ? 1 : 0;
     // The flat-pipeline kernel for real rulebooks and 32-bit addressable operands.  Its MFMAs are asm statements the
     // compiler's hazard recogniser cannot see: a block with a single accumulator (MI = NJ = 1: consecutive MFMAs on the

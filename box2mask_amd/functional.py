@@ -367,8 +367,24 @@ def wgrad_raw(x, dy, rb: Rulebook | None, K: int, dw3, ci0: int, cin: int | None
     else:
         rbi, rbo, rbc = rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr()
     ws = _wgrad_workspace(K, cin, cout, x.device) if deterministic() else None
+    sc = rb.scatter if rb is not None else None
+    if sc is not None and n_out > 0 and x.shape[0] > 0 and wgrad_up_over_down_map():
+        # a transposed k2s2 map: the same pairs through the map's DOWN rulebook (tiled over the coarse rows: up to 64 pairs per
+        # (tile, offset), where the UP rulebook has ~8 in half-empty 16-pair slots) with the roles of its two row numbers
+        # exchanged -- x lives on the tiles' own (coarse) rows, dy on the fine rows the pair lists name
+        assert sc.K == K and sc.n_out == x.shape[0]
+        _call('b2m_conv_wgrad_tr', x.data_ptr(), x.stride(0), cin, n_out, dy.data_ptr(), dy.stride(0), cout,
+              sc.rb_in.data_ptr(), sc.rb_out.data_ptr(), sc.rb_cnt.data_ptr(), x.shape[0], K,
+              dw3.data_ptr() + 4 * ci0 * cout, cout, cin_total * cout, _ptr(ws))
+        return
     _call('b2m_conv_wgrad', x.data_ptr(), x.stride(0), cin, x.shape[0], dy.data_ptr(), dy.stride(0), cout, rbi, rbo, rbc,
           n_out, K, dw3.data_ptr() + 4 * ci0 * cout, cout, cin_total * cout, _ptr(ws))
+
+
+def wgrad_up_over_down_map() -> bool:
+    """B2M_WGRAD_UP=0: the weight gradient of a transposed k2s2 map walks the UP rulebook (b2m_conv_wgrad) instead of the DOWN
+    rulebook with exchanged roles (b2m_conv_wgrad_tr)."""
+    return os.environ.get('B2M_WGRAD_UP', '1') == '1'
 
 
 # ---- weight gradients on a second stream

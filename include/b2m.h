@@ -263,6 +263,15 @@ int64_t b2m_conv_wgrad_workspace(int32_t K, int32_t cin, int32_t cout);
 int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy, int32_t cout,
                    const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                    int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace, void* stream);
+/* The same reduction with the roles of the rulebook's two row numbers EXCHANGED:
+ *   dW[k][ci][co] += sum over pairs of offset k:  X[tile*TILE + rb_out, ci] * dY[rb_in, co]
+ * x has n_out rows (the rows the rulebook is tiled over), dy n_in rows.  Weight gradient of a TRANSPOSED k2s2 map over the map's
+ * DOWN rulebook (x = the layer's coarse input rows, dy = the gradient of its fine output rows): up to 64 pairs per (tile, offset)
+ * where the UP rulebook has ~8 in half-empty 16-pair slots.  Replaces [ME] ConvolutionTransposeBackward (weight part),
+ * /root/reference/models/detection_net.py:96-133 (the decoder's MinkowskiConvolutionTranspose layers). */
+int b2m_conv_wgrad_tr(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy, int32_t cout,
+                   const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                   int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------- SyncBN statistics exchange inside one node (opt-in)
  * Device-side all-reduce (SUM) of n <= b2m_xchg_max_doubles() doubles between <= b2m_xchg_max_ranks() ranks whose MAILBOXES

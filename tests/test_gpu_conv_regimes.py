@@ -48,6 +48,7 @@ REGIMES = {
     'wgrad_plain': {'B2M_WGRAD_PIPE': '0'},
     'wgrad_compiler_tracked_loads': {'B2M_WGRAD_HANDLOADS': '0'},
     'wgrad_hand_issued_loads_square_blocks_only': {'B2M_WGRAD_HANDLOADS': '1'},
+    'wgrad_of_transposed_maps_over_the_up_rulebook': {'B2M_WGRAD_UP': '0'},     # (default: b2m_conv_wgrad_tr over the DOWN rulebook)
     'wgrad_64_tile_chunks': {'B2M_WGRAD_MIN_TILES': '64'},
     'wgrad_one_offset_per_workgroup': {'B2M_WGRAD_KPACK': '0'},
     'no_xcd_order': {'B2M_XCD': '0'},
@@ -80,7 +81,8 @@ REGIME_CASES = {
     'unsplit': _ALL, 'unsplit_compiler_tracked_loads': _ALL,
     'split_compiler_tracked_loads': _SPLIT, 'unsplit_32_column_strips': [1, 2, 4, 8, 9], 'atomic_combine': _SPLIT,
     'no_chunk_slices': _SPLIT, 'many_slices': _SPLIT, 'wgrad_plain': _WGRAD, 'wgrad_compiler_tracked_loads': _WGRAD,
-    'wgrad_hand_issued_loads_square_blocks_only': _WGRAD, 'wgrad_64_tile_chunks': _WGRAD, 'wgrad_one_offset_per_workgroup': [0, 5, 6],
+    'wgrad_hand_issued_loads_square_blocks_only': _WGRAD, 'wgrad_64_tile_chunks': _WGRAD,
+    'wgrad_of_transposed_maps_over_the_up_rulebook': [8, 9], 'wgrad_one_offset_per_workgroup': [0, 5, 6],
     'no_xcd_order': _ORDER, 'xcd_equal_tile_counts': _ORDER, 'unsplit_64bit': _ALL,
 }
 

@@ -18,6 +18,7 @@ m = CoordinateManager(b['vox_coords'], reorder=True)      # Morton rows, as the 
 rb0 = m.rulebook_same(0, 3); m.ensure_level(7); rb1 = m.rulebook_same(1, 3); rbu = m.rulebook_up(0); rb5 = m.rulebook_same(0, 5)
 rb2 = m.rulebook_same(2, 3); rb3 = m.rulebook_same(3, 3); rb4 = m.rulebook_same(4, 3)
 rb5l = m.rulebook_same(5, 3); rb6 = m.rulebook_same(6, 3)
+rbu1 = m.rulebook_up(1); rbu2 = m.rulebook_up(2); rbu3 = m.rulebook_up(3)
 torch.cuda.synchronize()
 print('N0', m.n(0), 'pairs k3', rb0.pairs, 'k5', rb5.pairs)
 
@@ -35,13 +36,14 @@ for spec in os.environ.get('VARIANTS', 'tw2:B2M_CONV_TW3=0;slow64:B2M_WGRAD_FAST
     if spec:
         name, kvs = spec.split(':')
         VARIANTS.append((name, dict(kv.split('=') for kv in kvs.split(','))))
-SWITCHES = ('B2M_WGRAD_LDS', 'B2M_CONV_CHAIN', 'B2M_WGRAD_HANDLOADS', 'B2M_CONV_HANDLOADS', 'B2M_PIPE_DBG', 'B2M_CONV_UP', 'B2M_CONV_UP_MIN_ITEMS', 'B2M_CONV_STEM', 'B2M_WGRAD_NARROW', 'B2M_WGRAD_PIPE_IDENT', 'B2M_WGRAD_KPACK', 'B2M_CONV_1X1', 'B2M_XCD_ORDER', 'B2M_XCD_BALANCE', 'B2M_CONV_FLOW_SPLIT', 'B2M_CONV_PIPE', 'B2M_CONV_TW3', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_CONV_MAXSLICE')
+SWITCHES = ('B2M_WGRAD_UP', 'B2M_WGRAD_LDS', 'B2M_CONV_CHAIN', 'B2M_WGRAD_HANDLOADS', 'B2M_CONV_HANDLOADS', 'B2M_PIPE_DBG', 'B2M_CONV_UP', 'B2M_CONV_UP_MIN_ITEMS', 'B2M_CONV_STEM', 'B2M_WGRAD_NARROW', 'B2M_WGRAD_PIPE_IDENT', 'B2M_WGRAD_KPACK', 'B2M_CONV_1X1', 'B2M_XCD_ORDER', 'B2M_XCD_BALANCE', 'B2M_CONV_FLOW_SPLIT', 'B2M_CONV_PIPE', 'B2M_CONV_TW3', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_CONV_MAXSLICE')
 cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
          ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L1 k3 32->32', rb1, 27, 32, 0, 32), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
          ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64),
          ('L2 k3 128->128', rb2, 27, 128, 0, 128), ('L2 k3 64->64', rb2, 27, 64, 0, 64), ('L3 k3 256->256', rb3, 27, 256, 0, 256),
          ('L3 k3 128->128', rb3, 27, 128, 0, 128), ('L4 k3 256->256', rb4, 27, 256, 0, 256),
-         ('L5 k3 256->256', rb5l, 27, 256, 0, 256), ('L6 k3 256->256', rb6, 27, 256, 0, 256)]
+         ('L5 k3 256->256', rb5l, 27, 256, 0, 256), ('L6 k3 256->256', rb6, 27, 256, 0, 256),
+         ('L1 up 128->96', rbu1, 8, 128, 0, 96), ('L2 up 256->128', rbu2, 8, 256, 0, 128), ('L3 up 256->256', rbu3, 8, 256, 0, 256)]
 if os.environ.get('CASES'):
     cases = [c for c in cases if any(c[0].startswith(p) for p in os.environ['CASES'].split(','))]
 for name, rb, K, c1, c2, co in cases:
