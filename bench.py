@@ -878,6 +878,33 @@ def _inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=1
         once(masks=False)
     torch.cuda.synchronize()
     dt_fwd = (time.perf_counter() - t0) / reps
+    # The same loop as an evaluation script with its data loader one scene ahead would run it: the forward pass is enqueued
+    # (its outputs stay on the device), the NEXT scene's coordinate hash and kernel maps are built on a second stream while it runs
+    # (Model.prefetch: their host reads wait for that stream only), then the outputs come to the host and the masks are made.
+    dt_pf = dt_fwd_pf = None
+    if not half:
+        def once_ahead(masks=with_masks):
+            pred = model.get_prediction(batch, with_grad=False, to_cpu=False, min_size=True)     # (takes the maps prefetched for it)
+            model.prefetch(batch, ready=True, loss_rows=False)  # the next scene -- here the same one again -- beside this forward pass
+            if not with_masks:
+                return pred
+            pred = {k: v.cpu() for k, v in pred.items()}        # the outputs come to the host as in evaluation.py:86
+            return model.pred2mask(cpu_batch, votes, 'eval') if masks else pred
+        model.prefetch(batch, ready=True, loss_rows=False)
+        for _ in range(3):
+            once_ahead()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once_ahead()
+        torch.cuda.synchronize()
+        dt_pf = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once_ahead(masks=False)
+        torch.cuda.synchronize()
+        dt_fwd_pf = (time.perf_counter() - t0) / reps
+        model._take_prefetched(batch)           # (drop the last one: the passes below build their own maps)
     # roofline of the forward pass's convolutions (own pass: the events serialise the stream)
     rec, launches = [], {}
 
@@ -940,6 +967,13 @@ def _inference_leg(model, dev, cfg, target_voxels, cpu_result, rb_lookup, reps=1
                         'kernel': 'b2m_conv_fwd_affine (conv_fwd_flow_kernel / conv_1x1_kernel / conv_stem_kernel with the '
                                   'BatchNorm epilogue) + b2m_conv_fwd (heads)',
                         'launches': len(rec), 'ms': round(ms, 3), 'gflop': round(flops / 1e9, 2)}}
+    if dt_pf is not None:
+        out['next_scene_prefetched'] = {
+            'value': round(n_scenes / dt_pf, 3), 'unit': 'scenes/s', 'ms_per_scene': round(dt_pf * 1e3 / n_scenes, 3),
+            'ms_forward': round(dt_fwd_pf * 1e3, 3),
+            'flow': 'the same loop with Model.prefetch(next scene) called right behind the enqueued forward pass: the next scene\'s '
+                    'coordinate hash, strided maps and kernel maps are built on a second stream while this scene\'s network runs '
+                    '(an evaluation script whose data loader is one scene ahead); same outputs (tests/test_gpu_inference.py)'}
     if half:
         tf_h = flops_h / max(ms_h, 1e-9) / 1e9
         out['features'] = 'f16 (trunk activations and weights IEEE half in HBM, v_mfma_f32_16x16x32_f16 / 16x16x16_f16, fp32 ' \

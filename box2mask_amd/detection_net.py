@@ -391,15 +391,18 @@ class SelectionNet(ResNetBase):
         return results
 
     # ------------------------------------------------------------------ prediction
-    def get_prediction(self, batch, with_grad=True, to_cpu=False, to_numpy=False, min_size=True):
-        """detection_net.py:493-517."""
+    def get_prediction(self, batch, with_grad=True, to_cpu=False, to_numpy=False, min_size=True, sin=None):
+        """detection_net.py:493-517.  `sin`: the batch's sparse tensor if the caller holds it already (Model.prefetch built it
+        on a second stream, one scene ahead of the evaluation loop) -- same maps, same outputs."""
         n_seg = batch['input_location'].shape[0] if self.cfg.do_segment_pooling else None
         if not with_grad:
             with torch.no_grad():
-                sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=self.device)
+                if sin is None:
+                    sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=self.device)
                 pred = self(sin, batch['pooling_ids'].to(self.device), n_seg)
         else:
-            sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=self.device)
+            if sin is None:
+                sin = ME.SparseTensor(batch['vox_features'], batch['vox_coords'], device=self.device)
             pred = self(sin, batch['pooling_ids'].to(self.device), n_seg)
         for mlp_head, sparse_tensor in pred.items():
             pred[mlp_head] = sparse_tensor.F if not to_cpu else sparse_tensor.F.cpu()

@@ -92,7 +92,7 @@ class Model:
         c, f = batch['vox_coords'], batch['vox_features']
         return (id(c), c.data_ptr(), tuple(c.shape), id(f), f.data_ptr())
 
-    def prefetch(self, batch, ready=None):
+    def prefetch(self, batch, ready=None, loss_rows=True):
         """Build the ME.SparseTensor of `batch` -- Morton order, coordinate hash, the 7 strided coordinate maps, the 16
         kernel maps and their rulebooks -- NOW, on a second stream, and hand it to the next `compute_loss(batch, ...)`.
         Called right after `optimizer.step()` for the batch the data loader already holds, the ~2 ms of map kernels and
@@ -105,7 +105,9 @@ class Model:
         stream so far (always safe, but the side stream then starts only when the current step has finished -- only the
         host reads move); a torch.cuda.Event recorded after they were written; True = they are complete already (host
         tensors, or device tensors made before the current step was enqueued) -- the maps are then built WHILE the
-        current step runs."""
+        current step runs.
+        Inference (evaluation.py:70-98): the same call one scene ahead of Model.get_prediction -- `loss_rows=False` skips the
+        foreground row list only the loss terms read."""
         if self._pf_stream is None:
             self._pf_stream = torch.cuda.Stream(device=self.device)
         side = self._pf_stream
@@ -118,7 +120,7 @@ class Model:
             if sin.manager is not None:
                 sin.manager.prefetch(8, same=[(0, 5)] + [(l, 3) for l in range(8)], strided=True)
             fg_rows = None                                     # the loss terms' foreground row list (a host read too)
-            if 'fg_instances' in batch and (self.cfg.loss_on_fg_instances or self.cfg.bb_supervision):
+            if loss_rows and 'fg_instances' in batch and (self.cfg.loss_on_fg_instances or self.cfg.bb_supervision):
                 fg_rows = torch.nonzero(batch['fg_instances'].to(self.device)).reshape(-1)
         self._prefetched = (self._batch_key(batch), sin, fg_rows)
 
@@ -297,7 +299,9 @@ class Model:
         return out
 
     def get_prediction(self, batch, with_grad=False, to_cpu=True, min_size=True, get_all=False):
-        return self.detection_model.get_prediction(batch, with_grad=with_grad, to_cpu=to_cpu, min_size=min_size)
+        # (an evaluation loop that called Model.prefetch(batch) one scene ahead: the maps are there already)
+        sin, _ = self._take_prefetched(batch) if self._prefetched is not None else (None, None)
+        return self.detection_model.get_prediction(batch, with_grad=with_grad, to_cpu=to_cpu, min_size=min_size, sin=sin)
 
     def pred2mask(self, batch, pred, mode):
         return self.detection_model.detection2mask(batch, pred, self.cfg, mode, True, *self.cfg.eval_ths)

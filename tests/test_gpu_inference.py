@@ -157,6 +157,25 @@ def test_inference_fused_equals_unfused_and_oracle(monkeypatch):
         assert e < 1e-3, (h, e)
 
 
+def test_next_scene_prefetched_gives_the_same_outputs(monkeypatch):
+    """An evaluation loop one scene ahead: Model.prefetch(scene) builds the scene's sparse tensor and every map on a second stream,
+    Model.get_prediction(scene) takes them -- the same outputs, bit for bit, as the pass that builds its maps itself, and a
+    prefetch made for ANOTHER scene is not taken (evaluation.py:70-98 with a data loader that runs ahead)."""
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    model, batch, cfg = _model_and_batch()
+    other = _model_and_batch(n_vox=5000, bs=1, seed=9)[1]
+    plain = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=True)
+    model.prefetch(batch, ready=True, loss_rows=False)
+    assert model._prefetched is not None
+    ahead = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=True)
+    assert model._prefetched is None                       # consumed
+    model.prefetch(other, ready=True, loss_rows=False)     # a scene the next call is NOT about
+    again = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=True)
+    for h in cfg.network_heads:
+        assert torch.equal(plain[h], ahead[h]), h
+        assert torch.equal(plain[h], again[h]), h
+
+
 def test_eval_affine_cache_follows_the_parameters():
     """The cached (scale, shift) of a layer is rebuilt after load_state_dict / an in-place change of the statistics."""
     from box2mask_amd import nn as ME
