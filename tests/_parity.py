@@ -100,10 +100,13 @@ class MaskRecorder:
         self.to_gpu = to_gpu
         return it
 
-    # bounds on the borderline decisions (see `masked`): at most 1e-3 of a layer's elements, each within 1e-4 of the layer's
-    # rms of zero -- the device forward agrees with the fp64 oracle to ~1e-5 of a tensor's maximum (a few 1e-5 of its rms)
+    # bounds on the borderline decisions (see `masked`): at most 1e-3 of a layer's elements, each within 3e-4 of the layer's
+    # rms of zero -- the device forward agrees with the fp64 oracle to ~1e-5 of a tensor's maximum (a few 1e-5 of its rms); the
+    # largest such element is a maximum over ~1e7 elements of a default-mode pass (atomics: it moves from run to run --
+    # 2e-6 ... 5e-5 in most runs, 1.1e-4 once in a dozen at layer 56 of 79, which a bound of 1e-4 turned into a failure of the
+    # whole GPU suite).  A kernel that decides `y > 0` wrongly disagrees at |x| ~ rms, four orders of magnitude from here.
     max_flip_fraction = 1e-3
-    max_flip_preact = 1e-4
+    max_flip_preact = 3e-4
 
     def summary(self):
         """(largest disagreeing fraction, largest |x| / rms of a disagreeing element) over the replayed ReLUs."""
