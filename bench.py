@@ -686,7 +686,8 @@ def spawn_ranks(n):
 
 
 KERNEL_OF = {'nmc_batch': 'nmc_batch_kernel', 'mask_project': 'mask_project_batch_kernel', 'mask_nms': 'mask_inter_batch_kernel',
-             'label_hist': 'label_hist_batch_kernel', 'mask_gather': 'mask_gather_batch_kernel'}
+             'label_hist': 'label_hist_batch_kernel', 'mask_gather': 'mask_gather_batch_kernel',
+             'mask_gather_t': 'mask_gather_t_batch_kernel'}
 
 
 def synthetic_votes(batch, cfg, seed=7):
@@ -734,7 +735,7 @@ def votes_leg(model, batch, cfg, cpu, pmc=None, pmc_src=None):
 
     def hook(name, a, meta_in=None):
         if name not in ('b2m_nmc_batch', 'b2m_mask_project_batch', 'b2m_mask_nms_batch', 'b2m_label_hist_batch',
-                        'b2m_mask_gather_batch'):
+                        'b2m_mask_gather_batch', 'b2m_mask_gather_batch_t'):
             return None
         s_ = torch.cuda.Event(enable_timing=True); e_ = torch.cuda.Event(enable_timing=True)
         s_.record()

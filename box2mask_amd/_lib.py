@@ -79,6 +79,7 @@ PROTOTYPES = {
     'b2m_mask_nms_batch': [P, I32, I32, F32, P],
     'b2m_label_hist_batch': [P, I32, I64, I32, P],
     'b2m_mask_gather_batch': [P, I32, I64, I64, P],
+    'b2m_mask_gather_batch_t': [P, I32, I64, I64, I64, P, P],
     'b2m_mask_hist': [P, I64, I32, P, I64, I32, P, P],
     'b2m_mask_pack': [P, I32, I64, P, I64, P],
     'b2m_set_ious': [P, P, I64, P, P],

@@ -5,6 +5,8 @@ detection2mask 369-488, get_prediction 493-521).  All sparse arithmetic runs in 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -355,9 +357,21 @@ class SelectionNet(ResNetBase):
                                idx_ptr, n_pts, out.data_ptr())
             desc[s_, 19] = row0
             row0 += kk
-        desc_dev = torch.from_numpy(desc).to(dev)
+        # (the scenes' voxel-major scratch images of b2m_mask_gather_batch_t ride behind the table: one upload)
+        nws = [(kk + 63) // 64 for kk in kks]
+        tb_all = torch.empty(max(sum(d['n_vox'] * nw for d, nw in zip(sc, nws)), 1), dtype=torch.int64, device=dev)
+        tb_ptrs = np.zeros(S, np.int64)
+        toff = 0
+        for s_, (d, nw) in enumerate(zip(sc, nws)):
+            tb_ptrs[s_] = tb_all.data_ptr() + 8 * toff
+            toff += d['n_vox'] * nw
+        desc_dev = torch.from_numpy(np.concatenate([desc.reshape(-1), tb_ptrs])).to(dev)
         _call('b2m_label_hist_batch', desc_dev.data_ptr(), S, total_kept, n_class)
-        _call('b2m_mask_gather_batch', desc_dev.data_ptr(), S, total_kept, max(int(o_.shape[1]) for o_ in outs))
+        if os.environ.get('B2M_MASK_GATHER_T', '1') == '1':
+            _call('b2m_mask_gather_batch_t', desc_dev.data_ptr(), S, total_kept, max(int(o_.shape[1]) for o_ in outs),
+                  max(d['words'] for d in sc), desc_dev.data_ptr() + 8 * S * 20)
+        else:
+            _call('b2m_mask_gather_batch', desc_dev.data_ptr(), S, total_kept, max(int(o_.shape[1]) for o_ in outs))
         labels_host = labels_all[:total_kept].cpu().numpy().astype('int32')
         # bytes every implementation of the four stages moves (for bench.py's roofline of the leg; nothing on the path reads it)
         self._d2m_bytes = {
@@ -366,6 +380,7 @@ class SelectionNet(ResNetBase):
             'b2m_label_hist_batch': float(sum(8 * kk * d['words'] + 4 * d['n_vox'] for d, kk in zip(sc, kks))),
             'b2m_mask_gather_batch': float(sum(8 * kk * d['words'] + 8 * o_.shape[1] + kk * o_.shape[1] for d, kk, o_ in zip(sc, kks, outs))),
         }
+        self._d2m_bytes['b2m_mask_gather_batch_t'] = self._d2m_bytes['b2m_mask_gather_batch']      # (the same operands, every one once)
         results = {}
         o = 0
         for d, r, out in zip(sc, rs, outs):

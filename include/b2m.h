@@ -514,6 +514,12 @@ int b2m_mask_project_batch(const int64_t* desc, int32_t n_scenes, int64_t total_
 int b2m_mask_nms_batch(const int64_t* desc, int32_t n_scenes, int32_t max_k, float mask_nms_th, void* stream);
 int b2m_label_hist_batch(const int64_t* desc, int32_t n_scenes, int64_t total_kept, int32_t n_class, void* stream);
 int b2m_mask_gather_batch(const int64_t* desc, int32_t n_scenes, int64_t total_kept, int64_t max_pts, void* stream);
+/* b2m_mask_gather_batch through a voxel-major image of the kept rows, built here first: `tbits` = device array of n_scenes
+ * pointers, scene s -> n_vox x ceil(kk / 64) uint64 words of scratch (word c of voxel v: the bits of kept rows 64c .. 64c + 63 at
+ * v).  One 8-byte look-up per point and 64 rows instead of one per point and row; the same bytes in `out`.  max_words = the
+ * largest `words` of the table. */
+int b2m_mask_gather_batch_t(const int64_t* desc, int32_t n_scenes, int64_t total_kept, int64_t max_pts, int64_t max_words,
+                            const int64_t* tbits, void* stream);
 
 #ifdef __cplusplus
 }

@@ -296,6 +296,54 @@ def test_detection2mask_batch_stages_with_an_empty_scene_against_oracle():
     assert total > 10
 
 
+def test_mask_gather_through_the_voxel_major_image_equals_the_row_lookups():
+    """b2m_mask_gather_batch_t (the kept rows transposed into one word per voxel and 64 rows, then one look-up per point) against
+    b2m_mask_gather_batch (one look-up per point and row) on a hand-made table: 150 kept rows of 200 (three words per voxel, a
+    row subset in scrambled order) with a point count that is not a multiple of 16, a scene without kept rows in the middle, a
+    scene with the identity index (training mode) and a 16-aligned one that takes the 16-byte stores."""
+    from box2mask_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    dev = 'cuda:0'
+    scenes = [dict(n_vox=1000, ksel=200, kk=150, n_pts=4099, ident=False), dict(n_vox=300, ksel=4, kk=0, n_pts=640, ident=False),
+              dict(n_vox=777, ksel=9, kk=5, n_pts=777, ident=True), dict(n_vox=2048, ksel=70, kk=65, n_pts=8192, ident=False)]
+    keep = []
+    desc = np.zeros((len(scenes), 20), np.int64)
+    for s_, sc in enumerate(scenes):
+        words = (sc['n_vox'] + 63) // 64
+        bits = torch.randint(-2**62, 2**62, (sc['ksel'], words), generator=g, dtype=torch.int64).to(dev)
+        rows = torch.randperm(sc['ksel'], generator=g)[:sc['kk']].int().to(dev)
+        index = None if sc['ident'] else torch.randint(0, sc['n_vox'], (sc['n_pts'],), generator=g, dtype=torch.int64).to(dev)
+        outs = [torch.full((max(sc['kk'], 1), sc['n_pts']), 7, dtype=torch.uint8, device=dev) for _ in range(2)]
+        tb = torch.empty(max(sc['n_vox'] * ((sc['kk'] + 63) // 64), 1), dtype=torch.int64, device=dev)
+        keep.append((bits, rows, index, outs, tb))
+        desc[s_, 6:9] = (sc['n_vox'], bits.data_ptr(), words)
+        desc[s_, 11:13] = (rows.data_ptr() if sc['kk'] else 0, sc['kk'])
+        desc[s_, 15:17] = (0 if index is None else index.data_ptr(), sc['n_pts'])
+    total = sum(sc['kk'] for sc in scenes)
+    for which, name in ((0, 'b2m_mask_gather_batch'), (1, 'b2m_mask_gather_batch_t')):
+        for s_ in range(len(scenes)):
+            desc[s_, 17] = keep[s_][3][which].data_ptr()
+        table = np.concatenate([desc.reshape(-1), np.array([k[4].data_ptr() for k in keep], np.int64)])
+        d_dev = torch.from_numpy(table).to(dev)
+        if which:
+            _lib.call(name, d_dev.data_ptr(), len(scenes), total, max(sc['n_pts'] for sc in scenes),
+                      max((sc['n_vox'] + 63) // 64 for sc in scenes), d_dev.data_ptr() + 8 * 20 * len(scenes))
+        else:
+            _lib.call(name, d_dev.data_ptr(), len(scenes), total, max(sc['n_pts'] for sc in scenes))
+        torch.cuda.synchronize()
+    for s_, sc in enumerate(scenes):
+        a, b = keep[s_][3]
+        if sc['kk'] == 0:
+            assert int((a != 7).sum()) == 0 and int((b != 7).sum()) == 0          # nothing written
+            continue
+        assert torch.equal(a, b), s_
+        # ... and both are the definition: bit (index[p]) of kept row r
+        bits, rows, index = keep[s_][0].cpu().numpy().view(np.uint64), keep[s_][1].cpu().numpy(), keep[s_][2]
+        v = np.arange(sc['n_pts']) if index is None else index.cpu().numpy()
+        ref = ((bits[rows][:, v >> 6] >> (v & 63).astype(np.uint64)) & np.uint64(1)).astype(np.uint8)
+        assert np.array_equal(ref, a.cpu().numpy()), s_
+
+
 def test_unique_insert_few_distinct_keys_and_mixed_waves():
     """b2m_unique_insert through prepare._unique_inverse against np.unique: ground-truth-id-like input (1 M keys, 30 values,
     long runs and random order: the wave-level election path), all-distinct keys (the per-lane path) and waves that mix both."""
