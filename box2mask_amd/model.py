@@ -300,7 +300,9 @@ class Model:
 
     def get_prediction(self, batch, with_grad=False, to_cpu=True, min_size=True, get_all=False):
         # (an evaluation loop that called Model.prefetch(batch) one scene ahead: the maps are there already)
-        sin, _ = self._take_prefetched(batch) if self._prefetched is not None else (None, None)
+        # (one made for ANOTHER batch -- the training loop's next step, with a validation pass in between -- stays where it is)
+        mine = self._prefetched is not None and self._prefetched[0] == self._batch_key(batch)
+        sin, _ = self._take_prefetched(batch) if mine else (None, None)
         return self.detection_model.get_prediction(batch, with_grad=with_grad, to_cpu=to_cpu, min_size=min_size, sin=sin)
 
     def pred2mask(self, batch, pred, mode):

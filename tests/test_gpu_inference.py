@@ -171,6 +171,9 @@ def test_next_scene_prefetched_gives_the_same_outputs(monkeypatch):
     assert model._prefetched is None                       # consumed
     model.prefetch(other, ready=True, loss_rows=False)     # a scene the next call is NOT about
     again = model.get_prediction(batch, with_grad=False, to_cpu=True, min_size=True)
+    assert model._prefetched is not None                   # ... and it stays for the call it was made for
+    model.get_prediction(other, with_grad=False, to_cpu=True, min_size=True)
+    assert model._prefetched is None
     for h in cfg.network_heads:
         assert torch.equal(plain[h], ahead[h]), h
         assert torch.equal(plain[h], again[h]), h
