@@ -775,8 +775,9 @@ __global__ __launch_bounds__(256) void mask_gather_t_batch_kernel(const MaskScen
             }
             gp_u8 o = outp + ((int64_t)c * 64 + r) * d.n_pts + p0;
             if (whole) {
-                struct __attribute__((packed, aligned(1))) b16 { uint32_t a, b, c, d; };
-                *(__attribute__((address_space(1))) b16*)o = b16{q[0], q[1], q[2], q[3]};
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+                *(__attribute__((address_space(1))) u32x4_unaligned*)o = u32x4{q[0], q[1], q[2], q[3]};
             }
             else {
 #pragma unroll
