@@ -140,6 +140,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch-size', type=int, default=8, help='scenes per GPU (configs/scannet.txt: 8)')
     ap.add_argument('--target-voxels', type=int, default=150_000)
+    ap.add_argument('--distinct-batches', type=int, default=4,
+                    help='synthetic batches (different scenes, so different voxel counts and kernel maps) the steps cycle through, as '
+                         'a data loader would deliver them; 1 = the same batch every step (rounds 1-5)')
     ap.add_argument('--cpu-baseline', type=int, default=1, help='0 disables the CPU oracle timing')
     ap.add_argument('--cpu-voxels', type=int, default=150_000, help='voxels per scene of the CPU baseline sample (default: the metric\'s scene size)')
     ap.add_argument('--cpu-scenes', type=int, default=1, help='scenes in the CPU baseline sample')
@@ -203,17 +206,27 @@ def main():
 
     backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
     workload, cfg, tables, batch = make_workload(args, rank, world)
+    # further batches of the same shape, other scenes (scannet only: the other workloads are four fixed scene sizes): the steps
+    # cycle through them, so allocation sizes, rulebook shapes and tile counts differ from step to step like a loader's
+    batches = [batch]
+    if args.workload == 'scannet':
+        t_more = time.time()
+        for j in range(1, max(1, args.distinct_batches)):
+            batches.append(synth.make_batch(args.batch_size, seed0=(j * world + rank) * args.batch_size, target_voxels=args.target_voxels))
+        workload['gen_s'] += time.time() - t_more
     model = Model(cfg, *tables, device=dev)
     opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, fused=True)      # same update as training.py:35, one kernel
     model.train()
 
     # ---- synthetic batch of this rank (weak scaling: every rank gets batch_size scenes), resident in HBM
     t0 = time.time()
-    n_vox = int(batch['vox_coords'].shape[0])
-    for k in ('vox_coords', 'vox_features', 'pooling_ids', 'input_location', 'gt_bb_offsets', 'gt_bb_bounds',
-              'gt_semantics', 'fg_instances', 'batch_ids', 'gt_per_vox_semantics'):
-        if k in batch:
-            batch[k] = batch[k].to(dev)
+    n_vox = int(sum(b_['vox_coords'].shape[0] for b_ in batches) // len(batches))        # mean over the cycle
+    vox_of_batches = [int(b_['vox_coords'].shape[0]) for b_ in batches]
+    for b_ in batches:
+        for k in ('vox_coords', 'vox_features', 'pooling_ids', 'input_location', 'gt_bb_offsets', 'gt_bb_bounds',
+                  'gt_semantics', 'fg_instances', 'batch_ids', 'gt_per_vox_semantics'):
+            if k in b_:
+                b_[k] = b_[k].to(dev)
     torch.cuda.synchronize()
     gen_s = workload['gen_s'] + time.time() - t0
 
@@ -242,18 +255,22 @@ def main():
     # on a second stream while this step's network runs, as a training loop with a data loader one batch ahead would do.
     # Every step still builds exactly one batch's maps inside the timed region (the one it hands to the next step).
     PREFETCH = os.environ.get('B2M_BENCH_PREFETCH', '1') != '0'
-    next_batch = [None]
     prefetch_on = [True]
+    cursor = [0]                        # steps taken: step i trains on cycle[i % len(cycle)] and prefetches the one after it
+    cycle = [batches]                   # (the H2D pass swaps in the pinned-host forms of the same batches)
 
     def step():
         timer.drain()
         timer.step_id += 1
+        cur = cycle[0][cursor[0] % len(cycle[0])]
+        nxt = cycle[0][(cursor[0] + 1) % len(cycle[0])]
+        cursor[0] += 1
         opt.zero_grad()                 # torch default (set_to_none=True), as the reference's train_step
-        losses = model.compute_loss(batch, 150)
+        losses = model.compute_loss(cur['step'] if 'step' in cur else cur, 150)
         if PREFETCH and prefetch_on[0]:
-            # (the synthetic batch repeats: "next" is the same tensors.  ready=True: they were complete before this
-            # step was enqueued -- device tensors from setup, or the pinned host buffers of the H2D pass)
-            model.prefetch(next_batch[0] or batch, ready=True)
+            # (ready=True: the next batch's tensors were complete before this step was enqueued -- device tensors from
+            # setup, or the pinned host buffers of the H2D pass)
+            model.prefetch(nxt['prefetch'] if 'prefetch' in nxt else nxt, ready=True)
         losses['optimization_loss'].backward()      # (N > 1: the gradient all-reduce completes inside backward)
         opt.step()
         return losses
@@ -308,27 +325,45 @@ def main():
     host_keys = ('vox_coords', 'vox_features', 'pooling_ids', 'input_location', 'gt_bb_offsets', 'gt_bb_bounds',
                  'gt_semantics', 'fg_instances', 'batch_ids')
     host_keys = tuple(k for k in host_keys + ('gt_per_vox_semantics',) if k in batch)
-    dev_batch = dict(batch)
-    pinned = {k: batch[k].cpu().pin_memory() for k in host_keys}
-    h2d_bytes = sum(v.numel() * v.element_size() for v in pinned.values())
+    pinned = [{k: b_[k].cpu().pin_memory() for k in host_keys} for b_ in batches]
+    h2d_bytes = sum(v.numel() * v.element_size() for p_ in pinned for v in p_.values()) // len(pinned)
 
-    def step_h2d():
-        for k in host_keys:
-            # with prefetch the voxel coordinates / features stay host tensors: the side stream copies them
-            keep_host = PREFETCH and k in ('vox_coords', 'vox_features')
-            batch[k] = pinned[k] if keep_host else pinned[k].to(dev, non_blocking=True)
-        return step()
+    class _HostBatch(dict):
+        """One batch of the H2D pass: ['step'] = what compute_loss takes -- made when the step asks for it, so that the copies
+        are queued inside the step -- and ['prefetch'] = what Model.prefetch takes (the same host tensors for coordinates and
+        features: the side stream copies them; compute_loss recognises the batch by those tensors)."""
+
+        def __init__(self, dev_b, pin):
+            super().__init__()
+            self.dev_b, self.pin = dev_b, pin
+
+        def __contains__(self, k):
+            return k in ('step', 'prefetch')
+
+        def __getitem__(self, k):
+            keep = ('vox_coords', 'vox_features', 'fg_instances') if k == 'prefetch' else \
+                (('vox_coords', 'vox_features') if PREFETCH else ())
+            out = dict(self.dev_b)
+            for hk in host_keys:
+                if k == 'prefetch':
+                    if hk in keep:
+                        out[hk] = self.pin[hk]
+                else:
+                    # with prefetch the voxel coordinates / features stay host tensors: the side stream copies them
+                    out[hk] = self.pin[hk] if hk in keep else self.pin[hk].to(dev, non_blocking=True)
+            return out
+
     elapsed_h2d = elapsed_sync = None
     if args.side_passes:
-        if PREFETCH:
-            next_batch[0] = dict(batch, **{k: pinned[k] for k in ('vox_coords', 'vox_features', 'fg_instances')})
-        step_h2d()
+        cycle[0] = [_HostBatch(b_, p_) for b_, p_ in zip(batches, pinned)]
+        cursor[0] = 0
+        step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t_h = time.perf_counter()
         for _ in range(args.steps):
-            step_h2d()
+            step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -337,8 +372,8 @@ def main():
             t = torch.tensor([elapsed_h2d], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed_h2d = float(t.item())
-        batch.update(dev_batch)
-        next_batch[0] = None
+        cycle[0] = batches
+        cursor[0] = 0
 
     # ---- the same K steps with every loss read on the host in every iteration, as the reference's loop does
     # (/root/reference/models/training.py:170-174: `.item()` of each entry of the loss dict): the host cannot run ahead
@@ -418,7 +453,8 @@ def main():
         # once (5 B per rulebook slot; identity maps have none)
         slots = 0 if meta['rb_cnt'] is None else meta['K'] * ((meta['n_out'] + 63) // 64) * 64
         # (a data gradient that accumulates onto the other consumer's gradient also reads its output once: acc)
-        nbytes = 4.0 * (meta['n_in'] * meta['cin'] + (1 + meta.get('acc', 0)) * meta['n_out'] * meta['cout'] +
+        # (b2m_conv_up: n_out is the DOWN rulebook's coarse row count -- for the pair lists; the output it writes has n_fine rows)
+        nbytes = 4.0 * (meta['n_in'] * meta['cin'] + (1 + meta.get('acc', 0)) * meta.get('n_fine', meta['n_out']) * meta['cout'] +
                         meta['K'] * meta['cin'] * meta['cout']) + 5.0 * slots
         a = agg.setdefault(name, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0, steps={}))
         a['ms'] += ms; a['flops'] += flops; a['launches'] += 1; a['bytes'] += nbytes
@@ -524,6 +560,12 @@ def main():
                    # what the process group saw (RCCL is backend "nccl" on ROCm); None / 1 for a single process
                    'backend': backend, 'ranks_seen': (dist.get_world_size() if backend else 1),
                    'voxels_per_gpu_batch': n_vox, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 4),
+                   # the steps cycle through this many different batches (sizes jitter like a loader's); their voxel counts
+                   'distinct_batches': len(batches), 'voxels_of_batches': vox_of_batches,
+                   # the SURVEY 8d form of the metric (H2D copy of the batch inside the step) next to `value` -- kept here too
+                   # because the driver's record carries `config` in full
+                   'value_incl_h2d': round(scenes / elapsed_h2d, 3) if elapsed_h2d else None,
+                   'h2d_mb_per_step': round(h2d_bytes / 1e6, 1),
                    'scene_gen_s': round(gen_s, 1), 'setup_steps': SETUP_STEPS,
                    'prefetch': ('next batch: coordinate + kernel maps on a second stream during the step'
                                 if PREFETCH else 'off'),

@@ -111,6 +111,7 @@ PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_
          'b2m_xchg_size': (C.c_int64, []), 'b2m_xchg_max_doubles': (C.c_int32, []), 'b2m_xchg_max_ranks': (C.c_int32, []),
          'b2m_xchg_alloc': (C.c_int, [C.POINTER(C.c_void_p), P]), 'b2m_xchg_open': (C.c_int, [P, C.POINTER(C.c_void_p)]),
          'b2m_xchg_close': (C.c_int, [P]), 'b2m_xchg_free': (C.c_int, [P]),
+         'b2m_xchg_is_finegrained': (C.c_int32, [P]),
          'b2m_weight_pack_plan': (C.c_int64, [I32, P, P, P, P, P, P, P, P, P, P, P])}
 
 _lib = None

@@ -906,7 +906,7 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     const bool fast = c1 % KC == 0 && c2 % KC == 0 && ldx1 % KS == 0 && (c2 == 0 || ldx2 % KS == 0) &&
                       ((uintptr_t)x1 % (4 * KS)) == 0 && ((uintptr_t)x2 % (4 * KS)) == 0;
     if (n_out == 0) return B2M_OK;
-    ConvArgs a;
+    ConvArgs a{};
     a.x1 = x1; a.ldx1 = ldx1; a.c1 = c1; a.x2 = x2; a.ldx2 = ldx2; a.c2 = c2;
     a.wp = wp; a.K = K; a.bias = bias;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
@@ -1138,7 +1138,7 @@ extern "C" int b2m_conv_up(const float* x1, int64_t ldx1, int32_t c1, const floa
     if (n_coarse <= 0 || n_fine <= 0) { *ran = 1; return B2M_OK; }
     const int cin = c1 + c2;
     const int TW = conv_tw(cout, K);
-    ConvArgs a;
+    ConvArgs a{};
     a.x1 = x1; a.ldx1 = ldx1; a.c1 = c1; a.x2 = x2; a.ldx2 = ldx2; a.c2 = c2;
     a.wp = wp; a.K = K; a.bias = bias;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
@@ -1237,7 +1237,7 @@ extern "C" int b2m_conv_fwd_h(const void* x1, int64_t ldx1, int32_t c1, const vo
     B2M_CHECK_ARG(n_in >= 1 && n_in < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_in * ldx1 * 2 < (1ll << 32) &&
                   n_in * ldx2 * 2 < (1ll << 32), "inputs must be 32-bit addressable (rows < 2^24, tensors < 4 GiB)");
     if (n_out == 0) return B2M_OK;
-    ConvArgs a;
+    ConvArgs a{};
     a.x1 = (const float*)x1; a.ldx1 = ldx1; a.c1 = c1; a.x2 = (const float*)x2; a.ldx2 = ldx2; a.c2 = c2;
     a.wp = (const float*)wp; a.K = K; a.bias = nullptr;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
@@ -1924,7 +1924,7 @@ static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_i
     B2M_CHECK_ARG(ldx >= cin && lddy >= cout && lddw >= cout && dw_kstride >= (int64_t)cin * lddw,
                   "leading dimension too small");
     if (n_out == 0) return B2M_OK;
-    WgradArgs a;
+    WgradArgs a{};
     a.swap = tr;
     a.x = x; a.ldx = ldx; a.cin = cin; a.dy = dy; a.lddy = lddy; a.cout = cout;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;

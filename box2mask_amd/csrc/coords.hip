@@ -138,13 +138,40 @@ __global__ void count_dups_kernel(const int32_t* __restrict__ coords, int64_t n,
 
 static bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Two buffers filled with a 32-bit pattern each in ONE launch (the empty markers of a hash table's keys and values, the two
+// k2s2 tables): the runtime's memset is a launch per buffer, and a batch's 8 coordinate maps + 7 strided maps paid 30 of them.
+// Both byte counts are multiples of 4; 16-byte stores where the address allows.
+__global__ void fill_pair_kernel(uint32_t* __restrict__ a, int64_t na, uint32_t pa, uint32_t* __restrict__ b, int64_t nb, uint32_t pb) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int pass = 0; pass < 2; ++pass) {
+        uint32_t* p = pass ? b : a;
+        const int64_t n = pass ? nb : na;
+        const uint32_t v = pass ? pb : pa;
+        if (!p || n <= 0) continue;
+        if (((uintptr_t)p & 15) == 0) {
+            const int64_t n4 = n / 4;
+            const uint4 v4 = make_uint4(v, v, v, v);
+            for (int64_t i = t; i < n4; i += stride) ((uint4*)p)[i] = v4;
+            for (int64_t i = n4 * 4 + t; i < n; i += stride) p[i] = v;
+        } else {
+            for (int64_t i = t; i < n; i += stride) p[i] = v;
+        }
+    }
+}
+static int fill_pair(void* a, int64_t bytes_a, uint32_t pa, void* b, int64_t bytes_b, uint32_t pb, hipStream_t st) {
+    const int64_t words = (bytes_a > bytes_b ? bytes_a : bytes_b) / 16 + 1;
+    int64_t nb = cdiv64(words, 256);
+    if (nb > 2048) nb = 2048;
+    fill_pair_kernel<<<(unsigned)nb, 256, 0, st>>>((uint32_t*)a, bytes_a / 4, pa, (uint32_t*)b, bytes_b / 4, pb);
+    return hipGetLastError() == hipSuccess ? 0 : B2M_ERR_HIP;
+}
+
 extern "C" int b2m_coords_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
                                 int32_t* dup_count, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(n >= 0 && n < (1ll << 31), "n out of range");
     B2M_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap < (1ll << 31), "cap must be a power of two >= 2n");
-    B2M_HIP(hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st));
-    B2M_HIP(hipMemsetAsync(vals, 0x7F, cap * sizeof(int32_t), st));
+    if (fill_pair(keys, cap * (int64_t)sizeof(uint64_t), 0xFFFFFFFFu, vals, cap * (int64_t)sizeof(int32_t), 0x7F7F7F7Fu, st)) return B2M_ERR_HIP;
     if (dup_count) B2M_HIP(hipMemsetAsync(dup_count, 0, sizeof(int32_t), st));
     if (n == 0) return B2M_OK;
     unsigned nb = (unsigned)cdiv64(n, 256);
@@ -198,8 +225,7 @@ extern "C" int b2m_coords_stride(const int32_t* coords, int64_t n, int32_t ts, i
     B2M_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap < (1ll << 31), "cap must be a power of two >= 2n");
     B2M_CHECK_ARG(n_out_host != nullptr, "n_out_host is NULL");
     *n_out_host = 0;
-    B2M_HIP(hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st));
-    B2M_HIP(hipMemsetAsync(vals, 0x7F, cap * sizeof(int32_t), st));
+    if (fill_pair(keys, cap * (int64_t)sizeof(uint64_t), 0xFFFFFFFFu, vals, cap * (int64_t)sizeof(int32_t), 0x7F7F7F7Fu, st)) return B2M_ERR_HIP;
     if (n == 0) return B2M_OK;
     int32_t* slot_of = scratch;            // [n]
     int32_t* pos = scratch + n;            // [n]  first-occurrence flag, then its exclusive scan in place
@@ -316,8 +342,9 @@ extern "C" int b2m_stride_tables(const int32_t* parent, const int32_t* koff, int
                                  int32_t* child, int64_t ld_c, int32_t* up, int64_t ld_f, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG((!child || ld_c >= n_coarse) && (!up || ld_f >= n_fine), "leading dimension too small");
-    if (child) B2M_HIP(hipMemsetAsync(child, 0xFF, 8 * ld_c * sizeof(int32_t), st));
-    if (up) B2M_HIP(hipMemsetAsync(up, 0xFF, 8 * ld_f * sizeof(int32_t), st));
+    if (child || up)
+        if (fill_pair(child, child ? 8 * ld_c * (int64_t)sizeof(int32_t) : 0, 0xFFFFFFFFu, up, up ? 8 * ld_f * (int64_t)sizeof(int32_t) : 0, 0xFFFFFFFFu, st))
+            return B2M_ERR_HIP;
     if (n_fine == 0) return B2M_OK;
     stride_tables_kernel<<<(unsigned)cdiv64(n_fine, 256), 256, 0, st>>>(parent, koff, n_fine, child, ld_c, up, ld_f);
     B2M_LAUNCH_CHECK();

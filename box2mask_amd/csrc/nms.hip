@@ -171,7 +171,7 @@ extern "C" int b2m_detection_loss(const float* off, int64_t ld_off, const float*
     B2M_CHECK_ARG(off && bnd && gt_off && gt_bnd && loc && d_off && d_bnd && sums && result && S >= 1 && n_fg >= 1, "bad arguments");
     B2M_CHECK_ARG(ld_off >= 3 && ld_bnd >= 3 && (!sc || (d_sc && ld_sc >= 1)), "leading dimensions / score gradient");
     B2M_CHECK_ARG(!sem || (d_sem && argmax && gt_sem && n_valid && n_class >= 1 && ld_sem >= n_class), "semantics arguments");
-    LossArgs a;
+    LossArgs a{};
     a.off = off; a.ld_off = ld_off; a.bnd = bnd; a.ld_bnd = ld_bnd; a.sc = sc; a.ld_sc = ld_sc; a.sem = sem; a.ld_sem = ld_sem;
     a.C = n_class; a.gt_off = gt_off; a.gt_bnd = gt_bnd; a.loc = loc; a.fg = fg; a.gt_sem = gt_sem; a.S = S;
     a.w_off = w_off; a.w_bnd = w_bnd; a.w_sc = w_sc; a.w_sem = w_sem; a.min_bb = min_bb_size; a.F = n_fg; a.n_valid = n_valid;

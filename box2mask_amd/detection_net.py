@@ -145,6 +145,8 @@ class SelectionNet(ResNetBase):
         # one launch repacks every layer's weight images for this pass (an inference pass keeps the previous ones if no
         # training pass ran in between)
         F_.packed_weights.begin_pass(inference=not (self.training or torch.is_grad_enabled()))
+        F_.zero_slab.new_pass()                     # the tiny maps' zero-filled outputs: a fresh chunk per pass
+        ME.defer_counters(True)                     # every BatchNorm's batch counter in ONE foreach add at the end of the pass
         arena = getattr(self, '_grad_arena', None)
         if arena is not None and torch.is_grad_enabled():
             arena.begin_pass()                      # one memset: every parameter gradient of this pass starts at zero
@@ -228,6 +230,7 @@ class SelectionNet(ResNetBase):
                 if t.F.shape[0] == perm.shape[0] and not isinstance(t, ME.PooledTensor):
                     outputs[name] = ME.PooledTensor(t.features_in_input_order())
         ME.flush_batch_counters()
+        ME.defer_counters(False)
         return outputs
 
     # ------------------------------------------------------------------ votes -> instance masks

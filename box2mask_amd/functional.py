@@ -7,6 +7,7 @@ the MinkowskiEngine operator the reference calls (file:line cited per function; 
 from __future__ import annotations
 
 import ctypes
+import itertools
 import os
 import weakref
 
@@ -160,6 +161,45 @@ class _PackedWeights:
 packed_weights = _PackedWeights()
 
 
+class _ZeroSlab:
+    """Zero-filled output tensors for the convolutions on the tiniest maps.  A map with fewer than 8 tiles (< 512 rows: the two
+    deepest levels of a training batch) is split over up to 16 waves per (tile, strip) that meet in the output with fp32 atomics,
+    so the output must start at zero -- one hipMemset2DAsync per launch inside b2m_conv_fwd, 52 of the ~100 runtime memsets of a
+    training step (profiles/r06_analysis.md).  Here such an output is a piece of ONE zero-filled chunk per pass (a single
+    memset of a few MB) and the convolution is told to accumulate onto it: the library then launches nothing but the kernel.
+    A chunk is never reused (pieces are saved for backward): when it is used up -- or a new pass begins -- the next one is made;
+    the pieces keep their chunk alive."""
+    CHUNK = 4 << 20          # floats (16 MB): a training pass of the 8-level U-Net takes ~1 M
+
+    def __init__(self):
+        self.chunk = {}      # device -> [tensor, floats used]
+
+    def new_pass(self):
+        self.chunk.clear()
+
+    def take(self, n, c, device):
+        need = (n * c + 63) // 64 * 64                  # 256-byte aligned pieces
+        if need > self.CHUNK // 4:
+            return None
+        e = self.chunk.get(device)
+        if e is None or e[1] + need > e[0].numel():
+            e = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0]
+            self.chunk[device] = e
+        t = e[0][e[1]:e[1] + n * c].view(n, c)
+        e[1] += need
+        t._b2m_slab = True                              # (a view, but nobody else's: see _accumulation_target)
+        return t
+
+
+zero_slab = _ZeroSlab()
+TINY_MAP_ROWS = 8 * 64       # below 8 tiles b2m_conv_fwd splits an item over up to 16 waves that add atomically (csrc/conv.hip)
+
+
+def conv_zero_slab() -> bool:
+    """B2M_CONV_ZERO_SLAB=0: the tiny maps' outputs are plain allocations and b2m_conv_fwd zero-fills each one itself."""
+    return os.environ.get('B2M_CONV_ZERO_SLAB', '1') == '1'
+
+
 def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: int, out=None, accumulate=False,
              tile_stats: list | None = None, logical_cin: int | None = None):
     """Y = sum_k [x1|x2][in_k] @ B[k] with B given as a packed image for (K, c1+c2, cout).
@@ -168,6 +208,9 @@ def conv_raw(x1, x2, wp, K: int, bias, rb: Rulebook | None, n_out: int, cout: in
     (tensor [ntiles, 2, cout], ntiles) -- b2m_conv_fwd_stats."""
     c1 = x1.shape[1]
     c2 = x2.shape[1] if x2 is not None else 0
+    if out is None and rb is not None and K > 1 and 0 < n_out < TINY_MAP_ROWS and not deterministic() and conv_zero_slab():
+        out = zero_slab.take(n_out, cout, x1.device)     # zero already: nothing for the library to fill (accumulate = 1)
+        accumulate = out is not None
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=x1.device)
     meta = None if logical_cin is None else {'cin': logical_cin}
@@ -443,6 +486,7 @@ class _SparseConv(torch.autograd.Function):
         ctx.save_for_backward(x1, x2, weight, bias)
         ctx.rb_f, ctx.rb_b, ctx.mirror, ctx.c1 = rb_f, rb_b, mirror, c1
         ctx.src1, ctx.src2 = _node_id(in1), _node_id(in2)     # the nodes the data gradients are made for (`_own`)
+        ctx._b2m_tag = next(_node_tags)                       # this node's own name (`_accumulation_target`)
         if passthrough:
             # The inputs come back as second / third outputs: whoever else consumes them (the residual branch of a
             # BasicBlock, its 1x1 shortcut) takes THESE, so their gradients arrive here, in one call with dy, and the data
@@ -465,14 +509,14 @@ class _SparseConv(torch.autograd.Function):
         dx1 = dx2 = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = packed_weights.get(weight, True, ctx.mirror, 0, c1)
-            acc = _accumulation_target(p1, x1.shape[0], c1, id(ctx))
+            acc = _accumulation_target(p1, x1.shape[0], c1, ctx._b2m_tag)
             dx1 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x1.shape[0], c1, out=acc, accumulate=acc is not None)
             if p1 is not None and acc is None:
                 dx1 = dx1 + p1
             _own(dx1, ctx.src1)
         if x2 is not None and ctx.needs_input_grad[1]:
             wt = packed_weights.get(weight, True, ctx.mirror, c1, x2.shape[1])
-            acc = _accumulation_target(p2, x2.shape[0], x2.shape[1], id(ctx))
+            acc = _accumulation_target(p2, x2.shape[0], x2.shape[1], ctx._b2m_tag)
             dx2 = conv_raw(dy, None, wt, K, None, ctx.rb_b, x2.shape[0], x2.shape[1], out=acc, accumulate=acc is not None)
             if p2 is not None and acc is None:
                 dx2 = dx2 + p2
@@ -510,10 +554,17 @@ class _SparseConv(torch.autograd.Function):
         return dx1, dx2, dw, db, None, None, None, None, None, None
 
 
+_node_tags = itertools.count(1)
+
+
 def _node_id(t) -> int:
-    """Identity of the backward node that will receive the gradient of forward tensor `t` (0: a leaf / no graph)."""
+    """Name of the backward node that will receive the gradient of forward tensor `t`, if that node is one of this package's
+    convolutions -- the only nodes that add onto an incoming gradient in place -- else 0 (a leaf, no graph, a torch node).
+    The name is a number drawn from a process-wide counter and stored on the node when its forward runs (`ctx._b2m_tag`);
+    `id()` of a torch C++ node's Python wrapper is NOT a name: the wrapper is a temporary, and its address can come back as
+    the address of a later object."""
     fn = getattr(t, 'grad_fn', None) if t is not None else None
-    return id(fn) if fn is not None else 0
+    return getattr(fn, '_b2m_tag', 0) if fn is not None else 0
 
 
 def _own(t, target: int):
@@ -528,12 +579,14 @@ def _own(t, target: int):
 def _accumulation_target(g, n: int, c: int, node: int):
     """The gradient of a passed-through input, if the data gradient may be added onto it in place: a dense fp32 (n, c)
     tensor that owns its memory AND was produced by one of this package's backward operators for THIS node's output alone
-    (`_own` carries the id of the node the gradient was made for; `node` = id of the convolution's own backward node).
+    (`_own` carries the name of the node the gradient was made for; `node` = the convolution's own name, `ctx._b2m_tag`).
     A gradient that went through a torch operator first is not accepted even when it is the very tensor object this
     package produced: AddBackward0 hands ONE tensor to both of its inputs, the mark then names the add node, not this
     one, and adding in place would corrupt the other branch -- such gradients are summed out of place
     (tests/test_gpu_determinism.py::test_torch_add_between_two_convolutions).  The mark is consumed here."""
-    if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n, c) or not g.is_contiguous() or g._base is not None:
+    if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n, c) or not g.is_contiguous():
+        return None
+    if g._base is not None and not getattr(g, '_b2m_slab', False):      # a view -- unless it is a piece of the zero slab, made for one tensor
         return None
     mark = g.__dict__.pop('_b2m_own', None)
     if mark is None or mark == 0 or mark != node:
@@ -1022,7 +1075,9 @@ class _DetectionLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g0 = g[0]
-        out = [None if d is None else d * g0 for d in ctx.grads]
+        live = [d for d in ctx.grads if d is not None]
+        scaled = iter(torch._foreach_mul(live, g0))         # one launch for the four heads' gradients
+        out = [None if d is None else next(scaled) for d in ctx.grads]
         return (out[0], out[1], out[2], out[3]) + (None,) * 9
 
 

@@ -200,7 +200,8 @@ class MinkowskiBatchNorm(nn.Module):
                              bn.momentum, bn.eps, residual, relu, self.sync, count_key)
 
     def forward(self, x: SparseTensor) -> SparseTensor:
-        return x.new(self.apply_bn(x.F, count_key=count_key_of(x)))
+        # (inside SelectionNet.forward -- defer_counters(True) -- the heads' layers join the one foreach add of the pass)
+        return x.new(self.apply_bn(x.F, count_key=count_key_of(x), defer_counter=_defer_all[0]))
 
     def _begin(self, feats, defer_counter):
         """The bookkeeping of apply_bn for a layer that runs inside a paired operator: (training?, parameter tuple)."""
@@ -240,6 +241,14 @@ def batch_norm_add_relu(norm_a: MinkowskiBatchNorm, feats_a, norm_b: MinkowskiBa
 
 
 _pending_counters = []
+_defer_all = [False]
+
+
+def defer_counters(on: bool):
+    """While on, EVERY training-mode BatchNorm layer (also the ones called as plain modules: the heads) books its
+    `num_batches_tracked += 1` for the next flush_batch_counters() instead of launching an add of its own.  The caller
+    flushes before it returns (SelectionNet.forward)."""
+    _defer_all[0] = bool(on)
 
 
 def flush_batch_counters():

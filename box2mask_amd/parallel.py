@@ -80,8 +80,22 @@ class IpcExchange:
             if lib.b2m_xchg_open(C.create_string_buffer(h, 64), C.byref(p)) != 0:
                 raise _lib.B2MError('b2m_xchg_open failed: ' + lib.b2m_last_error().decode())
             ptrs.append(p.value); self._opened.append(p.value)
+        # Ranks on DIFFERENT devices need fine-grained (peer-coherent) mailboxes: a waiting kernel must see a peer device's
+        # writes without a kernel boundary.  The plain allocation b2m_xchg_alloc falls back to is only coherent between
+        # processes that share one device (the two-ranks-on-one-GPU rehearsal) -- refuse anything else.
+        fine = bool(lib.b2m_xchg_is_finegrained(C.c_void_p(self._own)))
+        where = [None] * self.world
+        dist.all_gather_object(where, (_device_identity(self.device), fine), group=group)
+        self.fine_grained = all(f for _, f in where)
+        if len({d for d, _ in where}) > 1 and not self.fine_grained:
+            self.close()
+            raise _lib.B2MError('IpcExchange: ranks on different devices need fine-grained mailboxes and this runtime granted '
+                                'none (plain device memory is not coherent under a running kernel of a peer device); '
+                                'unset B2M_SYNCBN_IPC')
         self.peers = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._err_event = None
         self.epoch = 0
         dist.barrier(group=group)              # every mailbox is mapped everywhere before the first exchange
 
@@ -94,14 +108,27 @@ class IpcExchange:
         self.epoch += 1
         _lib.call('b2m_xchg_allreduce', t.data_ptr(), t.numel(), self.peers.data_ptr(), self.rank, self.world, self.epoch,
                   t.data_ptr(), self.err.data_ptr())
-        if self.epoch % 4096 == 0:         # (every ~25 training steps: one host read, so that a peer that went away is noticed)
-            self.check()
+
+    _MSG = ('IpcExchange: a rank did not arrive within the wait bound (B2M_XCHG_TIMEOUT_S); the statistics of that exchange '
+            'were replaced by NaN')
 
     def check(self):
-        """Raises if an exchange gave up waiting for a peer (host read: call it at a step boundary, not per layer)."""
+        """Raises if an exchange gave up waiting for a peer.  A blocking host read: for the end of a run or a test."""
         from . import _lib
         if int(self.err.item()) != 0:
-            raise _lib.B2MError('IpcExchange: a rank did not arrive within the wait bound; the statistics of that exchange are invalid')
+            raise _lib.B2MError(self._MSG)
+
+    def check_async(self):
+        """The step-boundary form (GradAllReduce._finalize calls it at the end of every backward pass): looks at the error
+        flag as it was copied to pinned host memory at the PREVIOUS boundary -- no wait for the device -- and queues the
+        next copy.  A timed-out exchange is therefore reported one step later at the latest; its result was NaN on the
+        device from the start, so nothing trained on stale statistics in between."""
+        from . import _lib
+        if self._err_event is not None and self._err_event.query() and int(self._err_host[0]) != 0:
+            raise _lib.B2MError(self._MSG)
+        self._err_host.copy_(self.err, non_blocking=True)
+        self._err_event = torch.cuda.Event()
+        self._err_event.record()
 
     def close(self):
         for p in self._opened:
@@ -110,6 +137,16 @@ class IpcExchange:
         if self._own:
             self._lib.b2m_xchg_free(self._own)
             self._own = None
+
+
+def _device_identity(device) -> str:
+    """What tells two ranks' devices apart across processes: the device's UUID where torch exposes it, else host + visible index."""
+    try:
+        return str(torch.cuda.get_device_properties(device).uuid)
+    except Exception:
+        import socket
+        return '%s/%s/%s' % (socket.gethostname(), os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES', '')),
+                             torch.device(device).index)
 
 
 def syncbn_ipc_enabled() -> bool:
@@ -191,6 +228,9 @@ class GradAllReduce:
         result back.  Parameters without a gradient keep `.grad is None`."""
         if self.world <= 1:
             return
+        from . import functional as F_
+        if F_.ipc_exchange is not None:       # a SyncBN mailbox exchange that timed out in this or the previous pass
+            F_.ipc_exchange.check_async()
         for bi in range(len(self.buckets)):
             if self._work[bi] is None:        # bucket with parameters that received no gradient in this pass
                 self._launch(bi)

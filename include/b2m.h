@@ -276,8 +276,8 @@ int b2m_conv_wgrad_tr(const float* x, int64_t ldx, int32_t cin, int64_t n_in, co
 /* ---------------------------------------------------------------- SyncBN statistics exchange inside one node (opt-in)
  * Device-side all-reduce (SUM) of n <= b2m_xchg_max_doubles() doubles between <= b2m_xchg_max_ranks() ranks whose MAILBOXES
  * (b2m_xchg_size() bytes of device memory each) are mapped into one another through HIP IPC: one launch of one workgroup
- * writes this rank's values into slot [rank] of every mailbox, raises its flag there, waits (bounded: ~7 s, then *err = 1) for
- * every flag of its own mailbox and adds the slots in rank order.  Replaces, for the 2c + 1 ... 3c doubles of a SyncBN layer
+ * writes this rank's values into slot [rank] of every mailbox, raises its flag there, waits (bounded: B2M_XCHG_TIMEOUT_S seconds of wall time,
+ * default 120; then *err = 1 and the result is NaN) for every flag of its own mailbox and adds the slots in rank order.  Replaces, for the 2c + 1 ... 3c doubles of a SyncBN layer
  * (/root/reference/models/model.py:25), the collective library's all-reduce.  Set-up per rank: b2m_xchg_alloc -> own mailbox + a
  * 64-byte IPC handle; the handles travel over the process group; b2m_xchg_open maps a peer's mailbox; `peers_dev` is a device
  * array of `world` mailbox addresses in rank order (own mailbox at [rank]).  `epoch` counts the exchanges of the group from 1
@@ -290,6 +290,10 @@ int b2m_xchg_alloc(void** buf, void* handle64);
 int b2m_xchg_open(const void* handle64, void** ptr);
 int b2m_xchg_close(void* ptr);
 int b2m_xchg_free(void* buf);
+/* 1 if `buf` (a mailbox of this process from b2m_xchg_alloc) is a fine-grained allocation -- what ranks on DIFFERENT devices need:
+ * a running kernel of a peer device must see the writes without a kernel boundary.  The plain allocation the call falls back to
+ * is only coherent between processes that share one device. */
+int32_t b2m_xchg_is_finegrained(const void* buf);
 int b2m_xchg_allreduce(const double* vals, int32_t n, const void* const* peers_dev, int32_t rank, int32_t world,
                        uint64_t epoch, double* out, int32_t* err, void* stream);
 

@@ -105,8 +105,14 @@ class MaskRecorder:
     # largest such element is a maximum over ~1e7 elements of a default-mode pass (atomics: it moves from run to run --
     # 2e-6 ... 5e-5 in most runs, 1.1e-4 once in a dozen at layer 56 of 79, which a bound of 1e-4 turned into a failure of the
     # whole GPU suite).  A kernel that decides `y > 0` wrongly disagrees at |x| ~ rms, four orders of magnitude from here.
+    # The relaxed bound is for the DEFAULT (atomic) mode only: under B2M_DETERMINISTIC=1 nothing moves from run to run and the
+    # tighter 1e-4 of round 4 holds.
     max_flip_fraction = 1e-3
-    max_flip_preact = 3e-4
+
+    @property
+    def max_flip_preact(self):
+        import os
+        return 1e-4 if os.environ.get('B2M_DETERMINISTIC', '0') == '1' else 3e-4
 
     def summary(self):
         """(largest disagreeing fraction, largest |x| / rms of a disagreeing element) over the replayed ReLUs."""

@@ -50,6 +50,9 @@ REGIMES = {
     'wgrad_hand_issued_loads_square_blocks_only': {'B2M_WGRAD_HANDLOADS': '1'},
     'wgrad_of_transposed_maps_over_the_up_rulebook': {'B2M_WGRAD_UP': '0'},     # (default: b2m_conv_wgrad_tr over the DOWN rulebook)
     'wgrad_64_tile_chunks': {'B2M_WGRAD_MIN_TILES': '64'},
+    # the ordered two-stage combine: the plain kernel with the row roles exchanged on the transposed maps (b2m_conv_wgrad_tr)
+    'deterministic': {'B2M_DETERMINISTIC': '1'},
+    'deterministic_up_rulebook': {'B2M_DETERMINISTIC': '1', 'B2M_WGRAD_UP': '0'},
     'wgrad_one_offset_per_workgroup': {'B2M_WGRAD_KPACK': '0'},
     'no_xcd_order': {'B2M_XCD': '0'},
     'xcd_equal_tile_counts': {'B2M_XCD_BALANCE': '0'},
@@ -83,6 +86,7 @@ REGIME_CASES = {
     'no_chunk_slices': _SPLIT, 'many_slices': _SPLIT, 'wgrad_plain': _WGRAD, 'wgrad_compiler_tracked_loads': _WGRAD,
     'wgrad_hand_issued_loads_square_blocks_only': _WGRAD, 'wgrad_64_tile_chunks': _WGRAD,
     'wgrad_of_transposed_maps_over_the_up_rulebook': [8, 9], 'wgrad_one_offset_per_workgroup': [0, 5, 6],
+    'deterministic': [1, 3, 6, 8, 9], 'deterministic_up_rulebook': [8, 9],
     'no_xcd_order': _ORDER, 'xcd_equal_tile_counts': _ORDER, 'unsplit_64bit': _ALL,
 }
 
