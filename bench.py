@@ -211,8 +211,11 @@ def main():
     batches = [batch]
     if args.workload == 'scannet':
         t_more = time.time()
+        # (a loader's batches differ by some per cent in size: 1.0 / 0.93 / 1.07 / 1.0 x the metric's scene size -- mean 1.0)
+        jitter = (1.0, 0.93, 1.07, 1.0)
         for j in range(1, max(1, args.distinct_batches)):
-            batches.append(synth.make_batch(args.batch_size, seed0=(j * world + rank) * args.batch_size, target_voxels=args.target_voxels))
+            batches.append(synth.make_batch(args.batch_size, seed0=(j * world + rank) * args.batch_size,
+                                            target_voxels=int(args.target_voxels * jitter[j % 4])))
         workload['gen_s'] += time.time() - t_more
     model = Model(cfg, *tables, device=dev)
     opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, fused=True)      # same update as training.py:35, one kernel

@@ -108,6 +108,36 @@ extern "C" int b2m_debug_clocks(unsigned long long* out8, int reset) {
 #define B2M_CLOCK_END(slot) do { } while (0)
 #endif
 
+// Diagnostic build only (-DB2M_RESIDENCY, tools/residency.py): when every wave of a conv_fwd_flow launch begins and ends
+// (s_memrealtime, 100 MHz) -- one slot per wave, no atomics; the host turns the intervals into waves resident over time.
+#ifdef B2M_RESIDENCY
+#define B2M_RES_CAP (1 << 18)
+__device__ unsigned long long g_res[3 * B2M_RES_CAP];
+extern "C" int b2m_debug_residency(unsigned long long* host_out, int reset) {      // host_out: 3 * B2M_RES_CAP words (or NULL)
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_res), sizeof(g_res)) != hipSuccess) return -1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_res)) != hipSuccess || hipMemset(p, 0, sizeof(g_res)) != hipSuccess) return -1;
+    }
+    return B2M_RES_CAP;
+}
+// (fp32 gather form only: in the half and scatter variants two more live scalars push the pair-list pointers of the
+// hand-issued loads out of the scalar file, which their "s" operands do not allow -- the -DB2M_CLOCKS build has that problem)
+#define B2M_RES_BEGIN() unsigned long long rs_t0 = 0; if constexpr (!F16 && !UP && DBG == 0) rs_t0 = __builtin_amdgcn_s_memrealtime()
+#define B2M_RES_END(slot_index, meta)                                                                       \
+    if constexpr (!F16 && !UP && DBG == 0) {                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+        const unsigned long long rs_t1 = __builtin_amdgcn_s_memrealtime();                                  \
+        const unsigned long long rs_i = (unsigned long long)(slot_index);                                   \
+        if ((threadIdx.x & 63) == 0 && rs_i < B2M_RES_CAP) {                                                \
+            g_res[3 * rs_i] = rs_t0; g_res[3 * rs_i + 1] = rs_t1; g_res[3 * rs_i + 2] = (unsigned long long)(meta); \
+        }                                                                                                   \
+    }
+#else
+#define B2M_RES_BEGIN() do { } while (0)
+#define B2M_RES_END(slot_index, meta) do { } while (0)
+#endif
+
 // The shader clock the chip holds under fp32-MFMA load (bench.py: before and after the bracketed roofline passes, so that a
 // fraction of the 2.4 GHz peak can be read against the clock the lease actually ran at).  Three waves per SIMD run `iters`
 // blocks of 12 v_mfma_f32_16x16x4_f32 (the convolution kernels' block); every wave stamps s_memtime (shader cycles) and
@@ -959,15 +989,28 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     const int nchunk_h = (cin + KC - 1) / KC;
     while (nslice > 1 && ncs < 4 && items0 * nslice * ncs < 2048 && nchunk_h / (ncs * 2) >= 2 && env_flag("B2M_CONV_CHUNKSPLIT", 1)) ncs *= 2;
     nslice *= ncs;
+    // (round 6) medium maps that run un-split -- a few rounds of long-lived waves, tools/residency.py: 14-18 % of such a launch is
+    // its drain -- as TWO slices per item (workgroups of two waves that combine in LDS): half the wave lifetime, half the drain.
+    // B2M_CONV_SPLIT2 = largest item count that takes this form (0: off)
+    // -- only where the hand-issued flow kernel runs (the one kernel with a two-wave instantiation)
+    const bool fast32_ok = n_in < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_in * ldx1 * 4 < (1ll << 32) &&
+                           n_in * ldx2 * 4 < (1ll << 32) && env_flag("B2M_CONV_FAST32", 1);
+    bool split2 = false;
+    if (nslice == 1 && K >= 8 && rb_in != nullptr && fast && KC == 16 && fast32_ok && (cin / 16) % 2 == 0 && cin >= 32 &&
+        env_flag("B2M_CONV_PIPE", 2) && env_flag("B2M_CONV_HANDLOADS", 1) && !env_flag("B2M_PIPE_DBG", 0) &&
+        !env_flag("B2M_DETERMINISTIC", 0) && items0 >= target && items0 < env_flag("B2M_CONV_SPLIT2", 0)) {
+        nslice = 2;
+        split2 = true;
+    }
     a.ncs = ncs;
     a.nslice = nslice;
-    a.wg_combine = (nslice > 1 && nslice % 4 == 0 && env_flag("B2M_CONV_WGCOMBINE", 1)) ? 1 : 0;
+    a.wg_combine = ((nslice > 1 && nslice % 4 == 0 && env_flag("B2M_CONV_WGCOMBINE", 1)) || split2) ? 1 : 0;
     a.fast32 = (n_in < (1 << 24) && ldx1 < (1 << 22) && ldx2 < (1 << 22) && n_in * ldx1 * 4 < (1ll << 32) &&
                 n_in * ldx2 * 4 < (1ll << 32) && env_flag("B2M_CONV_FAST32", 1)) ? 1 : 0;
     static const float* zeros_addr = nullptr;
     if (!zeros_addr) B2M_HIP(hipGetSymbolAddress((void**)&zeros_addr, HIP_SYMBOL(g_zeros)));
     a.zeros = zeros_addr;
-    if (nslice > 1 && !accumulate && !(a.wg_combine && nslice == 4))
+    if (nslice > 1 && !accumulate && !(a.wg_combine && (nslice == 4 || split2)))
         B2M_HIP(hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)cout * sizeof(float), (size_t)n_out, st));
     const int64_t items = items0 * nslice;
     a.nwg = cdiv64(items, 4);
@@ -1000,17 +1043,17 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
         const bool split_ok = nslice == 1 || (a.wg_combine && env_flag("B2M_CONV_FLOW_SPLIT", 1));
         if (depth >= 2 && !ident && fast && KC == 16 && split_ok && a.fast32 && nc % ncs == 0 && (nc / ncs) % depth == 0 &&
             nc / ncs >= depth) {
-            const int wpb = nslice == 1 ? 1 : 4;
+            const int wpb = nslice == 1 ? 1 : split2 ? 2 : 4;
             B2M_CHECK_ARG(items0 < (1ll << 31), "too many (tile, strip) items");      // (32-bit index arithmetic in the kernel)
             a.chain = (wpb == 1 && env_flag("B2M_CONV_CHAIN", 1)) ? 1 : 0;
             // the workgroup that writes a (tile, strip) sees its final values: un-split maps, or exactly 4 slices
             // combined in LDS and stored plainly
-            if (tile_stats && (nslice == 1 || (nslice == 4 && !accumulate))) {
+            if (tile_stats && (nslice == 1 || ((nslice == 4 || split2) && !accumulate))) {
                 a.stats = tile_stats;
                 if (wrote_stats) *wrote_stats = 1;
             }
             // (the workgroup that writes a (tile, strip) holds its final values: un-split, or exactly 4 slices combined in LDS)
-            if (ep_ok && (nslice == 1 || nslice == 4)) use_epilogue();
+            if (ep_ok && (nslice == 1 || nslice == 4 || split2)) use_epilogue();
             a.nwg = cdiv64(items, wpb);
             XcdOrder fo = xcd_order(a.nwg, xcd_tiles * a.nstrips * nslice / wpb);
             a.xcd_per = fo.chunk;
@@ -1034,7 +1077,10 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
                 return B2M_OK;
             }
             if (hl && depth == 2 && !dbg) {
-                if (wpb == 4) {
+                if (wpb == 2) {
+                    if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 2, 1><<<fo.grid, 128, 0, st>>>(a);
+                    else conv_fwd_flow_kernel<2, 2, 0, 2, 1><<<fo.grid, 128, 0, st>>>(a);
+                } else if (wpb == 4) {
                     if (TW == 3) conv_fwd_flow_kernel<2, 3, 0, 4, 1><<<fo.grid, 256, 0, st>>>(a);
                     else conv_fwd_flow_kernel<2, 2, 0, 4, 1><<<fo.grid, 256, 0, st>>>(a);
                 } else {

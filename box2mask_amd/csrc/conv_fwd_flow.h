@@ -148,6 +148,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
     const int strip = (int)((uint32_t)item % (uint32_t)a.nstrips);
     if (tile >= a.ntiles) return;             // the whole workgroup leaves (its waves share the item)
     B2M_CLOCK_BEGIN();
+    B2M_RES_BEGIN();
 #ifdef B2M_STAMPS
     unsigned long long fs_begin, fs_init = 0, fs_pro = 0, fs_t0 = 0, fs_t1 = 0, fs_t2 = 0, fs_loop = 0, fs_flush = 0, fs_adv = 0, fs_vis = 0, fs_walk = 0, fs_stat = 0;
     if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) { B2M_STAMP(fs_begin); }
@@ -595,8 +596,11 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
     // ---- write the strip (rows of the strip are 16-byte aligned: coalesced vector stores)
     if constexpr (WPB > 1) {
         __syncthreads();
-        if (wave != 0) return;
+        if (wave != 0) { B2M_RES_END((int64_t)blockIdx.x * WPB + wave, 0); return; }
         const bool plain = a.nslice == WPB && !a.accumulate;
+        // (round 6) accumulate with exactly one workgroup per (tile, strip): this wave is the only writer of the strip's rows, so
+        // the sum onto the tensor already there is a plain 16-byte read-modify-write, not 4 atomics per lane
+        const bool rmw = a.nslice == WPB && a.accumulate && !F16;
         for (int e = lane; e < B2M_TILE * (SW / 4); e += 64) {
             const int row = e / (SW / 4), c4 = (e % (SW / 4)) * 4;
             const int64_t grow = row0 + row;
@@ -614,6 +618,8 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
             if (plain && a.vec_store && col + 3 < a.cout) {
                 if (a.ep_scale) v = conv_epilogue(a, v, grow, col);
                 *(f32x4*)dst = v;
+            } else if (rmw && a.vec_store && col + 3 < a.cout) {
+                *(f32x4*)dst = *(const f32x4*)dst + v;
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -628,6 +634,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             tile_column_sums(a, smem, tile, row0, col0, lane);
         }
+        B2M_RES_END((int64_t)blockIdx.x * WPB, 0);
         return;
     }
     if (!F16 && a.stats) tile_column_sums(a, Cs, tile, row0, col0, lane);
@@ -667,6 +674,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
     }
 #endif
     B2M_CLOCK_END(0);
+    B2M_RES_END((int64_t)blockIdx.x * WPB + wave, 0);
 }
 #undef tile_column_sums
 #undef B2M_BV

@@ -80,6 +80,9 @@ class _PackedWeights:
     def __init__(self):
         self.entries = {}          # key -> [weakref(weight), args, image, version, data_ptr, pass_id]
         self.plan = None           # (device plan, n, total_blocks, keys)
+        self.split = (None, None, None)
+        self.group = {}
+        self.pending = {}
         self.dirty = True
         self.pass_id = 0
 
@@ -96,6 +99,10 @@ class _PackedWeights:
         key = (id(weight), bool(transpose), bool(mirror), int(slice_begin), int(sc))
         e = self.entries.get(key)
         if e is not None and e[0]() is weight and e[4] == weight.data_ptr():
+            if self.pending:                                         # packed on the side stream in this pass: first user waits
+                ev = self.pending.pop(self.group.get(key), None)
+                if ev is not None:
+                    torch.cuda.current_stream(weight.device).wait_event(ev)
             if e[5] != self.pass_id or e[3] != weight._version:      # not packed in this pass / changed since
                 weight_pack(w3, transpose, mirror, slice_begin, sc, out=e[2])
                 e[3], e[5] = weight._version, self.pass_id
@@ -106,18 +113,13 @@ class _PackedWeights:
         self.dirty = True
         return image
 
-    def _build_plan(self):
+    def _plan_of(self, keys):
+        """Device plan (descriptor table) of the images `keys`: (tensor, n, blocks, keys) or None."""
         import ctypes as C
         import numpy as np
-        dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[4]]
-        for k in dead:
-            del self.entries[k]
-        keys = list(self.entries)
         n = len(keys)
-        self.dirty = False
         if n == 0:
-            self.plan = None
-            return
+            return None
         lib = _lib.load()
         es = [self.entries[k] for k in keys]
         i64 = lambda v: np.ascontiguousarray(v, dtype=np.int64)
@@ -133,7 +135,30 @@ class _PackedWeights:
         if blocks < 0:
             raise _lib.B2MError('b2m_weight_pack_plan failed: ' + lib.b2m_last_error().decode())
         dev = es[0][2].device
-        self.plan = (torch.from_numpy(host).to(dev), n, int(blocks), keys)
+        return (torch.from_numpy(host).to(dev), n, int(blocks), keys)
+
+    # forward images packed on the main stream in front of the first layer: the first EARLY_BYTES of them in order of first use
+    # (the 5x5x5 stem and the encoder's 32- / 64-channel levels; a training pass reaches the first later layer milliseconds in)
+    EARLY_BYTES = 6 << 20
+
+    def _build_plan(self):
+        dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[4]]
+        for k in dead:
+            del self.entries[k]
+        keys = list(self.entries)
+        self.dirty = False
+        self.plan = self._plan_of(keys)
+        # the same images in three groups (pack_on_side_stream): forward images needed first | the other forward images | the
+        # data-gradient images (transposed: needed by the backward pass only)
+        early, late, back, size = [], [], [], 0
+        for k in keys:                              # (registration order = order of first use)
+            if k[1]:
+                back.append(k)
+                continue
+            size += self.entries[k][2].numel() * 4
+            (early if size <= self.EARLY_BYTES else late).append(k)
+        self.split = (self._plan_of(early), self._plan_of(late), self._plan_of(back))
+        self.group = {k: g for g, ks in enumerate((early, late, back)) for k in ks}
 
     def begin_pass(self, inference=False):
         """Open a new pass: repack every registered image from the current weights (one launch).
@@ -152,10 +177,40 @@ class _PackedWeights:
         if self.plan is None:
             return
         plan, n, blocks, keys = self.plan
-        _call('b2m_weight_pack_run', plan.data_ptr(), n, blocks)
+        self.pending = {}                # group -> event the first user of one of its images waits for
+        dev = plan.device
+        if not inference and pack_on_side_stream() and wgrad_on_side_stream() and torch.is_grad_enabled():
+            # A training pass needs a few small images at once and the bulk of them milliseconds later (the 7 MB images of the
+            # 256-channel levels, every data-gradient image): those are packed on the side stream, beside the first layers --
+            # the stem is bound by latency, not by bandwidth -- and whoever asks for one first makes its stream wait (`get`).
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            early, late, back = self.split
+            if early is not None:
+                _call('b2m_weight_pack_run', early[0].data_ptr(), early[1], early[2])
+            side.wait_stream(main)       # the optimizer's update of the weights (and everything before it)
+            with torch.cuda.stream(side):
+                for g, pl in ((1, late), (2, back)):
+                    if pl is not None:
+                        _call('b2m_weight_pack_run', pl[0].data_ptr(), pl[1], pl[2])
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        self.pending[g] = ev
+        else:
+            _call('b2m_weight_pack_run', plan.data_ptr(), n, blocks)
         for k in keys:
             e = self.entries[k]
             e[3], e[5] = e[0]()._version, self.pass_id
+
+    def join(self):
+        """The current stream waits for every image still being packed on the side stream (before anything that reads images
+        outside `get`: nothing in this package does; tests and tools may)."""
+        for g in list(self.pending):
+            torch.cuda.current_stream().wait_event(self.pending.pop(g))
+
+
+def pack_on_side_stream() -> bool:
+    """B2M_PACK_STREAM=0: every weight image of a pass is packed on the main stream in front of the first layer (rounds 1-5)."""
+    return os.environ.get('B2M_PACK_STREAM', '1') == '1'
 
 
 packed_weights = _PackedWeights()

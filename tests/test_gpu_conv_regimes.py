@@ -45,6 +45,8 @@ REGIMES = {
     'atomic_combine': {'B2M_CONV_WGCOMBINE': '0'},
     'no_chunk_slices': {'B2M_CONV_CHUNKSPLIT': '0'},
     'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'},
+    # (round 6) un-split maps as two slices per item, workgroups of two waves (the form B2M_CONV_SPLIT2 gives the medium maps)
+    'two_slices': {'B2M_CONV_TARGET': '0', 'B2M_CONV_SPLIT2': '100000000'},
     'wgrad_plain': {'B2M_WGRAD_PIPE': '0'},
     'wgrad_compiler_tracked_loads': {'B2M_WGRAD_HANDLOADS': '0'},
     'wgrad_hand_issued_loads_square_blocks_only': {'B2M_WGRAD_HANDLOADS': '1'},
@@ -83,7 +85,7 @@ _ORDER = [1, 2, 5, 8]               # dispatch-order switches: one case per rule
 REGIME_CASES = {
     'unsplit': _ALL, 'unsplit_compiler_tracked_loads': _ALL,
     'split_compiler_tracked_loads': _SPLIT, 'unsplit_32_column_strips': [1, 2, 4, 8, 9], 'atomic_combine': _SPLIT,
-    'no_chunk_slices': _SPLIT, 'many_slices': _SPLIT, 'wgrad_plain': _WGRAD, 'wgrad_compiler_tracked_loads': _WGRAD,
+    'no_chunk_slices': _SPLIT, 'many_slices': _SPLIT, 'two_slices': _ALL, 'wgrad_plain': _WGRAD, 'wgrad_compiler_tracked_loads': _WGRAD,
     'wgrad_hand_issued_loads_square_blocks_only': _WGRAD, 'wgrad_64_tile_chunks': _WGRAD,
     'wgrad_of_transposed_maps_over_the_up_rulebook': [8, 9], 'wgrad_one_offset_per_workgroup': [0, 5, 6],
     'deterministic': [1, 3, 6, 8, 9], 'deterministic_up_rulebook': [8, 9],
@@ -290,7 +292,7 @@ def test_dense_equivalence_k2s2_and_transpose_random_occupancy(cin, cout):
 
 
 # ------------------------------------------------------------------ 4. BatchNorm statistics from the convolution's epilogue
-@pytest.mark.parametrize('regime', ['unsplit', 'split4', 'many_slices', 'unsplit_two_launch_reduction'])
+@pytest.mark.parametrize('regime', ['unsplit', 'split4', 'split2', 'many_slices', 'unsplit_two_launch_reduction'])
 @pytest.mark.parametrize('cin,cout', [(96, 96), (32, 64), (64, 128)])
 def test_conv_tile_stats_feed_batchnorm(maps, monkeypatch, regime, cin, cout):
     """b2m_conv_fwd_stats: the per-tile column sums the convolution kernel leaves behind equal the sums of its output,
@@ -302,7 +304,7 @@ def test_conv_tile_stats_feed_batchnorm(maps, monkeypatch, regime, cin, cout):
     if regime == 'unsplit_two_launch_reduction':
         monkeypatch.setenv('B2M_BN_TS_ONE', '0')
         regime = 'unsplit'
-    env = {'unsplit': {'B2M_CONV_TARGET': '0'}, 'split4': {'B2M_CONV_TARGET': '800', 'B2M_CONV_CHUNKSPLIT': '0'}, 'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'}}
+    env = {'unsplit': {'B2M_CONV_TARGET': '0'}, 'split2': {'B2M_CONV_TARGET': '0', 'B2M_CONV_SPLIT2': '100000000'}, 'split4': {'B2M_CONV_TARGET': '800', 'B2M_CONV_CHUNKSPLIT': '0'}, 'many_slices': {'B2M_CONV_TARGET': '100000', 'B2M_CONV_MAXSLICE': '16'}}
     for k, v in env[regime].items():
         monkeypatch.setenv(k, v)
     m, _ = maps

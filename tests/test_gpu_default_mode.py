@@ -294,3 +294,42 @@ def test_full_size_scene_forward_matches_oracle(monkeypatch):
     errs['vox_feats'] = _rel(trunk, ref['_trunk'])
     print('full-size scene (%d voxels, %d rows at level 7): rel errors %s' % (n, sin.manager.n(7), errs))
     assert max(errs.values()) < 1e-3, errs
+
+
+@pytest.mark.gpu
+def test_weight_images_packed_on_the_side_stream_follow_the_optimizer(monkeypatch):
+    """A training pass packs the images of its first layers on the main stream and the rest -- the late forward images, every
+    data-gradient image -- on the side stream, beside the first layers (functional._PackedWeights.begin_pass); the first user of
+    such an image waits for it.  Four Adam steps at a large learning rate (3e-3) with that (default) and with B2M_PACK_STREAM=0 (every
+    image in front of the first layer): an image that missed an optimizer update, or was read before it was complete, would move
+    the losses by per cent; they agree to the run-to-run noise of the default mode's atomics."""
+    from box2mask_amd import functional as F_
+    from box2mask_amd.model import Model
+    _default_env(monkeypatch)
+    batch = synth.make_batch(4, seed0=21, target_voxels=20000, pts_per_m2=8000.0)
+
+    def run(side):
+        monkeypatch.setenv('B2M_PACK_STREAM', '1' if side else '0')
+        torch.manual_seed(11)
+        model = Model(scannet_config(), *synth.scannet_tables())
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=3e-3, fused=True)
+        losses, split = [], []
+        for _ in range(4):
+            opt.zero_grad()
+            ld = model.compute_loss(batch, 150)
+            split.append(sorted(F_.packed_weights.pending))          # image groups still guarded by an event after the forward pass
+            ld['optimization_loss'].backward()
+            opt.step()
+            losses.append(float(ld['optimization_loss']))
+        torch.cuda.synchronize()
+        return losses, split
+    a, split_a = run(True)
+    b, split_b = run(False)
+    print('losses, images on the side stream', a, 'on the main stream', b)
+    # from the second pass on the plan exists: the late forward images were taken (waited for) during the forward pass, the
+    # data-gradient images are still pending when backward begins
+    assert split_a[1:] == [[2]] * 3 and split_b == [[]] * 4, (split_a, split_b)
+    assert a[0] != a[1] and a[1] != a[2]                                  # (the weights move: a 3e-3 Adam step is ~6 % of a weight)
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 5e-3 * abs(y), (a, b)
