@@ -217,11 +217,24 @@ class SelectionNet(ResNetBase):
             if n_segments is None:
                 n_segments = int(pooling_ids.max().item()) + 1
             out = ME.PooledTensor(F_.segment_pool(out.F, pooling_ids, n_segments, mode))
+        # The heads that read the pooled features are independent of one another and layer-for-layer alike (conv1x1-ReLU-BN x2,
+        # conv1x1): they run in lockstep, so that under SyncBN the BatchNorms at equal depth share one statistics exchange per
+        # direction (ME.batch_norm_group; a single process runs every layer by itself, as before)
+        shared = [h for h in self.cfg.network_heads if not (self.requires_voxel_outputs and 'per_vox' in h)]
+        seqs = [self.network_heads[h] for h in shared]
+        if len(seqs) > 1 and len({len(sq) for sq in seqs}) == 1:
+            ts = [out] * len(seqs)
+            for stage in range(len(seqs[0])):
+                layers = [sq[stage] for sq in seqs]
+                if all(isinstance(l, ME.MinkowskiBatchNorm) for l in layers):
+                    ts = ME.batch_norm_group(layers, ts)
+                else:
+                    ts = [l(t) for l, t in zip(layers, ts)]
+            outputs.update(zip(shared, ts))
         for network_head in self.cfg.network_heads:
-            if self.requires_voxel_outputs and 'per_vox' in network_head:
-                outputs[network_head] = self.network_heads[network_head](outputs['vox_feats'])
-            else:
-                outputs[network_head] = self.network_heads[network_head](out)
+            if network_head not in outputs:
+                src = outputs['vox_feats'] if (self.requires_voxel_outputs and 'per_vox' in network_head) else out
+                outputs[network_head] = self.network_heads[network_head](src)
             if self.cfg.mlp_bounds_relu and network_head == self.cfg.mlp_bounds:
                 outputs[network_head] = self.relu(outputs[network_head])
         if perm is not None:

@@ -240,6 +240,27 @@ def batch_norm_add_relu(norm_a: MinkowskiBatchNorm, feats_a, norm_b: MinkowskiBa
     return F_.batch_norm_pair(feats_a, pa, feats_b, pb, tr_a, relu, norm_a.sync, count_key)
 
 
+def batch_norm_group(norms, tensors):
+    """[norm_j(x_j)] for BatchNorm layers that do not depend on one another and see the same rows (the heads' layers at equal
+    depth): under SyncBN in training mode ONE packed statistics exchange per direction for all of them
+    (functional._BatchNormGroup); otherwise -- a single process, eval mode, one member, B2M_BN_GROUP=0 -- every layer by itself."""
+    import os
+    sync = F_._sync_group() if all(nm.sync for nm in norms) else None
+    same_rows = len({t.F.shape[0] for t in tensors}) == 1
+    ok = (sync is not None and len(norms) > 1 and same_rows and all(nm.training for nm in norms) and
+          all(t.F.shape[1] % 4 == 0 and t.F.shape[1] <= 1024 for t in tensors) and tensors[0].F.shape[0] > 1 and
+          os.environ.get('B2M_BN_GROUP', '1') == '1')
+    if not ok:
+        return [nm(t) for nm, t in zip(norms, tensors)]
+    members = []
+    for nm, t in zip(norms, tensors):
+        training, (w, b, rm, rv, mom, eps) = nm._begin(t.F, _defer_all[0])
+        assert training
+        members.append((t.F, w, b, rm, rv, mom, eps))
+    ys = F_.batch_norm_group(members, sync)
+    return [t.new(y) for t, y in zip(tensors, ys)]
+
+
 _pending_counters = []
 _defer_all = [False]
 

@@ -300,36 +300,41 @@ def test_full_size_scene_forward_matches_oracle(monkeypatch):
 def test_weight_images_packed_on_the_side_stream_follow_the_optimizer(monkeypatch):
     """A training pass packs the images of its first layers on the main stream and the rest -- the late forward images, every
     data-gradient image -- on the side stream, beside the first layers (functional._PackedWeights.begin_pass); the first user of
-    such an image waits for it.  Four Adam steps at a large learning rate (3e-3) with that (default) and with B2M_PACK_STREAM=0 (every
-    image in front of the first layer): an image that missed an optimizer update, or was read before it was complete, would move
-    the losses by per cent; they agree to the run-to-run noise of the default mode's atomics."""
+    such an image waits for it.  Four optimizer steps: after every pass EVERY registered image must be, bit for bit, the image of
+    the weights as the optimizer left them before that pass (an image that missed an update, or was packed from weights the
+    optimizer was still writing, differs), and the groups are where the design says: the late forward images were waited for
+    during the forward pass, the data-gradient images are still guarded when backward begins.  (A trajectory comparison cannot
+    do this job in the default mode: with a handful of rows at the deepest level the atomics' rounding noise alone moves the
+    second loss of two identical runs by 4e-4.)"""
     from box2mask_amd import functional as F_
     from box2mask_amd.model import Model
     _default_env(monkeypatch)
     batch = synth.make_batch(4, seed0=21, target_voxels=20000, pts_per_m2=8000.0)
-
-    def run(side):
-        monkeypatch.setenv('B2M_PACK_STREAM', '1' if side else '0')
-        torch.manual_seed(11)
-        model = Model(scannet_config(), *synth.scannet_tables())
-        model.train()
-        opt = torch.optim.Adam(model.parameters(), lr=3e-3, fused=True)
-        losses, split = [], []
-        for _ in range(4):
-            opt.zero_grad()
-            ld = model.compute_loss(batch, 150)
-            split.append(sorted(F_.packed_weights.pending))          # image groups still guarded by an event after the forward pass
-            ld['optimization_loss'].backward()
-            opt.step()
-            losses.append(float(ld['optimization_loss']))
+    torch.manual_seed(11)
+    model = Model(scannet_config(), *synth.scannet_tables())
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3, fused=True)
+    pw = F_.packed_weights
+    for step in range(4):
+        opt.zero_grad()
+        ld = model.compute_loss(batch, 150)
+        guarded = sorted(pw.pending)
+        ld['optimization_loss'].backward()
         torch.cuda.synchronize()
-        return losses, split
-    a, split_a = run(True)
-    b, split_b = run(False)
-    print('losses, images on the side stream', a, 'on the main stream', b)
-    # from the second pass on the plan exists: the late forward images were taken (waited for) during the forward pass, the
-    # data-gradient images are still pending when backward begins
-    assert split_a[1:] == [[2]] * 3 and split_b == [[]] * 4, (split_a, split_b)
-    assert a[0] != a[1] and a[1] != a[2]                                  # (the weights move: a 3e-3 Adam step is ~6 % of a weight)
-    for x, y in zip(a, b):
-        assert abs(x - y) <= 5e-3 * abs(y), (a, b)
+        if step >= 1:                       # (the first pass registers the images one by one; from the second on the plan exists)
+            assert guarded == [2], guarded
+            sizes = [sum(1 for g in pw.group.values() if g == j) for j in range(3)]
+            assert min(sizes) > 0, sizes    # every group is populated: early / late forward images, data-gradient images
+        bad = []
+        for key, e in pw.entries.items():
+            w = e[0]()
+            if w is None:
+                continue
+            K, cin, cout, transpose, mirror, sb, sc = e[1]
+            w3 = w.detach() if w.dim() == 3 else w.detach().unsqueeze(0)
+            fresh = F_.weight_pack(w3, transpose, mirror, sb, sc)
+            if not torch.equal(fresh, e[2]):
+                bad.append((key[1:], tuple(w.shape)))
+        assert not bad, (step, len(bad), bad[:4])
+        opt.step()
+    assert len(pw.entries) > 150

@@ -87,8 +87,13 @@ def test_syncbn_execution_modes_agree_two_ranks():
     # the few ReLU decisions that flip differ from run to run, and with them the worst gradient figure)
     det = {'B2M_DETERMINISTIC': '1'}
     base = _run_two_ranks('gloo', det)
-    for what, env in (('unpaired', {'B2M_BN_PAIR': '0'}), ('two-stage small maps', {'B2M_BN_SMALL_ROWS': '0'})):
+    for what, env in (('unpaired', {'B2M_BN_PAIR': '0'}), ('two-stage small maps', {'B2M_BN_SMALL_ROWS': '0'}),
+                      ('heads layer by layer', {'B2M_BN_GROUP': '0'})):
         other = _run_two_ranks('gloo', dict(det, **env))
+        if what == 'heads layer by layer':
+            # (round 6) by default the four heads' BatchNorms at equal depth share ONE exchange per direction
+            # (functional._BatchNormGroup): 4 x 2 layers x 2 directions = 16 exchanges become 4
+            assert other[0]['syncbn'] - base[0]['syncbn'] == 12, (base[0]['syncbn'], other[0]['syncbn'])
         for r in (0, 1):
             a, b = base[r]['named'], other[r]['named']
             assert set(a) == set(b) and len(a) > 250
@@ -102,6 +107,8 @@ def test_syncbn_execution_modes_agree_two_ranks():
             assert float(np.percentile(list(rel.values()), 95)) < 0.05, (what, r)
             bn = max((v, n) for n, v in rel.items() if 'downsample.1.bn' in n or 'norm2.bn' in n)
             assert bn[0] < 0.5, (what, r, bn)
+            hb = max((v, n) for n, v in rel.items() if n.startswith('mlp_') and '.bn.' in n)
+            assert hb[0] < 0.5, (what, r, hb)
             for h in base[r]['pred']:
                 e = np.abs(base[r]['pred'][h] - other[r]['pred'][h]).max() / max(np.abs(other[r]['pred'][h]).max(), 1e-9)
                 assert e < 1e-3, (what, r, h, e)
