@@ -258,6 +258,7 @@ def main():
     # on a second stream while this step's network runs, as a training loop with a data loader one batch ahead would do.
     # Every step still builds exactly one batch's maps inside the timed region (the one it hands to the next step).
     PREFETCH = os.environ.get('B2M_BENCH_PREFETCH', '1') != '0'
+    PREFETCH_AT = os.environ.get('B2M_BENCH_PREFETCH_AT', 'now')
     prefetch_on = [True]
     cursor = [0]                        # steps taken: step i trains on cycle[i % len(cycle)] and prefetches the one after it
     cycle = [batches]                   # (the H2D pass swaps in the pinned-host forms of the same batches)
@@ -269,11 +270,18 @@ def main():
         nxt = cycle[0][(cursor[0] + 1) % len(cycle[0])]
         cursor[0] += 1
         opt.zero_grad()                 # torch default (set_to_none=True), as the reference's train_step
-        losses = model.compute_loss(cur['step'] if 'step' in cur else cur, 150)
+        cur_b = cur['step'] if 'step' in cur else cur
+        ev0 = None
+        if PREFETCH_AT == 'forward':
+            ev0 = torch.cuda.Event()
+            ev0.record()                # the device reaches this point when the step's forward pass begins
+        losses = model.compute_loss(cur_b, 150)
         if PREFETCH and prefetch_on[0]:
-            # (ready=True: the next batch's tensors were complete before this step was enqueued -- device tensors from
-            # setup, or the pinned host buffers of the H2D pass)
-            model.prefetch(nxt['prefetch'] if 'prefetch' in nxt else nxt, ready=True)
+            # ready=True: the next batch's tensors were complete before this step was enqueued (device tensors from setup, or the
+            # pinned host buffers of the H2D pass) -- the side stream starts at once, i.e. wherever the device is while the host
+            # runs ahead.  B2M_BENCH_PREFETCH_AT=forward: the side stream waits for the start of THIS step's forward pass, the one
+            # phase of a step that runs on a single stream (experiment, profiles/r06_analysis.md)
+            model.prefetch(nxt['prefetch'] if 'prefetch' in nxt else nxt, ready=ev0 if ev0 is not None else True)
         losses['optimization_loss'].backward()      # (N > 1: the gradient all-reduce completes inside backward)
         opt.step()
         return losses

@@ -310,7 +310,9 @@ extern "C" int b2m_bn_tilestats_finalize(const double* tile_stats, int64_t ntile
                                          float* shift, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(tile_stats && partial && scale && shift && ntiles >= 1 && n >= 1 && c > 0 && c <= 1024, "bad arguments");
-    if (ntiles <= b2m_env_int("B2M_BN_TS_ONE", 8192)) {
+    // (round 6: 8192 -> 2048 tiles.  A workgroup of the one-launch form owns 8 channels over ALL tiles: 4 workgroups for a 32-channel
+    // layer, 26 us on the 4.5 k tiles of level 1 where the two-launch reduction takes 10.)
+    if (ntiles <= b2m_env_int("B2M_BN_TS_ONE", 2048)) {
         bn_tilestats_finalize_one_kernel<<<(c + 7) / 8, 256, 0, st>>>(tile_stats, ntiles, (double)n, c, gamma, beta, eps, momentum,
                                                                       running_mean, running_var, mean, invstd, scale, shift, stats);
         B2M_LAUNCH_CHECK();

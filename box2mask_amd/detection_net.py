@@ -219,10 +219,11 @@ class SelectionNet(ResNetBase):
             out = ME.PooledTensor(F_.segment_pool(out.F, pooling_ids, n_segments, mode))
         # The heads that read the pooled features are independent of one another and layer-for-layer alike (conv1x1-ReLU-BN x2,
         # conv1x1): they run in lockstep, so that under SyncBN the BatchNorms at equal depth share one statistics exchange per
-        # direction (ME.batch_norm_group; a single process runs every layer by itself, as before)
+        # direction (ME.batch_norm_group)
         shared = [h for h in self.cfg.network_heads if not (self.requires_voxel_outputs and 'per_vox' in h)]
         seqs = [self.network_heads[h] for h in shared]
-        if len(seqs) > 1 and len({len(sq) for sq in seqs}) == 1:
+        lockstep = self.training and F_._sync_group() is not None        # (one process: head by head, the reference's order)
+        if lockstep and len(seqs) > 1 and len({len(sq) for sq in seqs}) == 1:
             ts = [out] * len(seqs)
             for stage in range(len(seqs[0])):
                 layers = [sq[stage] for sq in seqs]

@@ -658,7 +658,10 @@ def conv_tile_stats() -> bool:
 def bn_small_rows() -> int:
     """B2M_BN_SMALL_ROWS: training-mode BatchNorm of maps with at most this many rows runs as ONE launch each way
     (b2m_bn_small_fwd / _bwd; 0 switches it off); under SyncBN as two half-kernels around the statistics exchange."""
-    return min(int(os.environ.get('B2M_BN_SMALL_ROWS', '4096')), 16384)       # (B2M_BN_SMALL_MAX_ROWS of the library)
+    # (round 6: 4096 -> 2048.  The one-launch kernel gives a workgroup four channels of EVERY row -- 16 bytes per row and
+    # workgroup, 64 workgroups for 256 channels -- and at 3 k rows takes 25-33 us where statistics-from-tile-sums + apply take
+    # 11; launches cost the untraced step nothing (profiles/r06_analysis.md): BatchNorm 8.31 -> 8.01 ms per step.)
+    return min(int(os.environ.get('B2M_BN_SMALL_ROWS', '2048')), 16384)       # (B2M_BN_SMALL_MAX_ROWS of the library)
 
 
 def conv_passthrough() -> bool:

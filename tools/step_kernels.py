@@ -25,6 +25,9 @@ def main():
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '?')))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if r[2].startswith('weight_pack_batch_kernel')]
+    # (round 6: a training pass packs its images in up to three launches, the later ones on the side stream: a step begins at
+    # the first pack launch that follows the previous one by more than 5 ms)
+    marks = [i for j, i in enumerate(marks) if j == 0 or rows[i][0] - rows[marks[j - 1]][0] > 5_000_000]
     lo = int(sys.argv[2]) if len(sys.argv) > 2 else -24
     hi = int(sys.argv[3]) if len(sys.argv) > 3 else -20
     steps = list(zip(marks, marks[1:]))[lo:hi]

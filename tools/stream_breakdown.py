@@ -22,6 +22,7 @@ def main():
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Stream_Id', '?'), r.get('Queue_Id', '?')))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if r[2].startswith('weight_pack_batch_kernel')]
+    marks = [i for j, i in enumerate(marks) if j == 0 or rows[i][0] - rows[marks[j - 1]][0] > 5_000_000]   # (round 6: up to three pack launches per pass)
     for a, b in list(zip(marks, marks[1:]))[-3:]:
         seq = rows[a:b]
         wall = (seq[-1][1] - seq[0][0]) / 1e6
