@@ -29,6 +29,9 @@ PINNED = {
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi1ELi0ELi0EEv8ConvArgs': (128, 4, True),
     '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi4ELi1ELi0ELi0EEv8ConvArgs': (168, 3, True),
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi4ELi1ELi0ELi0EEv8ConvArgs': (128, 4, True),
+    # (round 6) two slices per item, workgroups of two waves (B2M_CONV_SPLIT2, off by default)
+    '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi2ELi1ELi0ELi0EEv8ConvArgs': (168, 3, True),
+    '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi2ELi1ELi0ELi0EEv8ConvArgs': (128, 4, True),
     # the half-precision inference variants (b2m_conv_fwd_h): 32-channel chunks with 2 / 3 steps in flight, 16-channel chunks
     '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1ELi1ELi1ELi0EEv8ConvArgs': (168, 3, True),
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi1ELi1ELi0EEv8ConvArgs': (128, 4, True),
@@ -119,7 +122,7 @@ def test_nothing_touches_a_register_of_a_load_in_flight(kernels, name):
     in the source -- the statement that waits is the only reader -- and this is the check that it stays cured; the trace also
     proves the counts themselves: an MFMA reading an operand whose load is still among the N youngest is reported.)"""
     import isa_check
-    assert len(HAND_ISSUED) == 30, HAND_ISSUED      # 12 forward variants + 9 weight-gradient block shapes x {plain, exchanged row roles}
+    assert len(HAND_ISSUED) == 32, HAND_ISSUED      # 14 forward variants (round 6: + the two-slice form) + 9 weight-gradient block shapes x {plain, exchanged row roles}
     body = isa_check.kernel_body(isa_check.device_asm(), name)
     assert sum(1 for i, l in enumerate(body) if 'global_load' in l and 'ASMSTART' in body[i - 1] + body[i - 2] + body[i - 3]) >= 8
     assert isa_check.inflight_violations(body) == []
