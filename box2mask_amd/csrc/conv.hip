@@ -987,7 +987,8 @@ static int conv_fwd_impl(const float* x1, int64_t ldx1, int32_t c1, const float*
     // chunk steps gets short; the slices still combine in LDS / with atomics
     int ncs = 1;
     const int nchunk_h = (cin + KC - 1) / KC;
-    while (nslice > 1 && ncs < 4 && items0 * nslice * ncs < 2048 && nchunk_h / (ncs * 2) >= 2 && env_flag("B2M_CONV_CHUNKSPLIT", 1)) ncs *= 2;
+    while (nslice > 1 && ncs < 4 && items0 * nslice * ncs < env_flag("B2M_CONV_CHUNK_ITEMS", 2048) && nchunk_h / (ncs * 2) >= 2 &&
+           env_flag("B2M_CONV_CHUNKSPLIT", 1)) ncs *= 2;
     nslice *= ncs;
     // (round 6) medium maps that run un-split -- a few rounds of long-lived waves, tools/residency.py: 14-18 % of such a launch is
     // its drain -- as TWO slices per item (workgroups of two waves that combine in LDS): half the wave lifetime, half the drain.

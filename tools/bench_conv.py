@@ -36,7 +36,7 @@ for spec in os.environ.get('VARIANTS', 'tw2:B2M_CONV_TW3=0;slow64:B2M_WGRAD_FAST
     if spec:
         name, kvs = spec.split(':')
         VARIANTS.append((name, dict(kv.split('=') for kv in kvs.split(','))))
-SWITCHES = ('B2M_CONV_SPLIT2', 'B2M_WGRAD_UP', 'B2M_WGRAD_LDS', 'B2M_CONV_CHAIN', 'B2M_WGRAD_HANDLOADS', 'B2M_CONV_HANDLOADS', 'B2M_PIPE_DBG', 'B2M_CONV_UP', 'B2M_CONV_UP_MIN_ITEMS', 'B2M_CONV_STEM', 'B2M_WGRAD_NARROW', 'B2M_WGRAD_PIPE_IDENT', 'B2M_WGRAD_KPACK', 'B2M_CONV_1X1', 'B2M_XCD_ORDER', 'B2M_XCD_BALANCE', 'B2M_CONV_FLOW_SPLIT', 'B2M_CONV_PIPE', 'B2M_CONV_TW3', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_CONV_MAXSLICE')
+SWITCHES = ('B2M_CONV_CHUNK_ITEMS', 'B2M_CONV_SPLIT2', 'B2M_WGRAD_UP', 'B2M_WGRAD_LDS', 'B2M_CONV_CHAIN', 'B2M_WGRAD_HANDLOADS', 'B2M_CONV_HANDLOADS', 'B2M_PIPE_DBG', 'B2M_CONV_UP', 'B2M_CONV_UP_MIN_ITEMS', 'B2M_CONV_STEM', 'B2M_WGRAD_NARROW', 'B2M_WGRAD_PIPE_IDENT', 'B2M_WGRAD_KPACK', 'B2M_CONV_1X1', 'B2M_XCD_ORDER', 'B2M_XCD_BALANCE', 'B2M_CONV_FLOW_SPLIT', 'B2M_CONV_PIPE', 'B2M_CONV_TW3', 'B2M_CONV_FAST32', 'B2M_WGRAD_FAST32', 'B2M_XCD', 'B2M_WGRAD_PIPE', 'B2M_CONV_WGCOMBINE', 'B2M_CONV_CHUNKSPLIT', 'B2M_WGRAD_MIN_TILES', 'B2M_CONV_TARGET', 'B2M_CONV_MAXSLICE')
 cases = [('L0 k3 96->96', rb0, 27, 96, 0, 96), ('L0 k3 128(96|32)->96', rb0, 27, 96, 32, 96), ('L0 k3 32->32', rb0, 27, 32, 0, 32),
          ('L1 k3 96->96', rb1, 27, 96, 0, 96), ('L1 k3 32->32', rb1, 27, 32, 0, 32), ('L0 up 96->96', rbu, 8, 96, 0, 96), ('L0 k5 8->32', rb5, 125, 8, 0, 32),
          ('L0 1x1 128->96', None, 1, 128, 0, 96), ('L1 k3 128->128', rb1, 27, 128, 0, 128), ('L1 k3 64->64', rb1, 27, 64, 0, 64),
