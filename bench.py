@@ -289,15 +289,18 @@ def main():
     # one-time setup, not part of --warmup: the first two steps register the packed weight images, grow the caching
     # allocator's pools and JIT the fused optimiser kernel (reported as config.setup_steps)
     SETUP_STEPS = 2
-    for _ in range(SETUP_STEPS + args.warmup):
+    for i_ in range(SETUP_STEPS + args.warmup):
         step()
-        rb_lookup.clear()
+        # (not after the last one: its prefetch built the maps of the first timed step -- cleared, that step's launches counted
+        # no FLOPs in `roofline_timed_region`, 5 % of the region's sum in rounds 2-5)
+        if i_ < SETUP_STEPS + args.warmup - 1:
+            rb_lookup.clear()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     # `roofline_timed_region`: HIP events around the dominant kernel's launches INSIDE the timed region -- on every
-    # TIMED_EVERY-th step only (default 5: steps 0, 5, 10, ...): two events per launch on 199 launches cost the step 1.5-2 %
+    # TIMED_EVERY-th step only (default 5: steps 2, 7, 12, ...): two events per launch on 199 launches cost the step 1.5-2 %
     # (the H2D-inclusive repeat, which carries none, used to come out FASTER than the headline: 117.0 against 114.8 scenes/s),
     # and the headline should not pay for its own instrumentation.  B2M_BENCH_TIMED_EVENTS=1: every step (rounds 1-5); 0: none.
     TIMED_EVERY = int(os.environ.get('B2M_BENCH_TIMED_EVENTS', '5'))
@@ -307,7 +310,7 @@ def main():
     cstat.update(syncbn=0, grad_buckets=0, bytes=0)
     t_start = time.perf_counter()
     for i_ in range(args.steps):
-        timer.enabled = TIMED_EVERY > 0 and i_ % TIMED_EVERY == 0
+        timer.enabled = TIMED_EVERY > 0 and i_ % TIMED_EVERY == min(TIMED_EVERY // 2, args.steps - 1)
         timed_steps_sampled += int(timer.enabled)
         losses = step()
     torch.cuda.synchronize()
@@ -446,6 +449,32 @@ def main():
         os.environ['B2M_WGRAD_STREAM'] = prev_wgrad_stream
     _lib.reload_env()
     prefetch_on[0] = True
+
+    # ---- `--features f16`: the same K steps with the trunk's activations and their gradients in half (half_train.py; BASELINE
+    # configs[4] -- never the headline, never the default).  Same batches, same optimizer, fp32 master weights, static loss scale.
+    train_f16 = None
+    if args.features == 'f16' and world == 1:
+        model.detection_model.half_training = True
+        try:
+            cursor[0] = 0
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t_q = time.perf_counter()
+            for _ in range(args.steps):
+                lq = step()
+            torch.cuda.synchronize()
+            el_q = time.perf_counter() - t_q
+            train_f16 = {'ms_per_step': round(el_q / args.steps * 1e3, 2),
+                         'value': round(world * workload['batch_size'] * args.steps / el_q, 3), 'unit': 'scenes/s',
+                         'speedup_vs_f32_step': round(elapsed / el_q, 3),
+                         'loss_scale': float(getattr(cfg, 'half_loss_scale', 1024.0)),
+                         'final_loss': round(float(lq['optimization_loss'].item()), 4),
+                         'what': 'the timed step with SelectionNet.half_training: activations and activation gradients of the trunk '
+                                 'as IEEE half in HBM (b2m_conv_fwd_h forward + data gradient, b2m_conv_wgrad_h, b2m_bn_*_h), fp32 stem, '
+                                 'pooling, heads, master weights and Adam; weight gradient on the fp32 MFMA (operands converted on load)'}
+        finally:
+            model.detection_model.half_training = False
 
     if rank != 0:
         if world > 1:
@@ -593,6 +622,7 @@ def main():
                                 if PREFETCH else 'off'),
                    'collectives': collectives,
                    'steps_executed': SETUP_STEPS + args.warmup + (4 if args.side_passes else 2) * args.steps + (3 if args.side_passes else 1) + (1 if world > 1 else 0)},
+        'train_f16': train_f16,
         'roofline': roofline, 'roofline_timed_region': roofline_timed, 'roofline_wgrad': roofline_wgrad,
         # an HBM-bound kernel of the path, same live HIP-event method: BatchNorm apply (+residual, +ReLU) streams
         # 2-3 tensors per launch; small deep-level layers (launch-latency bound) are part of the average

@@ -24,6 +24,8 @@ def scannet_config(**overrides):
         eval_ths=[0.5, 0.05, 0.3, 0.6],                                                    # configs/scannet.txt:15
         checkpoint_path='experiments/scannet/checkpoints/', voxel_size=0.02, batch_size=8, lr=1e-3,
         half_inference=False,        # build extension (no reference field): inference on half activations, see model.Model
+        half_training=False,         # build extension: training passes with the trunk's activations / gradients in half (half_train.py)
+        half_loss_scale=1024.0,      # ... and the factor its gradients are scaled by inside the half region (a power of two)
     )
     for k, v in overrides.items():
         setattr(cfg, k, v)

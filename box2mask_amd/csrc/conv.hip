@@ -1240,8 +1240,10 @@ extern "C" int64_t b2m_weight_pack_h_size(int32_t K, int32_t c1, int32_t c2, int
     const int TW = conv_tw(cout, K);
     return (int64_t)K * ((cout + 16 * TW - 1) / (16 * TW)) * ((c1 + c2) / conv_h_ck(c1, c2)) * (64 * TW * (conv_h_ck(c1, c2) / 4));
 }
-__global__ void weight_pack_h_kernel(const float* __restrict__ w, int64_t ldw, int K, int cin, int cout, int CK, int TW,
-                                     _Float16* __restrict__ wp, int64_t total) {
+// (source element of logical weight (k, ci, co): w[kk * sk + ci * sci + co * sco], kk = mirror ? K - 1 - k : k -- the plain image
+// has sk = cin * ldw, sci = ldw, sco = 1; the image of the TRANSPOSED weights, the data gradient's operand, exchanges sci and sco)
+__global__ void weight_pack_h_kernel(const float* __restrict__ w, int64_t sk, int64_t sci, int64_t sco, int mirror, int K, int cin,
+                                     int cout, int CK, int TW, _Float16* __restrict__ wp, int64_t total) {
     const int E = CK / 4, SW = 16 * TW, BLK = 64 * TW * E;
     const int nchunk = cin / CK, nstrip = (cout + SW - 1) / SW;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -1251,7 +1253,8 @@ __global__ void weight_pack_h_kernel(const float* __restrict__ w, int64_t ldw, i
         const int chunk = (int)(blk % nchunk); const int64_t b2 = blk / nchunk;
         const int strip = (int)(b2 % nstrip), k = (int)(b2 / nstrip);
         const int ci = chunk * CK + E * (lane >> 4) + j, co = strip * SW + 16 * t + (lane & 15);
-        wp[e] = (co < cout) ? (_Float16)w[((int64_t)k * cin + ci) * ldw + co] : (_Float16)0.f;
+        const int kk = mirror ? K - 1 - k : k;
+        wp[e] = (co < cout) ? (_Float16)w[(int64_t)kk * sk + (int64_t)ci * sci + (int64_t)co * sco] : (_Float16)0.f;
     }
 }
 extern "C" int b2m_weight_pack_h(const float* w, int64_t ldw, int32_t K, int32_t c1, int32_t c2, int32_t cout, void* wp, void* stream) {
@@ -1260,8 +1263,23 @@ extern "C" int b2m_weight_pack_h(const float* w, int64_t ldw, int32_t K, int32_t
     const int64_t total = b2m_weight_pack_h_size(K, c1, c2, cout);
     int64_t grid = (total + 255) / 256;
     if (grid > 65536) grid = 65536;
-    weight_pack_h_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(w, ldw, K, c1 + c2, cout, conv_h_ck(c1, c2), conv_tw(cout, K),
-                                                                         (_Float16*)wp, total);
+    weight_pack_h_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(w, (int64_t)(c1 + c2) * ldw, ldw, 1, 0, K, c1 + c2, cout,
+                                                                         conv_h_ck(c1, c2), conv_tw(cout, K), (_Float16*)wp, total);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+// Half image of the TRANSPOSED weights for the data gradient through b2m_conv_fwd_h (half-precision training): the layer's fp32
+// weights W (K, cin, cout, contiguous) -> the image of W'[k] = W[mirror ? K-1-k : k][s0 : s0 + sc, :]^T, i.e. of a layer with
+// cout input channels and sc output channels (b2m_weight_pack_h_size(K, cout, 0, sc) halfs).
+extern "C" int b2m_weight_pack_h_t(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mirror, int32_t s0, int32_t sc,
+                                   void* wp, void* stream) {
+    B2M_CHECK_ARG(w && wp && K >= 1 && cin > 0 && cout > 0 && s0 >= 0 && sc > 0 && s0 + sc <= cin, "bad arguments");
+    B2M_CHECK_ARG(cout % 16 == 0, "the layer's output channels (the data gradient's input channels) must be a multiple of 16");
+    const int64_t total = b2m_weight_pack_h_size(K, cout, 0, sc);
+    int64_t grid = (total + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    weight_pack_h_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(w + (int64_t)s0 * cout, (int64_t)cin * cout, 1, cout, mirror ? 1 : 0,
+                                                                         K, cout, sc, conv_h_ck(cout, 0), conv_tw(sc, K), (_Float16*)wp, total);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -1361,6 +1379,8 @@ struct WgradArgs {
     int kgroups;              // ceil(K / kpack)
     int handloads;            // conv_wgrad_flow_kernel<.., HL = 1> (B2M_WGRAD_HANDLOADS)
     int swap;                 // b2m_conv_wgrad_tr: x is indexed by the tile's own rows (row0 + rb_out), dy by rb_in
+    int half;                 // b2m_conv_wgrad_h: x and dy are IEEE binary16 (pitches in elements), converted on load; fp32 MFMA, fp32 dW
+    float out_scale;          // ... and the block is multiplied by this on its way into dW (1 / loss scale)
 };
 // work item of a wave -> (offset k, block blk, tile range [t0, t1)); false: nothing to do.  A workgroup is (offset group,
 // block group, tile chunk); its 4 waves are 4 blocks of one offset (kpack = 1) or 4 / kpack blocks of kpack consecutive
@@ -1396,8 +1416,12 @@ __device__ __forceinline__ bool wgrad_item(const WgradArgs& a, int wave, int& k,
     return true;
 }
 
-template <int MI, int NJ>
+// H = 1 (b2m_conv_wgrad_h, half-precision training): the operands are binary16 in memory -- half the gathered bytes --, every
+// element is converted as it is loaded, and the block is accumulated by the same fp32 MFMAs (the f16 MFMA wants four PAIRS per
+// lane where memory holds four CHANNELS per pair: an LDS transpose per slot, not built).
+template <int MI, int NJ, int H = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int ESZ = H ? 2 : 4;            // bytes per operand element
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     int k, blk;
@@ -1430,8 +1454,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             o4 = *(const uint32_t*)(a.rb_out + base);
         }
     };
-    const uint32_t ldx4 = (uint32_t)a.ldx * 4u, lddy4 = (uint32_t)a.lddy * 4u;
-    const uint32_t cxb = (uint32_t)(ci0 + i) * 4u, cyb = (uint32_t)(co0 + i) * 4u;
+    const uint32_t ldx4 = (uint32_t)a.ldx * (uint32_t)ESZ, lddy4 = (uint32_t)a.lddy * (uint32_t)ESZ;
+    const uint32_t cxb = (uint32_t)(ci0 + i) * (uint32_t)ESZ, cyb = (uint32_t)(co0 + i) * (uint32_t)ESZ;
     auto process = [&](int64_t slot, const int (&rin)[4], uint32_t o4) {
         if (__ballot(rin[0] >= 0) == 0) return;        // wave-uniform; also makes the list wait explicit before the gathers
         const int64_t row0 = (slot >> 2) * B2M_TILE;
@@ -1450,10 +1474,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 const char* px = (const char*)a.x + bx;
                 const char* py = (const char*)a.dy + by;
                 if (r >= 0) {
+                    if constexpr (H) {
 #pragma unroll
-                    for (int m = 0; m < MI; ++m) av[s][m] = *(const float*)(px + 64 * m);
+                        for (int m = 0; m < MI; ++m) av[s][m] = (float)*(const _Float16*)(px + 32 * m);
 #pragma unroll
-                    for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = *(const float*)(py + 64 * nn);
+                        for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = (float)*(const _Float16*)(py + 32 * nn);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MI; ++m) av[s][m] = *(const float*)(px + 64 * m);
+#pragma unroll
+                        for (int nn = 0; nn < NJ; ++nn) bv[s][nn] = *(const float*)(py + 64 * nn);
+                    }
                 } else {
 #pragma unroll
                     for (int m = 0; m < MI; ++m) av[s][m] = 0.f;
@@ -1464,12 +1495,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int m = 0; m < MI; ++m) {
                     const int ci = ci0 + 16 * m + i;
-                    av[s][m] = (r >= 0 && ci < a.cin) ? a.x[rx * a.ldx + ci] : 0.f;
+                    if constexpr (H) av[s][m] = (r >= 0 && ci < a.cin) ? (float)((const _Float16*)a.x)[rx * a.ldx + ci] : 0.f;
+                    else av[s][m] = (r >= 0 && ci < a.cin) ? a.x[rx * a.ldx + ci] : 0.f;
                 }
 #pragma unroll
                 for (int nn = 0; nn < NJ; ++nn) {
                     const int co = co0 + 16 * nn + i;
-                    bv[s][nn] = (r >= 0 && co < a.cout) ? a.dy[ry * a.lddy + co] : 0.f;
+                    if constexpr (H) bv[s][nn] = (r >= 0 && co < a.cout) ? (float)((const _Float16*)a.dy)[ry * a.lddy + co] : 0.f;
+                    else bv[s][nn] = (r >= 0 && co < a.cout) ? a.dy[ry * a.lddy + co] : 0.f;
                 }
             }
         }
@@ -1503,7 +1536,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci0 + 16 * m + 4 * q + r, co = co0 + 16 * nn + i;
                 if (ci < a.cin && co < a.cout) {
-                    const float v = acc[m][nn][r];
+                    float v = acc[m][nn][r];
+                    if constexpr (H) v *= a.out_scale;
                     if (a.partial) a.partial[(((int64_t)chunk * a.K + k) * a.cin + ci) * a.cout + co] = v;
                     else if (v != 0.f) atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)ci * a.lddw + co], v);
                 }
@@ -1902,6 +1936,15 @@ static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& 
             return;
         }
     }
+    if (a.half) {
+        switch (NJ) {
+            case 1: conv_wgrad_kernel<MI, 1, 1><<<grid, 256, 0, st>>>(a); break;
+            case 2: conv_wgrad_kernel<MI, 2, 1><<<grid, 256, 0, st>>>(a); break;
+            case 3: conv_wgrad_kernel<MI, 3, 1><<<grid, 256, 0, st>>>(a); break;
+            default: conv_wgrad_kernel<MI, 4, 1><<<grid, 256, 0, st>>>(a); break;
+        }
+        return;
+    }
     switch (NJ) {
         case 1: conv_wgrad_kernel<MI, 1><<<grid, 256, 0, st>>>(a); break;
         case 2: conv_wgrad_kernel<MI, 2><<<grid, 256, 0, st>>>(a); break;
@@ -1940,7 +1983,7 @@ extern "C" int64_t b2m_conv_wgrad_workspace(int32_t K, int32_t cin, int32_t cout
 static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
                            int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                            int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace,
-                           void* stream, int tr);
+                           void* stream, int tr, int half = 0, float out_scale = 1.f);
 extern "C" int b2m_conv_wgrad(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
                               int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                               int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace,
@@ -1961,7 +2004,7 @@ extern "C" int b2m_conv_wgrad_tr(const float* x, int64_t ldx, int32_t cin, int64
 static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_in, const float* dy, int64_t lddy,
                            int32_t cout, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                            int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace,
-                           void* stream, int tr) {
+                           void* stream, int tr, int half, float out_scale) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(x && dy && dw && cin > 0 && cout > 0 && K >= 1 && K <= 65535 && n_in >= 0, "bad pointers/sizes");
     B2M_CHECK_ARG((rb_in == nullptr) == (rb_out == nullptr) && (rb_in == nullptr) == (rb_cnt == nullptr),
@@ -1973,6 +2016,9 @@ static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_i
     if (n_out == 0) return B2M_OK;
     WgradArgs a{};
     a.swap = tr;
+    a.half = half;
+    a.out_scale = out_scale;
+    const int esz = half ? 2 : 4;
     a.x = x; a.ldx = ldx; a.cin = cin; a.dy = dy; a.lddy = lddy; a.cout = cout;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE); a.K = K; a.dw = dw; a.lddw = lddw; a.dw_kstride = dw_kstride;
@@ -1980,7 +2026,7 @@ static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_i
     if (!zeros_addr) B2M_HIP(hipGetSymbolAddress((void**)&zeros_addr, HIP_SYMBOL(g_zeros)));
     a.zeros = zeros_addr;
     // 1x1 layer with few output channels (the heads' last layers): a plain reduction, see wgrad_narrow_kernel
-    if (!tr && rb_in == nullptr && cout <= 32 && cout % 16 != 0 && cin <= 1024 && !workspace && n_in >= n_out && env_flag("B2M_WGRAD_NARROW", 1)) {
+    if (!half && !tr && rb_in == nullptr && cout <= 32 && cout % 16 != 0 && cin <= 1024 && !workspace && n_in >= n_out && env_flag("B2M_WGRAD_NARROW", 1)) {
         const unsigned g = (unsigned)cdiv64(n_out, WGN_ROWS);
         if (cout <= 4) wgrad_narrow_kernel<4><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
         else if (cout <= 8) wgrad_narrow_kernel<8><<<g, 256, 0, st>>>(x, ldx, cin, dy, lddy, cout, n_out, dw, lddw);
@@ -2039,12 +2085,12 @@ static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_i
     // (b2m_conv_wgrad_tr: x has the n_out rows of the tiles, dy the n_in rows the pair lists name)
     const int64_t nx = tr ? n_out : n_in, ny = tr ? n_in : n_out;
     a.fast32 = (ldx >= (int64_t)a.nmb * 16 * MI && lddy >= (int64_t)a.nnb * 16 * NJ && n_out < (1 << 24) && n_in < (1 << 24) &&
-                ldx < (1 << 22) && lddy < (1 << 22) && ny * lddy * 4 < (1ll << 32) && nx * ldx * 4 < (1ll << 32) &&
+                ldx < (1 << 22) && lddy < (1 << 22) && ny * lddy * esz < (1ll << 32) && nx * ldx * esz < (1ll << 32) &&
                 env_flag("B2M_WGRAD_FAST32", 1)) ? 1 : 0;
     // The flat-pipeline kernel for real rulebooks and 32-bit addressable operands.  Its MFMAs are asm statements the
     // compiler's hazard recogniser cannot see: a block with a single accumulator (MI = NJ = 1: consecutive MFMAs on the
     // same registers) stays on the plain kernel, where the builtin lets hipcc place whatever the dependence needs.
-    a.pipe = (a.fast32 && (rb_in != nullptr || (n_in >= n_out && env_flag("B2M_WGRAD_PIPE_IDENT", 1))) && MI * NJ >= 2 &&
+    a.pipe = (!half && a.fast32 && (rb_in != nullptr || (n_in >= n_out && env_flag("B2M_WGRAD_PIPE_IDENT", 1))) && MI * NJ >= 2 &&
               !workspace && env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
     a.handloads = env_flag("B2M_WGRAD_HANDLOADS", 2);
     launch_wgrad(MI, NJ, grid, st, a);
@@ -2056,4 +2102,13 @@ static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_i
     }
     B2M_LAUNCH_CHECK();
     return B2M_OK;
+}
+// Half-precision training: the same reduction with x and dy stored as IEEE binary16 (pitches in elements), dW accumulated in
+// fp32 with atomics (no deterministic form).  tr != 0: the rulebook's row roles exchanged, as b2m_conv_wgrad_tr.
+extern "C" int b2m_conv_wgrad_h(const void* x, int64_t ldx, int32_t cin, int64_t n_in, const void* dy, int64_t lddy, int32_t cout,
+                                const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, int32_t K,
+                                float* dw, int64_t lddw, int64_t dw_kstride, int32_t tr, float out_scale, void* stream) {
+    B2M_CHECK_ARG(((uintptr_t)x % 2) == 0 && ((uintptr_t)dy % 2) == 0, "x / dy must be 2-byte aligned");
+    return conv_wgrad_impl((const float*)x, ldx, cin, n_in, (const float*)dy, lddy, cout, rb_in, rb_out, rb_cnt, n_out, K, dw, lddw,
+                           dw_kstride, nullptr, stream, tr ? 1 : 0, 1, out_scale);
 }

@@ -103,7 +103,7 @@ __device__ __forceinline__ void column_reduce_staged(int64_t n, int c, double* _
 // one wave per output column: lanes sum strided partials, then a fixed-order shuffle tree (deterministic)
 __global__ __launch_bounds__(64) void reduce_final_kernel(const double* __restrict__ partial, int nblk, int c2,
                                                           double* __restrict__ out, float* __restrict__ out_lo,
-                                                          float* __restrict__ out_hi) {
+                                                          float* __restrict__ out_hi, float f32_scale = 1.f) {
     const int j = blockIdx.x;
     double s = 0;
     for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * c2 + j];
@@ -112,8 +112,9 @@ __global__ __launch_bounds__(64) void reduce_final_kernel(const double* __restri
     if (threadIdx.x == 0) {
         out[j] = s;
         const int c = c2 >> 1;          // fp32 copies of the two halves go to two separate buffers
-        if (j < c) { if (out_lo) out_lo[j] = (float)s; }
-        else if (out_hi) out_hi[j - c] = (float)s;
+        // (f32_scale: half-precision training un-scales the parameter gradients here; the fp64 sums stay as they are)
+        if (j < c) { if (out_lo) out_lo[j] = (float)s * f32_scale; }
+        else if (out_hi) out_hi[j - c] = (float)s * f32_scale;
     }
 }
 static int reduce_blocks(int64_t n) {
@@ -510,6 +511,185 @@ extern "C" int b2m_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, i
     bn_bwd_apply_kernel<<<row_grid(n, c / 4), 256, 0, st>>>(dy, lddy, y, ldy, x, ldx, n, c, mean, invstd, gamma, sums,
                                                              count, count_dev, relu, y ? nullptr : mask_scale,
                                                              y ? nullptr : mask_shift, dx, lddx, dres, lddres);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+
+// ------------------------------------------------------------------ half-precision training: BatchNorm with binary16 I/O
+// (round 6; /root/reference/configs/arkitscenes.txt is the workload BASELINE names for it.)  The activations and their gradients live
+// in HBM as IEEE half -- every pass below moves half the bytes of its fp32 twin --; statistics, the per-column constants and
+// all arithmetic stay fp32 / fp64 exactly as above, one rounding to half on the way out.  The ReLU mask is always the stored
+// output's sign (y > 0 on the half value the next layer saw), never recomputed from x: a pre-activation that rounds to +0 must
+// be "off" in both directions.  Pitches in ELEMENTS, multiples of 4; 8-byte aligned rows.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ldh4(const _Float16* p) {
+    const h16x4 v = *(const h16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void sth4(_Float16* p, const f32x4 v) {
+    h16x4 h;
+    h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+    *(h16x4*)p = h;
+}
+__global__ __launch_bounds__(256) void bn_stats_h_kernel(const _Float16* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                         double* __restrict__ partial) {
+    column_reduce_staged<1>(n, c, partial,
+        [&](int64_t r, int cg, f32x4 (&in)[1]) { in[0] = ldh4(x + r * ldx + cg * 4); },
+        [&](const f32x4 (&in)[1], f32x4& a, f32x4& b) { a = in[0]; b = in[0] * in[0]; });
+}
+extern "C" int b2m_bn_stats_h(const void* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(x && partial && stats && c > 0 && c % 4 == 0 && c <= 1024 && ldx % 4 == 0 && ldx >= c && n >= 1,
+                  "c and ldx must be multiples of 4, c <= 1024");
+    B2M_CHECK_ARG(((uintptr_t)x % 8) == 0, "x must be 8-byte aligned");
+    const int nblk = reduce_blocks(n);
+    const int c4 = c / 4, nslots = 256 / c4;
+    bn_stats_h_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>((const _Float16*)x, ldx, n, c, partial);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, stats, nullptr, nullptr);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+// statistics + finalize of a half tensor in two launches (b2m_bn_stats_finalize's half twin)
+extern "C" int b2m_bn_stats_finalize_h(const void* x, int64_t ldx, int64_t n, int32_t c, double* partial, const float* gamma,
+                                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                       float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(x && partial && scale && shift && c > 0 && c % 4 == 0 && c <= 1024 && ldx % 4 == 0 && ldx >= c && n >= 1,
+                  "c and ldx must be multiples of 4, c <= 1024");
+    B2M_CHECK_ARG(((uintptr_t)x % 8) == 0, "x must be 8-byte aligned");
+    const int nblk = reduce_blocks(n);
+    const int c4 = c / 4, nslots = 256 / c4;
+    bn_stats_h_kernel<<<nblk, 256, (size_t)nslots * c4 * 8 * sizeof(float), st>>>((const _Float16*)x, ldx, n, c, partial);
+    bn_final_finalize_kernel<<<c, 64, 0, st>>>(partial, nblk, (double)n, c, gamma, beta, eps, momentum, running_mean, running_var,
+                                               mean, invstd, scale, shift, nullptr);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+__global__ __launch_bounds__(256) void bn_apply_h_kernel(const _Float16* __restrict__ x, int64_t ldx, int64_t n, int c4,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const _Float16* __restrict__ res, int64_t ldr, int relu,
+                                                         _Float16* __restrict__ y, int64_t ldy) {
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    if (rs >= nslots) return;
+    const f32x4 s = *(const f32x4*)(scale + cg * 4), b = *(const f32x4*)(shift + cg * 4);
+    for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
+        f32x4 v = ldh4(x + r * ldx + cg * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_fmaf(v[u], s[u], b[u]);
+        if (res) v += ldh4(res + r * ldr + cg * 4);
+        if (relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = v[u] > 0.f ? v[u] : 0.f;
+        }
+        sth4(y + r * ldy + cg * 4, v);
+    }
+}
+extern "C" int b2m_bn_apply_h(const void* x, int64_t ldx, int64_t n, int32_t c, const float* scale, const float* shift,
+                              const void* residual, int64_t ldr, int32_t relu, void* y, int64_t ldy, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(x && y && scale && shift && c > 0 && c % 4 == 0 && c <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 &&
+                      (!residual || ldr % 4 == 0), "c and leading dimensions must be multiples of 4, c <= 1024");
+    B2M_CHECK_ARG(((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)residual % 8) == 0, "8-byte aligned rows");
+    if (n == 0) return B2M_OK;
+    bn_apply_h_kernel<<<row_grid(n, c / 4), 256, 0, st>>>((const _Float16*)x, ldx, n, c / 4, scale, shift,
+                                                          (const _Float16*)residual, ldr, relu, (_Float16*)y, ldy);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_h_kernel(const _Float16* __restrict__ dy, int64_t lddy,
+                                                              const _Float16* __restrict__ y, int64_t ldy,
+                                                              const _Float16* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              double* __restrict__ partial) {
+    const int c4 = c >> 2, mycg = (threadIdx.x % c4) * 4;
+    const f32x4 m = *(const f32x4*)(mean + mycg), is = *(const f32x4*)(invstd + mycg);
+    constexpr int NIN = RELU ? 3 : 2;
+    column_reduce_staged<NIN>(n, c, partial,
+        [&](int64_t r, int cg, f32x4 (&in)[NIN]) {
+            in[0] = ldh4(dy + r * lddy + cg * 4);
+            in[1] = ldh4(x + r * ldx + cg * 4);
+            if constexpr (RELU) in[2] = ldh4(y + r * ldy + cg * 4);
+        },
+        [&](const f32x4 (&in)[NIN], f32x4& a, f32x4& b) {
+            f32x4 g = in[0];
+            if constexpr (RELU) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = in[2][u] > 0.f ? g[u] : 0.f;
+            }
+            a = g; b = g * ((in[1] - m) * is);
+        });
+}
+extern "C" int b2m_bn_bwd_reduce_h(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx,
+                                   int64_t n, int32_t c, const float* mean, const float* invstd, int32_t relu, double* partial,
+                                   double* sums, float* dbeta_f32, float* dgamma_f32, float param_grad_scale, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(dy && x && mean && invstd && partial && sums && (!relu || y), "NULL argument (relu needs y)");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && (!relu || ldy % 4 == 0) && n >= 1,
+                  "c and leading dimensions must be multiples of 4");
+    B2M_CHECK_ARG(((uintptr_t)dy % 8) == 0 && ((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0, "8-byte aligned rows");
+    const int nblk = reduce_blocks(n);
+    const int c4 = c / 4, nslots = 256 / c4;
+    const size_t lds = (size_t)nslots * c4 * 8 * sizeof(float);
+    if (relu) bn_bwd_reduce_h_kernel<true><<<nblk, 256, lds, st>>>((const _Float16*)dy, lddy, (const _Float16*)y, ldy, (const _Float16*)x, ldx, n, c, mean, invstd, partial);
+    else bn_bwd_reduce_h_kernel<false><<<nblk, 256, lds, st>>>((const _Float16*)dy, lddy, nullptr, 0, (const _Float16*)x, ldx, n, c, mean, invstd, partial);
+    reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, dbeta_f32, dgamma_f32, param_grad_scale);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const _Float16* __restrict__ dy, int64_t lddy,
+                                                             const _Float16* __restrict__ y, int64_t ldy,
+                                                             const _Float16* __restrict__ x, int64_t ldx, int64_t n, int c,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                             double count_host, const double* __restrict__ count_dev, int relu,
+                                                             _Float16* __restrict__ dx, int64_t lddx,
+                                                             _Float16* __restrict__ dres, int64_t lddres) {
+    const int c4 = c >> 2;
+    const float inv_n = (float)(1.0 / (count_dev ? *count_dev : count_host));
+    const int nslots = 256 / c4;
+    const int cg = threadIdx.x % c4, rs = threadIdx.x / c4;
+    if (rs >= nslots) return;
+    const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
+    f32x4 sg, sgx, ga;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        sg[u] = (float)sums[cg * 4 + u] * inv_n; sgx[u] = (float)sums[c + cg * 4 + u] * inv_n;
+        ga[u] = (gamma ? gamma[cg * 4 + u] : 1.f) * is[u];
+    }
+    for (int64_t r = (int64_t)blockIdx.x * nslots + rs; r < n; r += (int64_t)gridDim.x * nslots) {
+        f32x4 g = ldh4(dy + r * lddy + cg * 4);
+        const f32x4 xx = ldh4(x + r * ldx + cg * 4);
+        if (relu) {
+            const f32x4 yy = ldh4(y + r * ldy + cg * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
+        }
+        f32x4 out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xh = (xx[u] - m[u]) * is[u];
+            out[u] = ga[u] * (g[u] - sg[u] - xh * sgx[u]);
+        }
+        sth4(dx + r * lddx + cg * 4, out);
+        if (dres) sth4(dres + r * lddres + cg * 4, g);
+    }
+}
+extern "C" int b2m_bn_bwd_apply_h(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx, int64_t n,
+                                  int32_t c, const float* mean, const float* invstd, const float* gamma, const double* sums,
+                                  double count, const double* count_dev, int32_t relu, void* dx, int64_t lddx, void* dres,
+                                  int64_t lddres, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    B2M_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y), "NULL argument (relu needs y)");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || ldy % 4 == 0) &&
+                      (!dres || lddres % 4 == 0) && (count_dev || count >= 1), "c and leading dimensions must be multiples of 4");
+    B2M_CHECK_ARG(((uintptr_t)dy % 8) == 0 && ((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)dx % 8) == 0 &&
+                      ((uintptr_t)dres % 8) == 0, "8-byte aligned rows");
+    if (n == 0) return B2M_OK;
+    bn_bwd_apply_h_kernel<<<row_grid(n, c / 4), 256, 0, st>>>((const _Float16*)dy, lddy, (const _Float16*)y, ldy, (const _Float16*)x, ldx,
+                                                              n, c, mean, invstd, gamma, sums, count, count_dev, relu,
+                                                              (_Float16*)dx, lddx, (_Float16*)dres, lddres);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

@@ -173,6 +173,14 @@ class SelectionNet(ResNetBase):
         # training passes in fp32) | False
         ht = getattr(self, 'half_trunk', False)
         half = bool(ht) and (ht != 'inference' or self.bn0.fusable())
+        # Half-precision TRAINING (half_train.py; `half_training = True` or cfg.half_training): the same region -- behind the stem,
+        # in front of the pooling -- in binary16 with gradients, loss-scaled; fp32 master weights.  Training passes only.
+        half_train = (bool(getattr(self, 'half_training', False) or getattr(self.cfg, 'half_training', False)) and self.training and
+                      torch.is_grad_enabled() and not half)
+        if half_train:
+            from . import half_train as HT
+            HT.loss_scale[0] = float(getattr(self.cfg, 'half_loss_scale', 1024.0))
+            out_p1 = out_p1.new(HT.to_half(out_p1.F))
         if half:
             if not self.bn0.fusable():
                 raise RuntimeError('half_trunk is an inference mode: model.eval() and torch.no_grad() (and B2M_CONV_AFFINE=1)')
@@ -186,7 +194,15 @@ class SelectionNet(ResNetBase):
         out_b2p4 = T('block2', self.block2(T('down2', down)))
         down, out_b2p4 = cbr(self.conv3p4s2, self.bn3, out_b2p4, skip=True)
         out_b3p8 = T('block3', self.block3(T('down3', down)))
-        down, out_b3p8 = cbr(self.conv4p8s2, self.bn4, out_b3p8, skip=True)
+        if half_train:
+            # Half training keeps the levels below tensor stride 8 in fp32: a few thousand rows at most -- no bytes to save, and the
+            # fp32 forms of the small maps are the fused ones (one-launch BatchNorm, paired block ends, tile statistics).  (Not for
+            # accuracy: those levels' train-mode BatchNorms over a few dozen rows amplify the rounding that ENTERS them 15 x
+            # whichever precision they run in, tools/debug_half_train.py.)  The gradient leaves the loss-scaled half region at
+            # `to_half` and re-enters it at `to_float`, as at the region's ends.
+            down = cbr(self.conv4p8s2, self.bn4, out_b3p8.new(HT.to_float(out_b3p8.F)))
+        else:
+            down, out_b3p8 = cbr(self.conv4p8s2, self.bn4, out_b3p8, skip=True)
         out_b4p16 = T('block4', self.block4(T('down4', down)))
         down, out_b4p16 = cbr(self.added_conv1p16s2, self.added_bn1, out_b4p16, skip=True)
         out_added_b1p32 = T('added_block1', self.added_block1(T('down5', down)))
@@ -198,13 +214,18 @@ class SelectionNet(ResNetBase):
         out = T('added_block4', self.added_block4(ME.cat(T('up6', cbr(self.added_convtr4p128s2, self.added_bntr4, out)), out_added_b2p64)))
         out = T('added_block5', self.added_block5(ME.cat(T('up5', cbr(self.added_convtr5p64s2, self.added_bntr5, out)), out_added_b1p32)))
         out = T('added_block6', self.added_block6(ME.cat(T('up4', cbr(self.added_convtr6p32s2, self.added_bntr6, out)), out_b4p16)))
-        out = T('block5', self.block5(ME.cat(T('up3', cbr(self.convtr4p16s2, self.bntr4, out)), out_b3p8)))
+        up3 = cbr(self.convtr4p16s2, self.bntr4, out)
+        if half_train:
+            up3 = up3.new(HT.to_half(up3.F))        # (back into the half region at tensor stride 8)
+        out = T('block5', self.block5(ME.cat(T('up3', up3), out_b3p8)))
         out = T('block6', self.block6(ME.cat(T('up2', cbr(self.convtr5p8s2, self.bntr5, out)), out_b2p4)))
         out = T('block7', self.block7(ME.cat(T('up1', cbr(self.convtr6p4s2, self.bntr6, out)), out_b1p2)))
         out = T('block8', self.block8(ME.cat(T('up0', cbr(self.convtr7p2s2, self.bntr7, out)), out_p1)))
 
         if half:
             out = out.new(out.F.float())
+        if half_train:
+            out = out.new(HT.to_float(out.F))
         outputs = {}
         perm = x.manager.perm if getattr(x, 'manager', None) is not None else None
         if self.requires_voxel_outputs:

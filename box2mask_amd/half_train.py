@@ -1,0 +1,251 @@
+"""Half-precision TRAINING of the trunk (BASELINE configs[4]: "ARKitScenes ... fp16 features on CDNA4";
+/root/reference/configs/arkitscenes.txt -- a build extension, the reference trains in fp32).
+
+Between the 5x5x5 stem (fp32) and the segment pooling (fp32) every activation and every activation gradient of the levels at
+tensor strides 1 ... 8 -- where the bytes are -- lives in HBM as IEEE binary16; the levels below (a few thousand rows at most)
+stay fp32, as do the weights (master copies, the optimizer's); every accumulation is fp32 / fp64:
+
+* forward and data gradient of a layer: `b2m_conv_fwd_h` (conv_fwd_flow_kernel<.., F16>: f16 MFMA, fp32 accumulators, one
+  rounding to half on the way out) -- the data gradient with the half image of the transposed (and, for the stride-1 maps,
+  mirrored) weights;
+* weight gradient: `b2m_conv_wgrad_h` (half operands converted on load, fp32 MFMA, fp32 dW);
+* BatchNorm: `b2m_bn_stats_finalize_h` -> `b2m_bn_apply_h`, backward `b2m_bn_bwd_reduce_h` -> `b2m_bn_bwd_apply_h`
+  (fp64 statistics, the ReLU mask is the sign of the stored half output);
+* loss scaling: the gradient is multiplied by `loss_scale` where it enters the half region (`to_float`), every parameter gradient
+  the region produces is multiplied by 1 / loss_scale by the operator that produced it, and the gradient that leaves the region
+  towards the stem (`to_half`) likewise -- outside the region nothing is scaled.
+
+Turned on by `SelectionNet.half_training = True` (or `cfg.half_training`); single process only (no SyncBN form).  The layers
+(`nn.MinkowskiConvolution` ...) route here by the dtype of their input.  Semantics per operator: those of `functional._SparseConv`
+/ `functional._BatchNorm` (/root/reference/models/resnet.py:61-83, detection_net.py:37-135)."""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from . import _lib
+from . import functional as F_
+from .grad_arena import grad_slot
+
+_call = _lib.call
+_ptr = _lib.ptr
+
+loss_scale = [1024.0]        # set by SelectionNet.forward from cfg.half_loss_scale (a power of two: scaling is exact)
+
+
+def _hc(t):
+    """half, unit column stride (the kernels take a row pitch)."""
+    assert t.dtype == torch.float16
+    return t if t.stride(1) == 1 else t.contiguous()
+
+
+# ---- half images of the TRANSPOSED weights (the data gradient's operand), cached like functional.weight_pack_h
+_images_t = {}
+
+
+def weight_pack_ht(weight, mirror: bool, s0: int, sc: int):
+    """Half image of W'[k] = W[k or K-1-k][s0:s0+sc, :]^T -- the operand with which b2m_conv_fwd_h computes the gradient w.r.t.
+    input channels [s0, s0 + sc) of a layer with weights W (K, cin, cout)."""
+    w3 = weight.detach()
+    w3 = w3 if w3.dim() == 3 else w3.unsqueeze(0)
+    K, cin, cout = w3.shape
+    key = (id(weight), bool(mirror), int(s0), int(sc))
+    e = _images_t.get(key)
+    if e is not None and e[0]() is weight and e[2] == weight._version and e[3] == weight.data_ptr() and e[4] == F_.training_epoch():
+        return e[1]
+    assert w3.is_contiguous()
+    n = _lib.load().b2m_weight_pack_h_size(K, cout, 0, sc)
+    image = e[1] if (e is not None and e[0]() is weight and e[1].numel() == n) else torch.empty(n, dtype=torch.float16, device=w3.device)
+    _call('b2m_weight_pack_h_t', w3.data_ptr(), K, cin, cout, 1 if mirror else 0, s0, sc, image.data_ptr())
+    if e is None:
+        for k in [k for k, v in _images_t.items() if v[0]() is None]:
+            del _images_t[k]
+    _images_t[key] = [weakref.ref(weight), image, weight._version, weight.data_ptr(), F_.training_epoch()]
+    return image
+
+
+def _conv_h(x1, x2, image, K, rb, n_out, cout):
+    c1 = x1.shape[1]
+    c2 = x2.shape[1] if x2 is not None else 0
+    out = torch.empty((n_out, cout), dtype=torch.float16, device=x1.device)
+    if n_out == 0:
+        return out
+    _call('b2m_conv_fwd_h', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2, x1.shape[0],
+          image.data_ptr(), K, rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr(), n_out, out.data_ptr(), out.stride(0),
+          cout, None, None, None, 0, 0, meta={'half': True})
+    return out
+
+
+def _wgrad_h(x, dy, rb, K, dw3, ci0, inv):
+    """dw3[:, ci0:ci0+cin, :] += inv * sum_pairs x[in]^T dy[out] with half x / dy (b2m_conv_wgrad_h); a transposed map walks its DOWN
+    rulebook with the row roles exchanged, as functional.wgrad_raw does."""
+    cin_total, cout = dw3.shape[1], dw3.shape[2]
+    cin = x.shape[1]
+    n_out = dy.shape[0]
+    dst = dw3.data_ptr() + 4 * ci0 * cout
+    sc = rb.scatter
+    if sc is not None and n_out > 0 and x.shape[0] > 0 and F_.wgrad_up_over_down_map():
+        _call('b2m_conv_wgrad_h', x.data_ptr(), x.stride(0), cin, n_out, dy.data_ptr(), dy.stride(0), cout, sc.rb_in.data_ptr(),
+              sc.rb_out.data_ptr(), sc.rb_cnt.data_ptr(), x.shape[0], K, dst, cout, cin_total * cout, 1, inv)
+        return
+    _call('b2m_conv_wgrad_h', x.data_ptr(), x.stride(0), cin, x.shape[0], dy.data_ptr(), dy.stride(0), cout, rb.rb_in.data_ptr(),
+          rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr(), n_out, K, dst, cout, cin_total * cout, 0, inv)
+
+
+class _ConvH(torch.autograd.Function):
+    """Y = sum_k [x1|x2][in_k] W[k], half in / out (functional._SparseConv without bias, pass-through and tile statistics)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, rb_f, rb_b, mirror, n_out):
+        x1 = _hc(x1)
+        x2 = _hc(x2) if x2 is not None else None
+        w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        K, cin, cout = w3.shape
+        c1 = x1.shape[1]
+        c2 = x2.shape[1] if x2 is not None else 0
+        assert c1 + c2 == cin and rb_f.K == K and rb_f.n_out == n_out
+        y = _conv_h(x1, x2, F_.weight_pack_h(weight, c1, c2), K, rb_f, n_out, cout)
+        ctx.save_for_backward(x1, x2, weight)
+        ctx.rb_f, ctx.rb_b, ctx.mirror = rb_f, rb_b, mirror
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, weight = ctx.saved_tensors
+        dy = _hc(dy)
+        w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        K, cin, cout = w3.shape
+        c1 = x1.shape[1]
+        inv = 1.0 / loss_scale[0]
+        dx1 = dx2 = dw = None
+        if ctx.needs_input_grad[0]:
+            dx1 = _conv_h(dy, None, weight_pack_ht(weight, ctx.mirror, 0, c1), K, ctx.rb_b, x1.shape[0], c1)
+        if x2 is not None and ctx.needs_input_grad[1]:
+            dx2 = _conv_h(dy, None, weight_pack_ht(weight, ctx.mirror, c1, x2.shape[1]), K, ctx.rb_b, x2.shape[0], x2.shape[1])
+        if ctx.needs_input_grad[2]:
+            dw = grad_slot(weight)
+            if dw is None:
+                dw = torch.zeros_like(weight, dtype=torch.float32)
+            dw3 = dw if weight.dim() == 3 else dw.unsqueeze(0)
+
+            def run():
+                _wgrad_h(x1, dy, ctx.rb_f, K, dw3, 0, inv)      # (inv: the kernel un-scales the block on its way into dW)
+                if x2 is not None:
+                    _wgrad_h(x2, dy, ctx.rb_f, K, dw3, c1, inv)
+            if F_.wgrad_on_side_stream():
+                main, side = torch.cuda.current_stream(dy.device), F_._side_stream(dy.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    run()
+                for t in (dy, x1, x2, dw):
+                    if t is not None:
+                        t.record_stream(side)
+                if not F_._side['armed']:
+                    F_._side['armed'] = True
+                    torch.autograd.Variable._execution_engine.queue_callback(F_.join_side_streams)
+            else:
+                run()
+        return dx1, dx2, dw, None, None, None, None
+
+
+def conv(x1, x2, weight, rb_f, rb_b, mirror, n_out):
+    return _ConvH.apply(x1, x2, weight, rb_f, rb_b, mirror, n_out)
+
+
+_ws = {}
+
+
+def _workspace(c, device):
+    """Partial-sum buffer of the two-stage column reductions (2c x 4096 doubles), kept per device: launches on one stream run in
+    order, so consecutive layers can share it."""
+    need = 2 * c * F_._RED_BLOCKS
+    w = _ws.get(device)
+    if w is None or w.numel() < need:
+        w = torch.empty(max(need, 2 * 256 * F_._RED_BLOCKS), dtype=torch.float64, device=device)
+        _ws[device] = w
+    return w
+
+
+class _BatchNormH(torch.autograd.Function):
+    """y = [relu](BN(x) [+ residual]) in training mode, half in / out (functional._BatchNorm's local-statistics branch)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu):
+        x = _hc(x)
+        n, c = x.shape
+        dev = x.device
+        if n <= 1:
+            raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(x.shape),))
+        residual = _hc(residual) if residual is not None else None
+        f32 = lambda: torch.empty(c, dtype=torch.float32, device=dev)
+        mean, invstd, scale, shift = f32(), f32(), f32(), f32()
+        _call('b2m_bn_stats_finalize_h', x.data_ptr(), x.stride(0), n, c, _workspace(c, dev).data_ptr(), _ptr(gamma), _ptr(beta), eps,
+              momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+        y = torch.empty_like(x)
+        _call('b2m_bn_apply_h', x.data_ptr(), x.stride(0), n, c, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
+              residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
+        ctx.save_for_backward(x, y if relu else None, gamma, beta, mean, invstd)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        dy = _hc(dy)
+        n, c = x.shape
+        dev = x.device
+        relu = 1 if ctx.relu else 0
+        dbeta, dgamma = grad_slot(beta), grad_slot(gamma)
+        if dbeta is None or dgamma is None:
+            dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+            dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+        _call('b2m_bn_bwd_reduce_h', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
+              x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _workspace(c, dev).data_ptr(), sums.data_ptr(),
+              dbeta.data_ptr(), dgamma.data_ptr(), 1.0 / loss_scale[0])       # (the sums are of the SCALED gradient)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[7]) else None
+        _call('b2m_bn_bwd_apply_h', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
+              x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), sums.data_ptr(), float(n), None, relu,
+              dx.data_ptr(), dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0)
+        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, None, None, None,
+                None, dres, None)
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=False):
+    return _BatchNormH.apply(x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu)
+
+
+class _ToHalf(torch.autograd.Function):
+    """fp32 -> half where a half region begins (behind the stem; behind the fp32 deep levels); the gradient leaves the region
+    here: un-scaled."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float() * (1.0 / loss_scale[0])
+
+
+class _ToFloat(torch.autograd.Function):
+    """half -> fp32 where a half region ends (in front of the segment pooling; in front of the fp32 deep levels); the gradient
+    enters the region here: scaled."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g * loss_scale[0]).half()
+
+
+def to_half(x):
+    return _ToHalf.apply(x)
+
+
+def to_float(x):
+    return _ToFloat.apply(x)

@@ -115,6 +115,19 @@ class MinkowskiConvolution(_ConvBase):
                 return x.new(out, level=level)
             y, a1, a2 = out
             return x.new(y, level=level), _like(x, a1, a2)
+        if x1.dtype == torch.float16:
+            # half-precision training (half_train.py): the same layer on binary16 activations.  No pass-through form: the
+            # other consumers of x take x itself and autograd sums the two half gradients
+            from . import half_train as HT
+            assert self.bias is None, 'the half trunk has no biased convolutions'
+            if self.kernel_volume == 1:
+                rb_f = rb_b = m.rulebook_identity(l); mirror, level = False, None
+            elif self.stride == 1:
+                rb_f = rb_b = m.rulebook_same(l, self.kernel_size); mirror, level = True, None
+            else:
+                rb_f, rb_b, mirror, level = m.rulebook_down(l), m.rulebook_up(l), False, l + 1
+            y = HT.conv(x1, x2, self.kernel, rb_f, rb_b, mirror, rb_f.n_out)
+            return result((y, x1, x2) if passthrough else y, level)
         if self.kernel_volume == 1:
             assert self.stride == 1
             return result(F_.sparse_conv(x1, x2, self.kernel, self.bias, None, None, False, x1.shape[0],
@@ -148,6 +161,10 @@ class MinkowskiConvolutionTranspose(_ConvBase):
             if self.bias is not None:       # (as above: the bias folds into the shift)
                 shift = shift + scale * self.bias.detach().reshape(-1).to(scale.dtype)
             return x.new(F_.conv_affine(x1, x2, self.kernel, rb_f, rb_f.n_out, scale, shift, residual, relu), level=l)
+        if x1.dtype == torch.float16:          # half-precision training (half_train.py)
+            from . import half_train as HT
+            assert self.bias is None
+            return x.new(HT.conv(x1, x2, self.kernel, rb_f, rb_b, False, rb_f.n_out), level=l)
         y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out,
                            collect_stats=self.training and self.bias is None)
         return x.new(y, level=l)
@@ -196,6 +213,13 @@ class MinkowskiBatchNorm(nn.Module):
                 bn.num_batches_tracked.add_(1)
         if training:
             F_.note_training_pass()        # running statistics are about to change behind torch's back (eval_affine)
+        if feats.dtype == torch.float16:   # half-precision training (half_train.py): binary16 in / out, fp64 statistics
+            from . import half_train as HT
+            if not training:
+                raise RuntimeError('half activations outside inference need training-mode BatchNorm (half_train.py)')
+            if self.sync and F_._sync_group() is not None:
+                raise RuntimeError('half-precision training has no SyncBN form: one process only')
+            return HT.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, residual, relu)
         return F_.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                              bn.momentum, bn.eps, residual, relu, self.sync, count_key)
 
@@ -226,6 +250,8 @@ def batch_norm_add_relu(norm_a: MinkowskiBatchNorm, feats_a, norm_b: MinkowskiBa
     or None when the paired operator does not apply (different modes of the two layers, small maps outside SyncBN:
     those take the one-launch kernels of functional._BatchNorm)."""
     if not F_.bn_pair() or norm_a.training != norm_b.training or norm_a.sync != norm_b.sync:
+        return None
+    if feats_a.dtype == torch.float16:       # half-precision training: two layers (half_train.py has no paired form)
         return None
     n, c = feats_a.shape
     # the paired kernels take 16-byte column groups of dense fp32 rows (b2m_bn_apply2 checks the same)

@@ -273,6 +273,43 @@ int b2m_conv_wgrad_tr(const float* x, int64_t ldx, int32_t cin, int64_t n_in, co
                    const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                    int64_t n_out, int32_t K, float* dw, int64_t lddw, int64_t dw_kstride, float* workspace, void* stream);
 
+/* ---------------------------------------------------------------- half-precision TRAINING (round 6; BASELINE configs[4])
+ * Activations and their gradients as IEEE binary16 in HBM between the layers of the trunk; fp32 master weights, fp32 / fp64
+ * statistics and accumulation.  Forward and data gradient of a layer are b2m_conv_fwd_h (above: scale / shift NULL, the data
+ * gradient with the image b2m_weight_pack_h makes of the transposed, mirrored weights); these are the remaining pieces.
+ * Pointers to half data are `void*`, pitches in ELEMENTS (multiples of 4, rows 8-byte aligned).
+ *   b2m_conv_wgrad_h      dW[k][ci][co] += out_scale * sum_pairs X[i, ci] * dY[o, co] with X, dY half, dW fp32 (atomics; out_scale =
+ *                         1 / loss scale).  tr != 0: the rulebook's row roles exchanged (b2m_conv_wgrad_tr).  Replaces [ME]
+ *                         ConvolutionBackward (weight part).
+ *   b2m_bn_stats_h        column sums / sums of squares of a half tensor (fp64; partial: 2*c*4096 doubles; stats: 2*c).
+ *   b2m_bn_apply_h        y = [relu](fmaf(x, scale, shift) [+ res]), half in / out.
+ *   b2m_bn_bwd_reduce_h   sums[0:c] = sum g, sums[c:2c] = sum g * xhat with g = dy * (y > 0) (relu); dbeta / dgamma = the sums as
+ *                         fp32 times param_grad_scale (1 / loss scale).
+ *   b2m_bn_bwd_apply_h    dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)), dres = g; half out.
+ * The BatchNorm arithmetic is that of b2m_bn_stats / _apply / _bwd_reduce / _bwd_apply (resnet.py:63,66,73-82); the ReLU mask
+ * is always the sign of the stored half output y. */
+int b2m_conv_wgrad_h(const void* x, int64_t ldx, int32_t cin, int64_t n_in, const void* dy, int64_t lddy, int32_t cout,
+                     const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt, int64_t n_out, int32_t K,
+                     float* dw, int64_t lddw, int64_t dw_kstride, int32_t tr, float out_scale, void* stream);
+/* half image of W'[k] = W[mirror ? K-1-k : k][s0 : s0+sc, :]^T, W (K, cin, cout) contiguous fp32: the operand with which
+ * b2m_conv_fwd_h computes the gradient w.r.t. input channels [s0, s0+sc) (b2m_weight_pack_h_size(K, cout, 0, sc) halfs). */
+int b2m_weight_pack_h_t(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mirror, int32_t s0, int32_t sc, void* wp,
+                        void* stream);
+/* b2m_bn_stats_h + the finalize of b2m_bn_stats_finalize in two launches (local statistics, count = n). */
+int b2m_bn_stats_finalize_h(const void* x, int64_t ldx, int64_t n, int32_t c, double* partial, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                            float* scale, float* shift, void* stream);
+int b2m_bn_stats_h(const void* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats, void* stream);
+int b2m_bn_apply_h(const void* x, int64_t ldx, int64_t n, int32_t c, const float* scale, const float* shift,
+                   const void* residual, int64_t ldr, int32_t relu, void* y, int64_t ldy, void* stream);
+int b2m_bn_bwd_reduce_h(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx, int64_t n,
+                        int32_t c, const float* mean, const float* invstd, int32_t relu, double* partial, double* sums,
+                        float* dbeta_f32, float* dgamma_f32, float param_grad_scale, void* stream);
+int b2m_bn_bwd_apply_h(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx, int64_t n,
+                       int32_t c, const float* mean, const float* invstd, const float* gamma, const double* sums,
+                       double count, const double* count_dev, int32_t relu, void* dx, int64_t lddx, void* dres,
+                       int64_t lddres, void* stream);
+
 /* ---------------------------------------------------------------- SyncBN statistics exchange inside one node (opt-in)
  * Device-side all-reduce (SUM) of n <= b2m_xchg_max_doubles() doubles between <= b2m_xchg_max_ranks() ranks whose MAILBOXES
  * (b2m_xchg_size() bytes of device memory each) are mapped into one another through HIP IPC: one launch of one workgroup

@@ -1,0 +1,260 @@
+"""Half-precision TRAINING of the trunk (box2mask_amd/half_train.py; BASELINE.json configs[4], a build extension: the reference
+trains in fp32 -- /root/reference/configs/arkitscenes.txt, models/resnet.py:61-83, detection_net.py:37-135).
+
+  1. every layer kind, forward / data gradient / weight gradient, against the fp32 kernels on the SAME half-rounded operands
+     (what is left: summation order and the one rounding of a half result -- <= 1e-3 of the tensor's maximum and 2^-10 relative
+     element by element for the half outputs; the fp32 weight gradient <= 1e-4);
+  2. training-mode BatchNorm (+ residual) (+ ReLU) with half I/O against the fp32 kernels on the same numbers, forward and backward;
+  3. the whole network: loss-scaled half training pass against the fp32 pass on the same weights and batch -- heads, and every one of
+     the 283 parameter gradients (bounds stated in the test: ~40 layers each round activations and gradients to 11 bits, and a
+     pre-activation within that rounding of zero flips its ReLU);
+  4. thirty optimizer steps in half against the same thirty in fp32: the loss curves stay together."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-9)
+
+
+def _half_close(h, ref, what):
+    """a half result against its fp32 twin: <= 1e-3 of the maximum, and element by element one rounding (2^-10 allowed) + noise"""
+    assert h.dtype == torch.float16 and torch.isfinite(h.float()).all(), what
+    e = _rel(h.float(), ref)
+    assert e < 1e-3, '%s: %.3e of the maximum' % (what, e)
+    d = (h.float() - ref).abs()
+    bound = ref.abs() * 2.0 ** -10 + 5e-5 * float(ref.abs().max())
+    assert bool((d <= bound).all()), '%s: %.2f x the element bound' % (what, float((d / bound).max()))
+
+
+@pytest.fixture(scope='module')
+def maps():
+    from test_gpu_ops import _scene
+    from box2mask_amd.sparse import CoordinateManager
+    b = _scene()
+    m = CoordinateManager(b['vox_coords'])
+    m.ensure_level(2)
+    return m
+
+
+CASES = [('k3', 0, (96, 0), 96), ('k3', 0, (96, 32), 96), ('k3', 0, (32, 0), 32), ('k3', 1, (128, 0), 128), ('k3', 1, (64, 0), 128),
+         ('k3', 2, (256, 0), 256), ('k3', 2, (256, 128), 256), ('down', 0, (32, 0), 32), ('down', 1, (96, 0), 96),
+         ('up', 0, (96, 0), 96), ('up', 1, (256, 0), 128), ('1x1', 0, (128, 0), 96), ('1x1', 1, (96, 32), 128)]
+
+
+@pytest.mark.parametrize('kind,level,cins,cout', CASES)
+def test_half_training_layer_against_fp32_kernels(maps, monkeypatch, kind, level, cins, cout):
+    from box2mask_amd import functional as F_, half_train as HT
+    monkeypatch.setenv('B2M_WGRAD_STREAM', '0')
+    monkeypatch.setattr(HT, 'loss_scale', [1.0])
+    m = maps
+    c1, c2 = cins
+    if kind == 'k3':
+        rb_f = rb_b = m.rulebook_same(level, 3); K = 27; mirror = True; n_in = n_out = m.n(level); rb32 = (rb_f, rb_b)
+    elif kind == 'down':
+        rb_f, rb_b = m.rulebook_down(level), m.rulebook_up(level); K = 8; mirror = False; n_in, n_out = m.n(level), m.n(level + 1); rb32 = (rb_f, rb_b)
+    elif kind == 'up':
+        rb_f, rb_b = m.rulebook_up(level), m.rulebook_down(level); K = 8; mirror = False; n_in, n_out = m.n(level + 1), m.n(level); rb32 = (rb_f, rb_b)
+    else:
+        rb_f = rb_b = m.rulebook_identity(level); K = 1; mirror = False; n_in = n_out = m.n(level); rb32 = (None, None)
+    torch.manual_seed(zlib.crc32(repr((kind, level, cins, cout)).encode()) % 1000)
+    x = torch.randn(n_in, c1 + c2, device='cuda').half()
+    w = (torch.randn(K, c1 + c2, cout, device='cuda') * (2.0 / ((c1 + c2) * min(K, 10)) ** 0.5)).half().float().contiguous()
+    if K == 1:
+        w = w[0].contiguous()
+    gy = torch.randn(n_out, cout, device='cuda').half()
+    # half path
+    xh = x.clone().requires_grad_(True)
+    wh = w.clone().requires_grad_(True)
+    x1 = xh[:, :c1].contiguous() if c2 else xh
+    x2 = xh[:, c1:].contiguous() if c2 else None
+    yh = HT.conv(x1, x2, wh, rb_f, rb_b, mirror, n_out)
+    yh.backward(gy)
+    # fp32 kernels on the same numbers
+    xf = x.float().requires_grad_(True)
+    wf = w.clone().requires_grad_(True)
+    f1 = xf[:, :c1].contiguous() if c2 else xf
+    f2 = xf[:, c1:].contiguous() if c2 else None
+    yf = F_.sparse_conv(f1, f2, wf, None, rb32[0], rb32[1], mirror, n_out)
+    yf.backward(gy.float())
+    torch.cuda.synchronize()
+    _half_close(yh.detach(), yf.detach(), 'forward')
+    _half_close(xh.grad, xf.grad, 'data gradient')
+    assert wh.grad.dtype == torch.float32
+    e = _rel(wh.grad, wf.grad)
+    assert e < 1e-4, 'weight gradient: %.3e' % e
+
+
+@pytest.mark.parametrize('n,c,res,relu', [(20000, 96, False, True), (20000, 96, True, True), (3000, 256, True, False),
+                                          (700, 128, False, False), (50000, 32, False, True)])
+def test_half_training_batchnorm_against_fp32_kernels(monkeypatch, n, c, res, relu):
+    from box2mask_amd import functional as F_, half_train as HT
+    monkeypatch.setattr(HT, 'loss_scale', [1.0])
+    monkeypatch.setenv('B2M_BN_SMALL_ROWS', '0')
+    torch.manual_seed(n + c)
+    x = (torch.randn(n, c, device='cuda') * 1.5 + 0.3).half()
+    r = torch.randn(n, c, device='cuda').half() if res else None
+    gy = torch.randn(n, c, device='cuda').half()
+    gamma = torch.rand(c, device='cuda') + 0.5
+    beta = torch.randn(c, device='cuda') * 0.2
+
+    def run(half):
+        g, b = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+        xi = (x if half else x.float()).clone().requires_grad_(True)
+        ri = None if r is None else (r if half else r.float()).clone().requires_grad_(True)
+        if half:
+            y = HT.batch_norm(xi, g, b, rm, rv, 0.1, 1e-5, ri, relu)
+        else:
+            y = F_.batch_norm(xi, g, b, rm, rv, True, 0.1, 1e-5, ri, relu)
+        y.backward(gy if half else gy.float())
+        return y.detach(), xi.grad, None if ri is None else ri.grad, g.grad, b.grad, rm, rv
+    yh, dxh, drh, dgh, dbh, rmh, rvh = run(True)
+    yf, dxf, drf, dgf, dbf, rmf, rvf = run(False)
+    torch.cuda.synchronize()
+    _half_close(yh, yf, 'BatchNorm output')
+    # the mask: y_half > 0 against y_fp32 > 0 differ only where the fp32 value rounds to zero in half
+    assert _rel(dxh.float(), dxf) < 2e-3, _rel(dxh.float(), dxf)
+    if res:
+        assert _rel(drh.float(), drf) < 1e-3
+    for a, b, nm in ((dgh, dgf, 'dgamma'), (dbh, dbf, 'dbeta'), (rmh, rmf, 'running mean'), (rvh, rvf, 'running var')):
+        assert _rel(a, b) < 1e-4, (nm, _rel(a, b))
+
+
+def _net_and_batch(seed=3, scenes=32, voxels=2000):
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.detection_net import SelectionNet
+    cfg = scannet_config()
+    valid, _, _, is_fg = synth.scannet_tables()
+    torch.manual_seed(seed)
+    net = SelectionNet(cfg, 'cuda', valid, is_fg, out_channels=[96, 96, 6]).cuda()
+    net.train()
+    batch = synth.make_batch(scenes, seed0=40, target_voxels=voxels, pts_per_m2=6000.0)
+    return net, batch, cfg
+
+
+def test_half_training_pass_against_the_fp32_pass(monkeypatch):
+    """One training pass (train-mode BatchNorm, all heads; 32 small scenes) with the trunk in half against the fp32 pass on the same
+    weights and batch.  The half pass runs b2m_conv_fwd_h for the forward AND the data gradient of every layer of the half region
+    (tensor strides 1 ... 8; the hook counts them) and b2m_conv_wgrad_h for their weight gradients.
+
+    What can be asked of the numbers.  Every layer rounds its activations to 11 bits: 4e-4 of a tensor per layer, 3e-3 when the
+    encoder reaches tensor stride 16 -- and the train-mode BatchNorms of the deepest levels (32 rows here) amplify whatever enters
+    them 15 x (tools/debug_half_train.py: the same 5e-2 at levels 5-7 whether those levels run in half or, as shipped, in fp32).
+    So: heads within 5e-2 of their maximum (observed 1.6e-2 ... 3.7e-2).  Gradients are compared with the fp32 pass's ReLU
+    decisions replayed in the half pass (tests/_parity.py says why: a unit whose pre-activation lies within the forward difference
+    of zero switches whole terms of a weight gradient on or off -- un-replayed the two gradient vectors have a cosine of 0.82):
+    the whole gradient vector points the same way (cosine >= 0.99, observed 0.997), the median parameter is within 1e-1 of its
+    own maximum (observed 5.9e-2), the worst within 3e-1 (observed 1.5e-1)."""
+    from box2mask_amd import _lib, nn as ME, functional as F_, half_train as HT
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    monkeypatch.setenv('B2M_BN_PAIR', '0')                  # (every BatchNorm through F_.batch_norm / HT.batch_norm: one hook each)
+    net, batch, cfg = _net_and_batch()
+    S_ = batch['input_location'].shape[0]
+    heads = ['mlp_offsets', 'mlp_bounds', 'mlp_bb_scores', 'mlp_semantics']
+    gws = None
+    masks, mode, idx = [], ['record'], [0]
+    bn32, bn16, relu32 = F_.batch_norm, HT.batch_norm, F_.relu
+
+    def take(z):
+        if mode[0] == 'record':
+            masks.append(z.detach() > 0)
+            return masks[-1]
+        m = masks[idx[0]]
+        idx[0] += 1
+        assert m.shape == z.shape
+        return m
+
+    def p_bn32(x, gamma, beta, rm, rv, training, momentum=0.1, eps=1e-5, residual=None, relu=False, sync=False, count_key=None):
+        z = bn32(x, gamma, beta, rm, rv, training, momentum, eps, residual, False, sync, count_key)
+        return z * take(z).to(z.dtype) if relu else z
+
+    def p_bn16(x, gamma, beta, rm, rv, momentum, eps, residual=None, relu=False):
+        z = bn16(x, gamma, beta, rm, rv, momentum, eps, residual, False)
+        return z * take(z).to(z.dtype) if relu else z
+    monkeypatch.setattr(F_, 'batch_norm', p_bn32)
+    monkeypatch.setattr(HT, 'batch_norm', p_bn16)
+    monkeypatch.setattr(F_, 'relu', lambda x: x * take(x).to(x.dtype))
+
+    def run(half):
+        nonlocal gws
+        net.half_training = half
+        for p in net.parameters():
+            p.grad = None
+        calls = []
+        _lib.set_hook(lambda name, a, meta=None: calls.append(name))
+        try:
+            out = net(ME.SparseTensor(batch['vox_features'], batch['vox_coords']), batch['pooling_ids'].cuda(), S_)
+            if gws is None:
+                gws = {h: torch.randn(out[h].F.shape, device='cuda') for h in heads}
+            # (a mean over the rows, like the reference's loss terms)
+            loss = sum(((out[h].F - gws[h]) ** 2).mean() for h in heads)
+            loss.backward()
+        finally:
+            _lib.set_hook(None)
+            net.half_training = False
+        torch.cuda.synchronize()
+        return ({h: out[h].F.detach().clone() for h in heads}, {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None},
+                calls)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    o32, g32, _ = run(False)
+    net.load_state_dict(sd)                     # (the running statistics moved)
+    mode[0] = 'replay'
+    o16, g16, calls = run(True)
+    assert idx[0] == len(masks) and len(masks) >= 75, (idx[0], len(masks))
+    n_h = sum(1 for c in calls if c == 'b2m_conv_fwd_h')
+    n_w = sum(1 for c in calls if c == 'b2m_conv_wgrad_h')
+    n_f = sum(1 for c in calls if c in ('b2m_conv_fwd', 'b2m_conv_fwd_stats', 'b2m_conv_up'))
+    print('half launches: conv_fwd_h %d, conv_wgrad_h %d; fp32 conv launches (stem, deep levels, heads) %d' % (n_h, n_w, n_f))
+    assert n_h >= 2 * 36 and n_w >= 36, (n_h, n_w)          # the 38 layers at tensor strides 1 ... 8: forward + data gradient, weight gradient
+    head_err = {h: _rel(o16[h], o32[h]) for h in heads}
+    print('heads half vs fp32:', {h: '%.3e' % e for h, e in head_err.items()})
+    assert set(g16) == set(g32) and len(g32) == 283
+    rel = {n: _rel(g16[n], g32[n]) for n in g32}
+    a = torch.cat([g16[n].reshape(-1).double() for n in g32]); b = torch.cat([g32[n].reshape(-1).double() for n in g32])
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    v = np.array(sorted(rel.values()))
+    print('parameter gradients half vs fp32, ReLU decisions replayed: cosine %.5f, median %.3e, 95th percentile %.3e, worst %.3e (%s)'
+          % (cos, np.median(v), np.percentile(v, 95), v[-1], max(rel, key=rel.get)))
+    assert all(torch.isfinite(g).all() for g in g16.values())
+    assert max(head_err.values()) < 5e-2, head_err
+    assert cos >= 0.99, cos
+    assert np.median(v) < 1e-1 and v[-1] < 3e-1, (np.median(v), v[-1])
+
+
+def test_half_training_loss_curve_follows_fp32(monkeypatch):
+    """Thirty Adam steps of Model.compute_loss on one batch, trunk in half (cfg.half_training, loss scale 1024) and in fp32, from the
+    same weights: both take the loss from 44 to 2 at the same pace.  Step by step the two trajectories drift like any two
+    trajectories of this network do (a handful of rows at the deepest level; observed: 5 % on average, 16 % at the worst step,
+    the final losses 4 % apart) -- the bounds are 10 % on average, 30 % at any step, 15 % at the end."""
+    from box2mask_amd import synth
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    monkeypatch.setenv('B2M_DETERMINISTIC', '1')
+    batch = synth.make_batch(8, seed0=60, target_voxels=6000, pts_per_m2=6000.0)
+
+    def run(half):
+        torch.manual_seed(7)
+        model = Model(scannet_config(half_training=half), *synth.scannet_tables())
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+        out = []
+        for _ in range(30):
+            opt.zero_grad()
+            ld = model.compute_loss(batch, 150)
+            ld['optimization_loss'].backward()
+            opt.step()
+            out.append(float(ld['optimization_loss'].detach()))
+        return out
+    a, b = run(True), run(False)
+    print('half', ['%.3f' % v for v in a[::3]], 'fp32', ['%.3f' % v for v in b[::3]])
+    assert all(np.isfinite(a)) and a[-1] < 0.1 * a[0] and b[-1] < 0.1 * b[0]
+    d = [abs(x - y) / y for x, y in zip(a, b)]
+    assert max(d) < 0.30 and float(np.mean(d)) < 0.10 and d[-1] < 0.15, (max(d), float(np.mean(d)), d[-1])
