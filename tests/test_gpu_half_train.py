@@ -45,7 +45,9 @@ def maps():
 
 CASES = [('k3', 0, (96, 0), 96), ('k3', 0, (96, 32), 96), ('k3', 0, (32, 0), 32), ('k3', 1, (128, 0), 128), ('k3', 1, (64, 0), 128),
          ('k3', 2, (256, 0), 256), ('k3', 2, (256, 128), 256), ('down', 0, (32, 0), 32), ('down', 1, (96, 0), 96),
-         ('up', 0, (96, 0), 96), ('up', 1, (256, 0), 128), ('1x1', 0, (128, 0), 96), ('1x1', 1, (96, 32), 128)]
+         ('up', 0, (96, 0), 96), ('up', 1, (256, 0), 128), ('1x1', 0, (128, 0), 96), ('1x1', 1, (96, 32), 128),
+         # every (MI, NJ) block shape the weight gradient picks for the trunk's channel counts: 2x2 (above), 3x3, 4x4, 2x3, 2x4, 4x3 and
+         ('k3', 1, (96, 0), 32), ('k3', 1, (128, 0), 64), ('k3', 1, (64, 0), 64), ('k3', 1, (32, 0), 64), ('k3', 2, (384, 0), 256)]
 
 
 @pytest.mark.parametrize('kind,level,cins,cout', CASES)
@@ -233,7 +235,8 @@ def test_half_training_loss_curve_follows_fp32(monkeypatch):
     """Thirty Adam steps of Model.compute_loss on one batch, trunk in half (cfg.half_training, loss scale 1024) and in fp32, from the
     same weights: both take the loss from 44 to 2 at the same pace.  Step by step the two trajectories drift like any two
     trajectories of this network do (a handful of rows at the deepest level; observed: 5 % on average, 16 % at the worst step,
-    the final losses 4 % apart) -- the bounds are 10 % on average, 30 % at any step, 15 % at the end."""
+    the mean of the last five steps 2 - 6 % apart over three builds) -- the bounds are 10 % on average, 30 % at any step, 15 % for
+    the mean of the last five steps."""
     from box2mask_amd import synth
     from box2mask_amd.config import scannet_config
     from box2mask_amd.model import Model
@@ -257,4 +260,5 @@ def test_half_training_loss_curve_follows_fp32(monkeypatch):
     print('half', ['%.3f' % v for v in a[::3]], 'fp32', ['%.3f' % v for v in b[::3]])
     assert all(np.isfinite(a)) and a[-1] < 0.1 * a[0] and b[-1] < 0.1 * b[0]
     d = [abs(x - y) / y for x, y in zip(a, b)]
-    assert max(d) < 0.30 and float(np.mean(d)) < 0.10 and d[-1] < 0.15, (max(d), float(np.mean(d)), d[-1])
+    tail = abs(np.mean(a[-5:]) - np.mean(b[-5:])) / np.mean(b[-5:])          # (single steps fluctuate by 10 %: the last five together)
+    assert max(d) < 0.30 and float(np.mean(d)) < 0.10 and tail < 0.15, (max(d), float(np.mean(d)), tail)
