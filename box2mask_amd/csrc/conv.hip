@@ -44,7 +44,7 @@ struct ConvArgs {
 };
 
 // loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
-__device__ float g_zeros[64];
+__device__ __attribute__((aligned(16))) float g_zeros[64];
 
 // the inference epilogue on four consecutive columns of output row `grow` (ConvArgs::ep_scale != NULL; col + 3 < cout)
 __device__ __forceinline__ f32x4 conv_epilogue(const ConvArgs& a, f32x4 v, int64_t grow, int col) {
@@ -1382,6 +1382,7 @@ struct WgradArgs {
     int swap;                 // b2m_conv_wgrad_tr: x is indexed by the tile's own rows (row0 + rb_out), dy by rb_in
     int half;                 // b2m_conv_wgrad_h: x and dy are IEEE binary16 (pitches in elements), converted on load; fp32 MFMA, fp32 dW
     float out_scale;          // ... and the block is multiplied by this on its way into dW (1 / loss scale)
+    int trh;                  // ... on the f16 MFMA through the transposing LDS read (conv_wgrad_trh_kernel)
 };
 // work item of a wave -> (offset k, block blk, tile range [t0, t1)); false: nothing to do.  A workgroup is (offset group,
 // block group, tile chunk); its 4 waves are 4 blocks of one offset (kpack = 1) or 4 / kpack blocks of kpack consecutive
@@ -1778,7 +1779,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_kernel(WgradArgs a) {
 #ifdef B2M_WGRAD_NOMFMA      // diagnostic build (wrong results): what the loop costs without its MFMAs -- the operands stay consumed
                         asm volatile("" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
 #else
-                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
+                    {
+                        // hipcc-tracked loads: the operands were just written by VALU instructions (the select of bz, the
+                        // conversions of the half form) and an MFMA that reads a VGPR fewer than 2 wait states after a VALU wrote
+                        // it reads the OLD value -- hipcc pads that for its own MFMAs, not for an asm statement.  (Seen in round
+                        // 6 on the half form's 2 x 2 blocks: the first MFMA of a k-step took bz[0] unmasked.  The hand-issued
+                        // form's select is an asm statement, behind which hipcc places one state of its own; tests/test_isa.py
+                        // checks the distance on every variant.)
+                        if (!HL && m == 0 && nn == 0)
+                            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
+                        else
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
+                    }
 #endif
             }
             asm volatile("" ::: "memory");                       // the refill stays behind the MFMAs that read the registers
@@ -1956,7 +1968,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_h_kernel(WgradArgs a) {
 #ifdef B2M_WGRAD_NOMFMA      // diagnostic build (wrong results): what the loop costs without its MFMAs -- the operands stay consumed
                         asm volatile("" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
 #else
-                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
+                    {
+                        // (VALU write -> MFMA operand: 2 wait states, see the fp32 kernel)
+                        if (!HL && m == 0 && nn == 0)
+                            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
+                        else
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[m][nn]) : "v"(az[m]), "v"(bz[nn]));
+                    }
 #endif
             }
             asm volatile("" ::: "memory");                       // the refill stays behind the MFMAs that read the registers
@@ -2000,6 +2018,174 @@ __global__ __launch_bounds__(256) void conv_wgrad_flow_h_kernel(WgradArgs a) {
                 }
             }
     B2M_CLOCK_END(3);
+}
+
+// Half operands on the f16 MFMA (round 6, the default of b2m_conv_wgrad_h).  dW[ci][co] = sum over pairs of x[pair][ci] * dy[pair][co]:
+// the MFMA's reduction index is the PAIR, and memory holds a pair's channels side by side -- v_mfma_f32_16x16x16_f16 wants lane
+// (i, g) to hold channel i of the four pairs 4g .. 4g+3.  The kernels above gather element by element (a 2-byte load per lane and
+// sub-tile, 4 (MI + NJ) loads per 16-pair slot) and multiply on the fp32 MFMA (4 MI NJ per slot): 69 % of the fp32 MFMA peak on the
+// 96 -> 96 layers, and that peak is the bound.  Here a wave
+//   * gathers the 16 rows of a slot with 16-byte loads (a lane = 8 channels of one pair: 2 MI / 64 + 2 NJ / 64 loads per slot),
+//   * writes them row-major into its own LDS image ([16 pairs][channels of the block], two buffers; no other wave reads it: no
+//     barrier, LDS operations of a wave complete in order),
+//   * reads the operands back with ds_read_b64_tr_b16 -- gfx950's transposing read: a group of 16 lanes takes a 4-row x 16-column
+//     block of 16-bit elements and lane i receives column i of the 4 rows, exactly the MFMA's A / B layout -- MI + NJ reads,
+//   * and issues MI NJ v_mfma_f32_16x16x16_f16 per slot (fp32 accumulators; the products of two halves are exact in fp32, so
+//     the sums differ from the kernels above by their order only).
+// Missing pairs are zero rows (the load's ADDRESS is switched to g_zeros); a slot always costs its MI NJ MFMAs (a quarter of one
+// fp32 k-step each).  Walk, work items, XCD order and the atomics into dW are those of conv_wgrad_flow_kernel; loads are tracked by
+// hipcc, the MFMAs are builtins (hipcc pads their hazards).  Row pitch of the LDS image: 32 B (MI = 1), 96 B (MI = 2, 3), 160 B
+// (MI = 4): the eight rows a 32-lane half reads start in eight different groups of 8 banks.
+typedef __fp16 b2m_h4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int M> struct TrhPitch { static constexpr int value = M == 1 ? 32 : M <= 3 ? 96 : 160; };
+template <int MI, int NJ, int SWP>
+__global__ __launch_bounds__(256) void conv_wgrad_trh_kernel(WgradArgs a) {
+    constexpr int SX = TrhPitch<MI>::value, SY = TrhPitch<NJ>::value;      // bytes per image row
+    constexpr int CPX = 2 * MI, CPY = 2 * NJ;                                // 16-byte chunks per row
+    constexpr int NX = (16 * CPX + 63) / 64, NY = (16 * CPY + 63) / 64;      // loads per slot and lane
+    constexpr int BUF = 16 * (SX + SY);                                      // one buffer: x image, dy image
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * 2 * BUF];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    int k, blk;
+    int64_t chunk, t0, t1;
+    if (!wgrad_item(a, wave, k, blk, chunk, t0, t1)) return;
+    const int ci0 = (blk / a.nnb) * 16 * MI, co0 = (blk % a.nnb) * 16 * NJ;
+    const int64_t ldr = a.ntiles * B2M_TILE;
+    const int nt = (int)(t1 - t0);
+    int cnt = 0;
+    if (lane < nt) cnt = a.rb_cnt[(int64_t)k * a.ntiles + t0 + lane];
+    const uint64_t live = __ballot(cnt > 0);
+    if (live == 0) return;
+    unsigned char* const lds = lds_all + wave * 2 * BUF;
+
+    auto pairs_of = [&](int ti, int g) { const int n = __builtin_amdgcn_readlane(cnt, ti) - 16 * g; return n > 16 ? 16 : n; };
+    auto advance = [&](int& ti, int& g) {
+        if (16 * (g + 1) < __builtin_amdgcn_readlane(cnt, ti)) { ++g; return true; }
+        const uint64_t rest_mask = ti >= 63 ? 0ull : (live >> (ti + 1));
+        if (rest_mask == 0) return false;
+        ti = ti + 1 + __builtin_ctzll(rest_mask); g = 0;
+        return true;
+    };
+    const int64_t kbase = (int64_t)k * ldr + t0 * B2M_TILE;
+    // entry i of the slot: input row | row inside the tile << 24, bit 31 = no pair
+    auto load_word = [&](int ti, int g) -> uint32_t {
+        const int64_t base = kbase + (int64_t)ti * B2M_TILE + 16 * g + i;
+        const int r_in = a.rb_in[base];
+        const uint32_t r_out = a.rb_out[base];
+        return (r_in < 0 || i >= pairs_of(ti, g)) ? 0x80000000u : ((uint32_t)r_in | (r_out << 24));
+    };
+    // chunk e = lane + 64 j of an image: pair e / CP, 16-byte chunk e % CP of its row
+    int px[NX], py[NY];
+    uint32_t cxb[NX], cyb[NY], lx[NX], ly[NY];
+    bool actx[NX], acty[NY];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int e = lane + 64 * j;
+        actx[j] = e < 16 * CPX;
+        px[j] = actx[j] ? e / CPX : 0;
+        cxb[j] = (uint32_t)(ci0 * 2 + 16 * (e % CPX));
+        lx[j] = (uint32_t)(px[j] * SX + 16 * (e % CPX));
+    }
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+        const int e = lane + 64 * j;
+        acty[j] = e < 16 * CPY;
+        py[j] = acty[j] ? e / CPY : 0;
+        cyb[j] = (uint32_t)(co0 * 2 + 16 * (e % CPY));
+        ly[j] = (uint32_t)(16 * SX + py[j] * SY + 16 * (e % CPY));
+    }
+    const uint32_t ldxb = (uint32_t)a.ldx * 2u, lddyb = (uint32_t)a.lddy * 2u;
+    const char* const zeros = (const char*)a.zeros;
+    u32x4 rx[NX], ry[NY];
+    auto gather = [&](int ti, uint32_t word) {
+        const uint32_t row0 = (uint32_t)((t0 + ti) * B2M_TILE);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(px[j] << 2, (int)word);
+            const uint32_t rlist = w & 0xFFFFFFu, rtile = row0 + ((w >> 24) & 63u);
+            const char* p = (const char*)a.x + (__umul24(SWP ? rtile : rlist, ldxb) + cxb[j]);
+            rx[j] = *(const u32x4*)(((int)w >= 0 && actx[j]) ? p : zeros);
+        }
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(py[j] << 2, (int)word);
+            const uint32_t rlist = w & 0xFFFFFFu, rtile = row0 + ((w >> 24) & 63u);
+            const char* p = (const char*)a.dy + (__umul24(SWP ? rlist : rtile, lddyb) + cyb[j]);
+            ry[j] = *(const u32x4*)(((int)w >= 0 && acty[j]) ? p : zeros);
+        }
+    };
+    auto store = [&](int buf) {
+        unsigned char* b = lds + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+            if (actx[j]) *(u32x4*)(b + lx[j]) = rx[j];
+#pragma unroll
+        for (int j = 0; j < NY; ++j)
+            if (acty[j]) *(u32x4*)(b + ly[j]) = ry[j];
+    };
+    // transposing read: lane 4q' + p' of a 16-lane group addresses row 4 group + q', columns 4p' .. 4p'+3 of the block
+    const uint32_t trx = (uint32_t)((4 * q + (i >> 2)) * SX + 8 * (i & 3));
+    const uint32_t try_ = (uint32_t)(16 * SX + (4 * q + (i >> 2)) * SY + 8 * (i & 3));
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) b2m_h4v* lds_h4;
+    auto compute = [&](int buf) {
+        unsigned char* b = lds + buf * BUF;
+        f16x4 av[MI], bv[NJ];
+#pragma unroll
+        for (int m = 0; m < MI; ++m) av[m] = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(b + trx + 32 * m)));
+#pragma unroll
+        for (int nn = 0; nn < NJ; ++nn) bv[nn] = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(b + try_ + 32 * nn)));
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NJ; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x16f16(av[m], bv[nn], acc[m][nn], 0, 0, 0);
+    };
+
+    // prologue: slot C staged in buffer 0, slot N's rows in flight, slot NN's list entry in flight
+    int tiC = __builtin_ctzll(live), gC = 0;
+    int tiN = tiC, gN = gC;
+    bool hasN = advance(tiN, gN);
+    int tiNN = tiN, gNN = gN;
+    bool hasNN = hasN && advance(tiNN, gNN);
+    {
+        const uint32_t wC = load_word(tiC, gC);
+        const uint32_t wN = hasN ? load_word(tiN, gN) : 0x80000000u;
+        gather(tiC, wC);
+        store(0);
+        gather(tiN, wN);
+    }
+    uint32_t wNN = hasNN ? load_word(tiNN, gNN) : 0x80000000u;
+    int buf = 0;
+    for (;;) {
+        compute(buf);
+        if (!hasN) break;
+        store(buf ^ 1);                     // slot N's rows have arrived (hipcc's wait); the buffer was read a slot ago
+        buf ^= 1;
+        hasN = hasNN; tiN = tiNN; gN = gNN;
+        if (hasN) {
+            gather(tiN, wNN);
+            hasNN = advance(tiNN, gNN);
+            if (hasNN) wNN = load_word(tiNN, gNN);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NJ; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + 16 * m + 4 * q + r, co = co0 + 16 * nn + i;
+                const float v = acc[m][nn][r] * a.out_scale;
+                if (v != 0.f) atomicAdd(&a.dw[(int64_t)k * a.dw_kstride + (int64_t)ci * a.lddw + co], v);
+            }
 }
 
 // Weight gradient of an identity map (1x1 layer) with FEW output channels -- the last layer of every head (96 -> 3 / 1 /
@@ -2082,6 +2268,24 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restri
 
 template <int MI>
 static void launch_wgrad_nj(int NJ, dim3 grid, hipStream_t st, const WgradArgs& a) {
+    if (a.trh) {                     // half operands, complete blocks, 16-byte aligned rows: f16 MFMA
+        if (a.swap) {
+            switch (NJ) {
+                case 1: conv_wgrad_trh_kernel<MI, 1, 1><<<grid, 256, 0, st>>>(a); break;
+                case 2: conv_wgrad_trh_kernel<MI, 2, 1><<<grid, 256, 0, st>>>(a); break;
+                case 3: conv_wgrad_trh_kernel<MI, 3, 1><<<grid, 256, 0, st>>>(a); break;
+                default: conv_wgrad_trh_kernel<MI, 4, 1><<<grid, 256, 0, st>>>(a); break;
+            }
+        } else {
+            switch (NJ) {
+                case 1: conv_wgrad_trh_kernel<MI, 1, 0><<<grid, 256, 0, st>>>(a); break;
+                case 2: conv_wgrad_trh_kernel<MI, 2, 0><<<grid, 256, 0, st>>>(a); break;
+                case 3: conv_wgrad_trh_kernel<MI, 3, 0><<<grid, 256, 0, st>>>(a); break;
+                default: conv_wgrad_trh_kernel<MI, 4, 0><<<grid, 256, 0, st>>>(a); break;
+            }
+        }
+        return;
+    }
     if (a.pipe && a.half) {          // half operands: the flat-pipeline kernel with hipcc-tracked loads, both row-role forms
         if (a.swap) {
             switch (NJ) {
@@ -2289,12 +2493,12 @@ static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_i
     // same registers) stays on the plain kernel, where the builtin lets hipcc place whatever the dependence needs.
     a.pipe = (a.fast32 && (rb_in != nullptr || (n_in >= n_out && env_flag("B2M_WGRAD_PIPE_IDENT", 1))) && MI * NJ >= 2 &&
               !workspace && env_flag("B2M_WGRAD_PIPE", 1)) ? 1 : 0;
-    // (half operands: blocks of at most four sub-tiles -- 32- and 64-channel layers -- stay on the plain kernel.  The flat-pipeline
-    // form with 2 x 2 blocks gives wrong sums there (tools/debug_wgrad_h.py: 0.6 of the maximum on 32->32 / 64->64, every larger
-    // block exact); its MFMAs are asm statements hipcc's hazard recogniser cannot see, and with four MFMAs between a k-step's
-    // conversions and the next one's nothing hides what it would have padded.  Not understood further; 1.5 ms of a 46 ms step.)
-    if (half && MI * NJ <= 4) a.pipe = 0;
+    // (diagnostics, tools/debug_wgrad_h22.py: half operands, blocks of at most four sub-tiles on the plain kernel)
+    if (half && MI * NJ <= 4 && env_flag("B2M_WGRAD_H_PIPE_SMALL", 1) == 0) a.pipe = 0;
     a.handloads = env_flag("B2M_WGRAD_HANDLOADS", 2);
+    // half operands: the f16-MFMA kernel wherever its 16-byte row chunks exist (complete blocks, aligned rows, a real rulebook)
+    a.trh = (half && a.fast32 && rb_in != nullptr && !workspace && cin % (16 * MI) == 0 && cout % (16 * NJ) == 0 &&
+             ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ldx % 8 == 0 && lddy % 8 == 0 && env_flag("B2M_WGRAD_TRH", 1)) ? 1 : 0;
     launch_wgrad(MI, NJ, grid, st, a);
     if (workspace) {
         const int nchunks = (int)cdiv64(a.ntiles, tpc);

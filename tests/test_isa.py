@@ -186,3 +186,43 @@ def test_the_register_trace_follows_the_path_that_skips_a_wait():
     assert isa_check.inflight_violations((asm % 'v_add_u32_e32 v2, 4, v2').split('\n')) == []
     hit = isa_check.inflight_violations((asm % 'v_lshrrev_b32_e32 v10, 24, v3').split('\n'))     # the "dead" register as a temporary
     assert [v[2] for v in hit] == [[10]]
+
+
+def test_no_mfma_reads_an_operand_a_valu_instruction_has_just_written(kernels):
+    """The flow kernels' MFMAs are asm statements: hipcc pads no hazard for them.  A VGPR written by a VALU instruction (the
+    select that zeroes a missing pair's dy, the half form's conversions) is read OLD by an MFMA issued fewer than two wait
+    states later.  Round 6: conv_wgrad_flow_h_kernel<2, 2> -- `v_cndmask v29; v_cndmask v28; v_mfma .., v26, v29` -- added the
+    UNMASKED dy of missing pairs into the first sub-tile of every block (dW 4 - 40 % too large at the offsets with few pairs),
+    while the 3 x 2 block, one conversion further from its first MFMA, was exact; the fp32 form was one `s_waitcnt` away from
+    the same.  The cure is `s_nop 1` in the first MFMA statement of a k-step; this is the check on EVERY kernel with MFMAs."""
+    import isa_check
+    path = isa_check.device_asm()
+    checked = 0
+    for name in sorted(kernels):
+        if kernels[name]['mfma']:
+            assert isa_check.mfma_operand_violations(isa_check.kernel_body(path, name)) == [], name
+            checked += 1
+    assert checked >= 150
+
+
+def test_the_operand_check_sees_the_hazard_it_is_there_for():
+    import isa_check
+    bad = """
+	v_cvt_f32_f16_e32 v26, v26
+	v_cndmask_b32_e32 v29, 0, v29, vcc
+	v_cndmask_b32_e32 v28, 0, v28, vcc
+	;;#ASMSTART
+	v_mfma_f32_16x16x4_f32 v[12:15], v26, v29, v[12:15]
+	;;#ASMEND
+	;;#ASMSTART
+	v_mfma_f32_16x16x4_f32 v[8:11], v26, v28, v[8:11]
+	;;#ASMEND
+""".split('\n')
+    v = isa_check.mfma_operand_violations(bad)
+    assert [x[2] for x in v] == [[29], [28]]
+    good = [l for l in bad]
+    good.insert(good.index('\t;;#ASMSTART') + 1, '\ts_nop 1')
+    assert isa_check.mfma_operand_violations(good) == []
+    # a wide accumulator written by a VALU move and read as A two instructions later: still too close by one state
+    assert isa_check.mfma_operand_violations(['v_mov_b32_e32 v4, 0', 's_waitcnt vmcnt(3)', 'v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]']) != []
+    assert isa_check.mfma_operand_violations(['v_mov_b32_e32 v4, 0', 's_nop 0', 's_waitcnt vmcnt(3)', 'v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]']) == []

@@ -90,6 +90,19 @@ for name, rb, K, c1, c2, co in cases:
         f_h = lambda: F_.conv_affine_h(x1h, x2h, wh, rbh, n_out)
         f_h(); torch.cuda.synchronize()
         line += ' | half fwd %6.2f TF' % (fl / min(timeit(f_h) for _ in range(4)) / 1e9)
+        if rb is not None and c2 == 0:
+            # ... and the half weight gradient (b2m_conv_wgrad_h): f16 MFMA through the transposing LDS read | operands converted on
+            # load, fp32 MFMA, flat pipeline | the same, plain kernel
+            from box2mask_amd import half_train as HT
+            dyh = dy.half(); dwh = torch.zeros_like(w)
+            f_wh = lambda: HT._wgrad_h(x1h, dyh, rb, K, dwh, 0, 1.0)
+            for tag, env in (('trh', {}), ('cvt', {'B2M_WGRAD_TRH': '0'}), ('plain', {'B2M_WGRAD_TRH': '0', 'B2M_WGRAD_PIPE': '0'})):
+                for k_ in SWITCHES + ('B2M_WGRAD_TRH',): os.environ.pop(k_, None)
+                os.environ.update(env); _lib.reload_env()
+                f_wh(); torch.cuda.synchronize()
+                line += ' half wg %s %6.2f TF' % (tag, fl / min(timeit(f_wh) for _ in range(4)) / 1e9)
+            for k_ in SWITCHES + ('B2M_WGRAD_TRH',): os.environ.pop(k_, None)
+            _lib.reload_env()
     for v, _ in VARIANTS:
         line += ' | %s fwd %6.2f TF wg %6.2f TF' % (v, fl / min(res[v][0]) / 1e9, fl / min(res[v][1]) / 1e9)
         if CORUN:

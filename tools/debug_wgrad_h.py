@@ -8,12 +8,12 @@ from test_gpu_ops import _scene
 b = _scene()
 m = CoordinateManager(b['vox_coords']); m.ensure_level(2)
 HT.loss_scale[0] = 1.0
-for (lvl, cin, cout) in ((0, 32, 32), (0, 64, 64), (0, 32, 128), (0, 128, 32), (0, 32, 96)):
+for (lvl, cin, cout) in ((0, 32, 32), (0, 64, 64), (0, 32, 128), (0, 128, 32), (0, 32, 96), (0, 96, 96), (1, 128, 128), (1, 16, 48), (1, 48, 16), (2, 256, 128)):
     rb = m.rulebook_same(lvl, 3); n = m.n(lvl)
     torch.manual_seed(1)
     x = torch.randn(n, cin, device='cuda').half(); dy = torch.randn(n, cout, device='cuda').half()
-    for env in ({}, {'B2M_WGRAD_PIPE': '0'}, {'B2M_WGRAD_HANDLOADS': '0'}):
-        for k_ in ('B2M_WGRAD_KPACK', 'B2M_WGRAD_PIPE', 'B2M_XCD_BALANCE', 'B2M_WGRAD_HANDLOADS'): os.environ.pop(k_, None)
+    for env in ({}, {'B2M_WGRAD_TRH': '0'}, {'B2M_WGRAD_TRH': '0', 'B2M_WGRAD_PIPE': '0'}, {'B2M_WGRAD_KPACK': '0'}, {'B2M_XCD_BALANCE': '0'}):
+        for k_ in ('B2M_WGRAD_KPACK', 'B2M_WGRAD_PIPE', 'B2M_XCD_BALANCE', 'B2M_WGRAD_HANDLOADS', 'B2M_WGRAD_TRH'): os.environ.pop(k_, None)
         os.environ.update(env); _lib.reload_env()
         dwh = torch.zeros(27, cin, cout, device='cuda'); dwf = torch.zeros(27, cin, cout, device='cuda')
         HT._wgrad_h(x, dy, rb, 27, dwh, 0, 1.0)

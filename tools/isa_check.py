@@ -170,6 +170,37 @@ def inflight_violations(body):
     return [bad[k] for k in sorted(bad)]
 
 
+def mfma_operand_violations(body, states=2):
+    """An MFMA written as an asm statement is invisible to hipcc's hazard recogniser: a VGPR a VALU instruction wrote fewer than
+    `states` wait states earlier is read OLD by the MFMA's A / B operand (round 6: the half weight gradient's 2 x 2 blocks took
+    bz[0] unmasked in the first MFMA of every k-step).  Linear scan of the text, branches not followed: every instruction is one
+    state, `s_nop N` is N + 1; a label keeps the history (the fall-through path is a real path).  Returns (line, mfma text,
+    registers, states since the write)."""
+    bad = []
+    recent = []          # (destination registers, states since) of VALU writes, youngest last
+    for k, raw in enumerate(body):
+        l = raw.split(';')[0].strip()
+        if not l or l.endswith(':') or l.startswith('.') or l.startswith(';;'):
+            continue
+        ops = l.split(None, 1)
+        op = ops[0]
+        cost = 1
+        m = re.match(r's_nop\s+(\d+)', l)
+        if m:
+            cost = int(m.group(1)) + 1
+        if op.startswith('v_mfma') and len(ops) > 1:
+            parts = [x.strip() for x in ops[1].split(',')]
+            # "v[12:15], v26, v29, v[12:15]": operands 1 and 2 are A and B
+            ab = _regs(parts[1]) | _regs(parts[2]) if len(parts) >= 3 else set()
+            for dst, age in recent:
+                if age < states and dst & ab:
+                    bad.append((k, l, sorted(dst & ab), age))
+        recent = [(d, a + cost) for d, a in recent if a + cost < 8]
+        if op.startswith('v_') and not op.startswith(('v_mfma', 'v_cmp', 'v_nop')) and len(ops) > 1:
+            recent.append((_regs(ops[1].split(',')[0]), 0))
+    return bad
+
+
 if __name__ == '__main__':
     ks = kernels(device_asm())
     pats = sys.argv[1:] or ['conv_fwd_flow_kernel', 'conv_wgrad_flow_kernel', 'conv_stem_kernel', 'conv_1x1']
@@ -181,3 +212,5 @@ if __name__ == '__main__':
                 k['mfma'], k['loop_waits']))
             for v in inflight_violations(kernel_body(device_asm(), n)):
                 print('    register of a load in flight touched: line %d  %s  %s' % v)
+            for v in mfma_operand_violations(kernel_body(device_asm(), n)):
+                print('    MFMA operand written by a VALU instruction %d state(s) earlier: line %d  %s  %s' % (v[3], v[0], v[1], v[2]))
