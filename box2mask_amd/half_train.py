@@ -15,7 +15,8 @@ stay fp32, as do the weights (master copies, the optimizer's); every accumulatio
   the region produces is multiplied by 1 / loss_scale by the operator that produced it, and the gradient that leaves the region
   towards the stem (`to_half`) likewise -- outside the region nothing is scaled.
 
-Turned on by `SelectionNet.half_training = True` (or `cfg.half_training`); single process only (no SyncBN form).  The layers
+Turned on by `SelectionNet.half_training = True` (or `cfg.half_training`); under data parallelism the BatchNorm takes its SyncBN form
+(one packed exchange per direction, as the fp32 operator) and the fp32 parameter gradients travel as always.  The layers
 (`nn.MinkowskiConvolution` ...) route here by the dtype of their input.  Semantics per operator: those of `functional._SparseConv`
 / `functional._BatchNorm` (/root/reference/models/resnet.py:61-83, detection_net.py:37-135)."""
 from __future__ import annotations
@@ -168,25 +169,43 @@ def _workspace(c, device):
 
 
 class _BatchNormH(torch.autograd.Function):
-    """y = [relu](BN(x) [+ residual]) in training mode, half in / out (functional._BatchNorm's local-statistics branch)."""
+    """y = [relu](BN(x) [+ residual]) in training mode, half in / out (functional._BatchNorm's large-map branches).  sync: SyncBN
+    (/root/reference/models/model.py:25) -- the ranks' column sums and row counts meet in one packed fp64 all-reduce per direction,
+    exactly as in functional._BatchNorm: (sum x, sum x^2, n) forward, (sum g, sum g xhat) backward; the parameter gradients stay this
+    rank's own sums (the gradient all-reduce averages them)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, sync=False):
         x = _hc(x)
         n, c = x.shape
         dev = x.device
-        if n <= 1:
+        group = F_._sync_group() if sync else None
+        if n <= 1 and group is None:
             raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(x.shape),))
         residual = _hc(residual) if residual is not None else None
         f32 = lambda: torch.empty(c, dtype=torch.float32, device=dev)
         mean, invstd, scale, shift = f32(), f32(), f32(), f32()
-        _call('b2m_bn_stats_finalize_h', x.data_ptr(), x.stride(0), n, c, _workspace(c, dev).data_ptr(), _ptr(gamma), _ptr(beta), eps,
-              momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+        count_dev = None
+        if group is None:
+            _call('b2m_bn_stats_finalize_h', x.data_ptr(), x.stride(0), n, c, _workspace(c, dev).data_ptr(), _ptr(gamma), _ptr(beta), eps,
+                  momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+        else:
+            stats = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+            if n > 0:
+                _call('b2m_bn_stats_h', x.data_ptr(), x.stride(0), n, c, _workspace(c, dev).data_ptr(), stats.data_ptr())
+            else:
+                stats.zero_()
+            stats[2 * c:].fill_(float(n))
+            F_._sync_all_reduce(stats, group)
+            count_dev = stats[2 * c:]
+            _call('b2m_bn_finalize', stats.data_ptr(), 0.0, count_dev.data_ptr(), c, _ptr(gamma), _ptr(beta), eps, momentum,
+                  _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
         y = torch.empty_like(x)
-        _call('b2m_bn_apply_h', x.data_ptr(), x.stride(0), n, c, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
-              residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
+        if n > 0:
+            _call('b2m_bn_apply_h', x.data_ptr(), x.stride(0), n, c, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
+                  residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
         ctx.save_for_backward(x, y if relu else None, gamma, beta, mean, invstd)
-        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        ctx.relu, ctx.has_res, ctx.sync, ctx.count_dev = bool(relu), residual is not None, bool(sync), count_dev
         return y
 
     @staticmethod
@@ -201,20 +220,28 @@ class _BatchNormH(torch.autograd.Function):
             dbeta = torch.empty(c, dtype=torch.float32, device=dev)
             dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
-        _call('b2m_bn_bwd_reduce_h', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
-              x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _workspace(c, dev).data_ptr(), sums.data_ptr(),
-              dbeta.data_ptr(), dgamma.data_ptr(), 1.0 / loss_scale[0])       # (the sums are of the SCALED gradient)
+        if n > 0:
+            _call('b2m_bn_bwd_reduce_h', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
+                  x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _workspace(c, dev).data_ptr(), sums.data_ptr(),
+                  dbeta.data_ptr(), dgamma.data_ptr(), 1.0 / loss_scale[0])       # (the sums are of the SCALED gradient)
+        else:
+            sums.zero_(); dbeta.zero_(); dgamma.zero_()
+        group = F_._sync_group() if ctx.sync else None
+        if group is not None:
+            F_._sync_all_reduce(sums, group)          # (dbeta / dgamma were taken from this rank's sums by the kernel above)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.needs_input_grad[7]) else None
-        _call('b2m_bn_bwd_apply_h', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
-              x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), sums.data_ptr(), float(n), None, relu,
-              dx.data_ptr(), dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0)
+        if n > 0:
+            _call('b2m_bn_bwd_apply_h', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
+                  x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), sums.data_ptr(), float(n),
+                  _ptr(ctx.count_dev) if group is not None else None, relu,
+                  dx.data_ptr(), dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, None, None, None,
-                None, dres, None)
+                None, dres, None, None)
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=False):
-    return _BatchNormH.apply(x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu)
+def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=False, sync=False):
+    return _BatchNormH.apply(x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, sync)
 
 
 class _ToHalf(torch.autograd.Function):

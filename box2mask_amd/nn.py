@@ -217,9 +217,8 @@ class MinkowskiBatchNorm(nn.Module):
             from . import half_train as HT
             if not training:
                 raise RuntimeError('half activations outside inference need training-mode BatchNorm (half_train.py)')
-            if self.sync and F_._sync_group() is not None:
-                raise RuntimeError('half-precision training has no SyncBN form: one process only')
-            return HT.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, residual, relu)
+            return HT.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, residual, relu,
+                                 bool(self.sync))
         return F_.batch_norm(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
                              bn.momentum, bn.eps, residual, relu, self.sync, count_key)
 
