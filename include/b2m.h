@@ -280,7 +280,10 @@ int b2m_conv_wgrad_tr(const float* x, int64_t ldx, int32_t cin, int64_t n_in, co
  * Pointers to half data are `void*`, pitches in ELEMENTS (multiples of 4, rows 8-byte aligned).
  *   b2m_conv_wgrad_h      dW[k][ci][co] += out_scale * sum_pairs X[i, ci] * dY[o, co] with X, dY half, dW fp32 (atomics; out_scale =
  *                         1 / loss scale).  tr != 0: the rulebook's row roles exchanged (b2m_conv_wgrad_tr).  Replaces [ME]
- *                         ConvolutionBackward (weight part).
+ *                         ConvolutionBackward (weight part).  With complete 16-channel blocks, 16-byte aligned rows (pitches in
+ *                         multiples of 8 elements) and a real rulebook the products run on the f16 MFMA (operands transposed by
+ *                         ds_read_b64_tr_b16; the product of two halves is exact in fp32, the sums differ by their order);
+ *                         otherwise the operands are converted on load and multiplied on the fp32 MFMA.
  *   b2m_bn_stats_h        column sums / sums of squares of a half tensor (fp64; partial: 2*c*4096 doubles; stats: 2*c).
  *   b2m_bn_apply_h        y = [relu](fmaf(x, scale, shift) [+ res]), half in / out.
  *   b2m_bn_bwd_reduce_h   sums[0:c] = sum g, sums[c:2c] = sum g * xhat with g = dy * (y > 0) (relu); dbeta / dgamma = the sums as

@@ -69,6 +69,12 @@ PINNED = {
     '_Z22conv_wgrad_flow_kernelILi4ELi4ELi0ELi0EEv9WgradArgs': (128, 4, True),
     '_Z22conv_wgrad_flow_kernelILi2ELi2ELi0ELi0EEv9WgradArgs': (64, 8, True),
     '_Z16conv_stem_kernelILb0EEv8ConvArgs': (128, 4, True),                       # the 5x5x5 first layer
+    # half weight gradient on the f16 MFMA (round 6; hipcc-tracked loads, builtin MFMAs: accumulators in AGPRs, occupancy by LDS)
+    '_Z21conv_wgrad_trh_kernelILi3ELi3ELi0EEv9WgradArgs': (64, 5, False),
+    '_Z21conv_wgrad_trh_kernelILi3ELi3ELi1EEv9WgradArgs': (64, 5, False),
+    '_Z21conv_wgrad_trh_kernelILi2ELi2ELi0EEv9WgradArgs': (48, 6, False),
+    '_Z21conv_wgrad_trh_kernelILi4ELi4ELi0EEv9WgradArgs': (80, 3, False),
+    '_Z21conv_wgrad_trh_kernelILi2ELi3ELi0EEv9WgradArgs': (56, 6, False),
     '_Z15conv_1x1_kernelILi3EEv8ConvArgs': (176, 2, False),                        # 1x1 streaming GEMM (compiler-scheduled waits)
     '_Z15conv_1x1_kernelILi2EEv8ConvArgs': (168, 3, False),
 }
@@ -226,3 +232,25 @@ def test_the_operand_check_sees_the_hazard_it_is_there_for():
     # a wide accumulator written by a VALU move and read as A two instructions later: still too close by one state
     assert isa_check.mfma_operand_violations(['v_mov_b32_e32 v4, 0', 's_waitcnt vmcnt(3)', 'v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]']) != []
     assert isa_check.mfma_operand_violations(['v_mov_b32_e32 v4, 0', 's_nop 0', 's_waitcnt vmcnt(3)', 'v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]']) == []
+
+
+def test_half_weight_gradient_reads_its_operands_transposed(kernels):
+    """conv_wgrad_trh_kernel: per 16-pair slot MI + NJ `ds_read_b64_tr_b16` (gfx950's transposing LDS read) feed MI x NJ
+    v_mfma_f32_16x16x16_f16 whose accumulators stay in AGPRs for the whole walk -- no accumulator copies inside the loop (what the
+    fp32 kernels' builtin form suffered from in round 1), 16-byte gathers, 16-byte LDS writes."""
+    import isa_check
+    path = isa_check.device_asm()
+    for mi, nj in ((3, 3), (2, 2), (4, 4), (2, 4)):
+        body = isa_check.kernel_body(path, '_Z21conv_wgrad_trh_kernelILi%dELi%dELi0EEv9WgradArgs' % (mi, nj))
+        text = '\n'.join(body)
+        assert text.count('ds_read_b64_tr_b16') == mi + nj, (mi, nj)
+        mf = [l for l in body if 'v_mfma' in l]
+        assert len(mf) == mi * nj and all('v_mfma_f32_16x16x16_f16 a[' in l for l in mf), mf[:2]
+        first = next(i for i, l in enumerate(body) if 'v_mfma' in l)
+        loop_top = max(i for i in range(first) if 'Loop Header' in body[i])
+        back = max(i for i, l in enumerate(body) if re.search(r's_cbranch\w*\s+' + re.escape(body[loop_top].split(':')[0]), l) or
+                   re.search(r's_branch\s+' + re.escape(body[loop_top].split(':')[0]), l))
+        loop = body[loop_top:back + 1]
+        assert not any('v_accvgpr' in l for l in loop), [l for l in loop if 'v_accvgpr' in l][:3]
+        assert any('global_load_dwordx4' in l for l in loop) and any('ds_write_b128' in l for l in loop)
+        assert not any('global_load_ushort' in l or 'global_load_short' in l for l in loop)
