@@ -472,7 +472,7 @@ def main():
                          'final_loss': round(float(lq['optimization_loss'].item()), 4),
                          'what': 'the timed step with SelectionNet.half_training: activations and activation gradients of the trunk '
                                  'as IEEE half in HBM (b2m_conv_fwd_h forward + data gradient, b2m_conv_wgrad_h, b2m_bn_*_h), fp32 stem, '
-                                 'pooling, heads, master weights and Adam; weight gradient on the fp32 MFMA (operands converted on load)'}
+                                 'pooling, heads, master weights and Adam; weight gradient on the f16 MFMA (operands transposed by ds_read_b64_tr_b16; fp32 accumulation)'}
         finally:
             model.detection_model.half_training = False
 
