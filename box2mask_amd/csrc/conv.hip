@@ -2457,6 +2457,16 @@ static int conv_wgrad_impl(const float* x, int64_t ldx, int32_t cin, int64_t n_i
     const int min_tiles = env_flag("B2M_WGRAD_MIN_TILES", (rb_in == nullptr && a.ntiles <= 1024) ? 2 : a.ntiles >= 32 ? 8 : 4);
     if (tpc < min_tiles) tpc = min_tiles;
     { const int mx = large ? 32 : 64; if (tpc > mx) tpc = mx; }
+    // (half operands on the f16 MFMA, conv_wgrad_trh_kernel: a slot costs a quarter of its fp32 MFMA time, so a wave's fixed costs
+    // -- the MI NJ x 256 atomics at its end above all -- weigh four times as much: chunks of 16 tiles wherever that still leaves
+    // 500 workgroups.  Level 1 128->128 124 -> 209 TFLOP/s, level 1 96->96 121 -> 170, level 2 128->128 115 -> 166, level 3
+    // 256->256 125 -> 158; with fewer workgroups (level 3 128->128: 270) 95 -> 71, and the transposed maps lose: both keep 8.)
+    if (half && !tr && rb_in != nullptr && !workspace && tpc < 16 && b2m_env_int("B2M_WGRAD_MIN_TILES", -1) < 0) {
+        const int nblk_ = a.nmb * a.nnb;
+        const int kp_ = (nblk_ <= 2 && K >= 4 && env_flag("B2M_WGRAD_KPACK", 1)) ? 4 / nblk_ : 1;
+        const int64_t wgs16 = (int64_t)((K + kp_ - 1) / kp_) * ((nblk_ + 3) / 4) * cdiv64(a.ntiles, 16);
+        if (wgs16 >= 500 && env_flag("B2M_WGRAD_TRH", 1)) tpc = 16;
+    }
     // Deterministic mode (workspace given): at most B2M_WGRAD_DET_CHUNKS tile chunks, every chunk stores its partial
     // blocks plainly and a second kernel adds them up in chunk order -- no atomics, the same bits on every run.
     a.partial = workspace;

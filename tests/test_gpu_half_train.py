@@ -192,8 +192,8 @@ def test_half_training_pass_against_the_fp32_pass(monkeypatch):
         z = bn32(x, gamma, beta, rm, rv, training, momentum, eps, residual, False, sync, count_key)
         return z * take(z).to(z.dtype) if relu else z
 
-    def p_bn16(x, gamma, beta, rm, rv, momentum, eps, residual=None, relu=False):
-        z = bn16(x, gamma, beta, rm, rv, momentum, eps, residual, False)
+    def p_bn16(x, gamma, beta, rm, rv, momentum, eps, residual=None, relu=False, sync=False):
+        z = bn16(x, gamma, beta, rm, rv, momentum, eps, residual, False, sync)
         return z * take(z).to(z.dtype) if relu else z
     monkeypatch.setattr(F_, 'batch_norm', p_bn32)
     monkeypatch.setattr(HT, 'batch_norm', p_bn16)

@@ -96,7 +96,7 @@ for name, rb, K, c1, c2, co in cases:
             from box2mask_amd import half_train as HT
             dyh = dy.half(); dwh = torch.zeros_like(w)
             f_wh = lambda: HT._wgrad_h(x1h, dyh, rb, K, dwh, 0, 1.0)
-            for tag, env in (('trh', {}), ('cvt', {'B2M_WGRAD_TRH': '0'}), ('plain', {'B2M_WGRAD_TRH': '0', 'B2M_WGRAD_PIPE': '0'})):
+            for tag, env in [('trh', {})] + [('trh ' + kv, dict([kv.split('=')])) for kv in os.environ.get('HALF_WG_VARIANTS', '').split(';') if kv] + [('cvt', {'B2M_WGRAD_TRH': '0'}), ('plain', {'B2M_WGRAD_TRH': '0', 'B2M_WGRAD_PIPE': '0'})]:
                 for k_ in SWITCHES + ('B2M_WGRAD_TRH',): os.environ.pop(k_, None)
                 os.environ.update(env); _lib.reload_env()
                 f_wh(); torch.cuda.synchronize()
