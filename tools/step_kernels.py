@@ -5,12 +5,16 @@ duration of the kernel behind the gap -- where the launches are and whose gaps t
     python tools/step_kernels.py <kernel_trace.csv> [first step] [last step]      (default -24 -20: the timed region)"""
 import collections
 import csv
+import re
 import sys
 
 
 def klass(n):
     if n.startswith('void '):
         n = n[5:]
+    m = re.match(r'_Z\d+([a-z_0-9]+?)(?:I|P|v|E)', n)          # a mangled name (kernels with _Float16 parameters are not demangled)
+    if m:
+        n = m.group(1)
     for pre, k in (('conv_wgrad', 'wgrad'), ('wgrad_narrow', 'wgrad'), ('conv_', 'conv_fwd'), ('bn_', 'batchnorm'),
                    ('reduce_final', 'batchnorm'), ('__amd_rocclr_copy', 'rt copy'), ('__amd_rocclr_fill', 'rt memset'),
                    ('at::', 'torch'), ('rocprim', 'torch'), ('deep_', 'deep program'), ('weight_pack', 'weight pack'), ('pool_', 'pooling')):
@@ -33,13 +37,14 @@ def main():
     steps = list(zip(marks, marks[1:]))[lo:hi]
     cnt = collections.Counter(); busy = collections.Counter(); idle = collections.Counter(); idle_n = collections.Counter()
     by_len = collections.Counter(); by_len_n = collections.Counter(); queues = collections.Counter()
+    per_q = collections.defaultdict(collections.Counter)
     wall = union = 0.0
     for a, b in steps:
         seq = rows[a:b]
         t0, cur_end = seq[0][0], seq[0][0]
         for s, e, n, q in seq:
             k = klass(n)
-            cnt[k] += 1; busy[k] += e - s; queues[q] += 1
+            cnt[k] += 1; busy[k] += e - s; queues[q] += 1; per_q[q][k] += e - s
             if s > cur_end:
                 g = s - cur_end
                 idle[k] += g; idle_n[k] += 1
@@ -58,6 +63,10 @@ def main():
     print('%-18s %9s %9s %12s %9s' % ('class', 'launches', 'ms/step', 'idle before', 'gaps'))
     for k, _ in busy.most_common():
         print('%-18s %9.1f %9.3f %12.3f %9.1f' % (k, cnt[k] / ns, busy[k] / ns / 1e6, idle[k] / ns / 1e6, idle_n[k] / ns))
+    print('per queue (stream): kernel time by class, ms/step')
+    for qid in sorted(per_q):
+        tot = sum(per_q[qid].values())
+        print('   queue %-3s %8.3f  %s' % (qid, tot / ns / 1e6, '  '.join('%s %.2f' % (k, v / ns / 1e6) for k, v in per_q[qid].most_common(6))))
     print('idle in front of kernels by THEIR duration:')
     for c in ('<10us', '10-30us', '30-100us', '>=100us'):
         print('   %-9s %8.3f ms/step in %6.1f gaps' % (c, by_len[c] / ns / 1e6, by_len_n[c] / ns))
