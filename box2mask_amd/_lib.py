@@ -52,6 +52,7 @@ PROTOTYPES = {
     'b2m_conv_up': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, P, I64, I32, I64, I32, P, P, P, I64, I32, P, P],
     'b2m_weight_pack': [P, I64, I32, I32, I32, I32, I32, I32, I32, P, P],
     'b2m_weight_pack_run': [P, I32, I64, P],
+    'b2m_weight_pack_h_run': [P, I32, I64, P],
     'b2m_conv_wgrad': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P, P],
     'b2m_conv_wgrad_tr': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, P, P],
     'b2m_bn_stats': [P, I64, I64, I32, P, P, P],
@@ -113,6 +114,8 @@ PLAIN = {'b2m_last_error': (C.c_char_p, []), 'b2m_version': (C.c_int, []), 'b2m_
          'b2m_weight_pack_h_size': (C.c_int64, [I32, I32, I32, I32]),
          'b2m_unique_insert': (C.c_int64, [P, I64, P, I64, P, P, P, P]),
          'b2m_weight_pack_plan_size': (C.c_int32, []),
+         'b2m_weight_pack_h_plan_size': (C.c_int32, []),
+         'b2m_weight_pack_h_plan': (C.c_int64, [I32, P, P, P, P, P, P, P, P, P, P, P]),
          'b2m_rulebook_cnt_size': (C.c_int64, [I32, I64]),
          'b2m_radix_argsort_scratch': (C.c_int64, [I64]),
          'b2m_xchg_size': (C.c_int64, []), 'b2m_xchg_max_doubles': (C.c_int32, []), 'b2m_xchg_max_ranks': (C.c_int32, []),

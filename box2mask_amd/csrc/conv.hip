@@ -1284,6 +1284,74 @@ extern "C" int b2m_weight_pack_h_t(const float* w, int32_t K, int32_t cin, int32
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
+// ---- every half image of a training step in ONE launch (half-precision training: a forward image and one or two transposed
+// images per layer, ~90 per step): a table of descriptors built on the host once (b2m_weight_pack_h_plan), kept on the device.
+struct PackHDesc {
+    const float* w; _Float16* wp;
+    int64_t sk, sci, sco, total, first_block;
+    int32_t mirror, K, cin, cout, CK, TW;
+};
+#define PACKH_PER_WG 2048          // elements of an image per workgroup
+extern "C" int32_t b2m_weight_pack_h_plan_size(void) { return (int32_t)sizeof(PackHDesc); }
+extern "C" int64_t b2m_weight_pack_h_plan(int32_t n, const int64_t* w, const int64_t* wp, const int32_t* K, const int32_t* cin,
+                                          const int32_t* cout, const int32_t* c1, const int32_t* transposed, const int32_t* mirror,
+                                          const int32_t* s0, const int32_t* sc, void* plan_host) {
+    B2M_CHECK_ARG(n >= 0 && (n == 0 || (w && wp && K && cin && cout && c1 && transposed && mirror && s0 && sc && plan_host)), "bad arguments");
+    PackHDesc* d = (PackHDesc*)plan_host;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        B2M_CHECK_ARG(w[i] && wp[i] && K[i] >= 1 && cin[i] > 0 && cout[i] > 0, "bad layer");
+        PackHDesc e;
+        e.wp = (_Float16*)(uintptr_t)wp[i]; e.K = K[i]; e.sk = (int64_t)cin[i] * cout[i];
+        if (!transposed[i]) {          // b2m_weight_pack_h(w, cout, K, c1, cin - c1, cout)
+            const int c2 = cin[i] - c1[i];
+            B2M_CHECK_ARG(c1[i] > 0 && c2 >= 0 && c1[i] % 16 == 0 && c2 % 16 == 0, "input channels of both sources must be multiples of 16");
+            e.w = (const float*)(uintptr_t)w[i]; e.sci = cout[i]; e.sco = 1; e.mirror = 0;
+            e.cin = cin[i]; e.cout = cout[i]; e.CK = conv_h_ck(c1[i], c2); e.TW = conv_tw(cout[i], K[i]);
+            e.total = b2m_weight_pack_h_size(K[i], c1[i], c2, cout[i]);
+        } else {                       // b2m_weight_pack_h_t(w, K, cin, cout, mirror, s0, sc)
+            B2M_CHECK_ARG(s0[i] >= 0 && sc[i] > 0 && s0[i] + sc[i] <= cin[i] && cout[i] % 16 == 0, "bad channel slice");
+            e.w = (const float*)(uintptr_t)w[i] + (int64_t)s0[i] * cout[i]; e.sci = 1; e.sco = cout[i]; e.mirror = mirror[i] ? 1 : 0;
+            e.cin = cout[i]; e.cout = sc[i]; e.CK = conv_h_ck(cout[i], 0); e.TW = conv_tw(sc[i], K[i]);
+            e.total = b2m_weight_pack_h_size(K[i], cout[i], 0, sc[i]);
+        }
+        e.first_block = blocks;
+        blocks += cdiv64(e.total, PACKH_PER_WG);
+        d[i] = e;
+    }
+    return blocks;
+}
+__global__ __launch_bounds__(256) void weight_pack_h_batch_kernel(const PackHDesc* __restrict__ plan, int n) {
+    // the image of this workgroup: the last descriptor whose first block is not behind it
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (plan[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackHDesc d = plan[lo];
+    const int E = d.CK / 4, SW = 16 * d.TW, BLK = 64 * d.TW * E;
+    const int nchunk = d.cin / d.CK, nstrip = (d.cout + SW - 1) / SW;
+    const int64_t e0 = ((int64_t)blockIdx.x - d.first_block) * PACKH_PER_WG;
+    for (int u = threadIdx.x; u < PACKH_PER_WG; u += 256) {
+        const int64_t e = e0 + u;
+        if (e >= d.total) break;
+        const int pos = (int)(e % BLK);
+        const int t = pos / (64 * E), lane = (pos / E) % 64, j = pos % E;
+        const int64_t blk = e / BLK;
+        const int chunk = (int)(blk % nchunk); const int64_t b2 = blk / nchunk;
+        const int strip = (int)(b2 % nstrip), k = (int)(b2 / nstrip);
+        const int ci = chunk * d.CK + E * (lane >> 4) + j, co = strip * SW + 16 * t + (lane & 15);
+        const int kk = d.mirror ? d.K - 1 - k : k;
+        d.wp[e] = (co < d.cout) ? (_Float16)d.w[(int64_t)kk * d.sk + (int64_t)ci * d.sci + (int64_t)co * d.sco] : (_Float16)0.f;
+    }
+}
+extern "C" int b2m_weight_pack_h_run(const void* plan_dev, int32_t n, int64_t total_blocks, void* stream) {
+    B2M_CHECK_ARG(n >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31) && (n == 0 || plan_dev), "bad arguments");
+    if (n == 0 || total_blocks == 0) return B2M_OK;
+    weight_pack_h_batch_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>((const PackHDesc*)plan_dev, n);
+    B2M_LAUNCH_CHECK();
+    return B2M_OK;
+}
 // Y(half) = [relu]( conv(X1 | X2)(half) * scale + shift [+ res(half)] ) through conv_fwd_flow_kernel<.., F16>: real rulebooks
 // only (a 1x1 layer comes with the identity rulebook of its map: b2m_rulebook of K = 1), input channels of both sources in
 // multiples of 16, output channels in multiples of 16, 16-byte aligned rows.  scale / shift may be NULL (plain convolution).

@@ -180,6 +180,7 @@ class SelectionNet(ResNetBase):
         if half_train:
             from . import half_train as HT
             HT.loss_scale[0] = float(getattr(self.cfg, 'half_loss_scale', 1024.0))
+            HT.images.begin_pass()                  # every half weight image of the step in one launch, beside the stem
             out_p1 = out_p1.new(HT.to_half(out_p1.F))
         if half:
             if not self.bn0.fusable():

@@ -41,29 +41,108 @@ def _hc(t):
     return t if t.stride(1) == 1 else t.contiguous()
 
 
-# ---- half images of the TRANSPOSED weights (the data gradient's operand), cached like functional.weight_pack_h
-_images_t = {}
+# ---- the half images of a training step: forward image and transposed image(s) of every layer, repacked in ONE launch per pass
+class _HalfImages:
+    """Every (weight, form) a half layer asks for is registered on first use with a persistent image; `begin_pass()` (SelectionNet.
+    forward with half_training) repacks all of them from the current weights with one b2m_weight_pack_h_run launch on the side
+    stream -- the first layer that asks for an image makes its stream wait -- and opens a new pass; lookups during that forward and
+    its backward are hits: 1 launch per step instead of ~90.  The rules are those of functional._PackedWeights: begin_pass repacks
+    unconditionally (a fused optimizer bumps no version counter); outside a pass opened for the current weights an image is reused
+    only if the tensor's version counter and address are unchanged, else repacked on the spot; entries die with their tensors."""
+
+    def __init__(self):
+        self.entries = {}          # key -> [weakref(weight), (K, cin, cout, c1, transposed, mirror, s0, sc), image, version, data_ptr, pass_id]
+        self.plan = None           # (device table, n, blocks, keys)
+        self.dirty = True
+        self.pass_id = 0
+        self.pending = None        # event of the side-stream launch of this pass
+
+    @staticmethod
+    def _pack_one(w3, d, image):
+        K, cin, cout, c1, transposed, mirror, s0, sc = d
+        if transposed:
+            _call('b2m_weight_pack_h_t', w3.data_ptr(), K, cin, cout, 1 if mirror else 0, s0, sc, image.data_ptr())
+        else:
+            _call('b2m_weight_pack_h', w3.data_ptr(), cout, K, c1, cin - c1, cout, image.data_ptr())
+
+    def get(self, weight, c1=0, transposed=False, mirror=False, s0=0, sc=0):
+        w3 = weight.detach()
+        w3 = w3 if w3.dim() == 3 else w3.unsqueeze(0)
+        assert w3.dtype == torch.float32 and w3.is_contiguous()
+        K, cin, cout = w3.shape
+        key = (id(weight), int(c1), bool(transposed), bool(mirror), int(s0), int(sc))
+        e = self.entries.get(key)
+        if e is not None and e[0]() is weight and e[4] == weight.data_ptr():
+            if self.pending is not None:
+                torch.cuda.current_stream(weight.device).wait_event(self.pending)
+                self.pending = None
+            if e[5] != self.pass_id or e[3] != weight._version:      # not packed in this pass / changed since
+                self._pack_one(w3, e[1], e[2])
+                e[3], e[5] = weight._version, self.pass_id
+            return e[2]
+        d = (K, cin, cout, int(c1), bool(transposed), bool(mirror), int(s0), int(sc))
+        lib = _lib.load()
+        n = lib.b2m_weight_pack_h_size(K, cout, 0, sc) if transposed else lib.b2m_weight_pack_h_size(K, c1, cin - c1, cout)
+        image = torch.empty(n, dtype=torch.float16, device=w3.device)
+        self._pack_one(w3, d, image)
+        self.entries[key] = [weakref.ref(weight), d, image, weight._version, weight.data_ptr(), self.pass_id]
+        self.dirty = True
+        return image
+
+    def _build_plan(self):
+        import ctypes as C
+        import numpy as np
+        for k in [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[4]]:
+            del self.entries[k]
+        self.dirty = False
+        keys = list(self.entries)
+        if not keys:
+            self.plan = None
+            return
+        lib = _lib.load()
+        es = [self.entries[k] for k in keys]
+        i64 = lambda v: np.ascontiguousarray(v, dtype=np.int64)
+        i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        cols = [i64([e[4] for e in es]), i64([e[2].data_ptr() for e in es])] + [i32([int(e[1][j]) for e in es]) for j in range(8)]
+        host = np.zeros(len(keys) * lib.b2m_weight_pack_h_plan_size(), np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        blocks = lib.b2m_weight_pack_h_plan(len(keys), *[p(c) for c in cols], p(host))
+        if blocks < 0:
+            raise _lib.B2MError('b2m_weight_pack_h_plan failed: ' + lib.b2m_last_error().decode())
+        self.plan = (torch.from_numpy(host).to(es[0][2].device), len(keys), int(blocks), keys)
+
+    def begin_pass(self):
+        self.pass_id += 1
+        self.pending = None
+        if not self.entries:
+            return
+        if self.dirty or any(e[0]() is None or e[0]().data_ptr() != e[4] for e in self.entries.values()):
+            self._build_plan()
+        if self.plan is None:
+            return
+        table, n, blocks, keys = self.plan
+        dev = table.device
+        if F_.pack_on_side_stream() and F_.wgrad_on_side_stream():
+            main, side = torch.cuda.current_stream(dev), F_._side_stream(dev)
+            side.wait_stream(main)           # the optimizer's update of the weights
+            with torch.cuda.stream(side):
+                _call('b2m_weight_pack_h_run', table.data_ptr(), n, blocks)
+                self.pending = torch.cuda.Event()
+                self.pending.record(side)
+        else:
+            _call('b2m_weight_pack_h_run', table.data_ptr(), n, blocks)
+        for k in keys:
+            e = self.entries[k]
+            e[3], e[5] = e[0]()._version, self.pass_id
+
+
+images = _HalfImages()
 
 
 def weight_pack_ht(weight, mirror: bool, s0: int, sc: int):
     """Half image of W'[k] = W[k or K-1-k][s0:s0+sc, :]^T -- the operand with which b2m_conv_fwd_h computes the gradient w.r.t.
     input channels [s0, s0 + sc) of a layer with weights W (K, cin, cout)."""
-    w3 = weight.detach()
-    w3 = w3 if w3.dim() == 3 else w3.unsqueeze(0)
-    K, cin, cout = w3.shape
-    key = (id(weight), bool(mirror), int(s0), int(sc))
-    e = _images_t.get(key)
-    if e is not None and e[0]() is weight and e[2] == weight._version and e[3] == weight.data_ptr() and e[4] == F_.training_epoch():
-        return e[1]
-    assert w3.is_contiguous()
-    n = _lib.load().b2m_weight_pack_h_size(K, cout, 0, sc)
-    image = e[1] if (e is not None and e[0]() is weight and e[1].numel() == n) else torch.empty(n, dtype=torch.float16, device=w3.device)
-    _call('b2m_weight_pack_h_t', w3.data_ptr(), K, cin, cout, 1 if mirror else 0, s0, sc, image.data_ptr())
-    if e is None:
-        for k in [k for k, v in _images_t.items() if v[0]() is None]:
-            del _images_t[k]
-    _images_t[key] = [weakref.ref(weight), image, weight._version, weight.data_ptr(), F_.training_epoch()]
-    return image
+    return images.get(weight, 0, True, mirror, s0, sc)
 
 
 def _conv_h(x1, x2, image, K, rb, n_out, cout):
@@ -106,7 +185,7 @@ class _ConvH(torch.autograd.Function):
         c1 = x1.shape[1]
         c2 = x2.shape[1] if x2 is not None else 0
         assert c1 + c2 == cin and rb_f.K == K and rb_f.n_out == n_out
-        y = _conv_h(x1, x2, F_.weight_pack_h(weight, c1, c2), K, rb_f, n_out, cout)
+        y = _conv_h(x1, x2, images.get(weight, c1), K, rb_f, n_out, cout)
         ctx.save_for_backward(x1, x2, weight)
         ctx.rb_f, ctx.rb_b, ctx.mirror = rb_f, rb_b, mirror
         return y

@@ -298,6 +298,16 @@ int b2m_conv_wgrad_h(const void* x, int64_t ldx, int32_t cin, int64_t n_in, cons
  * b2m_conv_fwd_h computes the gradient w.r.t. input channels [s0, s0+sc) (b2m_weight_pack_h_size(K, cout, 0, sc) halfs). */
 int b2m_weight_pack_h_t(const float* w, int32_t K, int32_t cin, int32_t cout, int32_t mirror, int32_t s0, int32_t sc, void* wp,
                         void* stream);
+/* Every half image of a training step in one launch (half_train.py: ~90 images per step).  b2m_weight_pack_h_plan fills plan_host
+ * (n descriptors of b2m_weight_pack_h_plan_size() bytes, host memory): image i is b2m_weight_pack_h(w, cout, K, c1, cin - c1, cout)
+ * when transposed[i] == 0 and b2m_weight_pack_h_t(w, K, cin, cout, mirror, s0, sc) otherwise, of the contiguous (K, cin, cout)
+ * weights at address w[i] into wp[i]; returns the number of workgroups b2m_weight_pack_h_run launches (< 0: error).  The caller
+ * copies the table to the device once and runs it whenever the weights changed. */
+int32_t b2m_weight_pack_h_plan_size(void);
+int64_t b2m_weight_pack_h_plan(int32_t n, const int64_t* w, const int64_t* wp, const int32_t* K, const int32_t* cin, const int32_t* cout,
+                               const int32_t* c1, const int32_t* transposed, const int32_t* mirror, const int32_t* s0, const int32_t* sc,
+                               void* plan_host);
+int b2m_weight_pack_h_run(const void* plan_dev, int32_t n, int64_t total_blocks, void* stream);
 /* b2m_bn_stats_h + the finalize of b2m_bn_stats_finalize in two launches (local statistics, count = n). */
 int b2m_bn_stats_finalize_h(const void* x, int64_t ldx, int64_t n, int32_t c, double* partial, const float* gamma, const float* beta,
                             float eps, float momentum, float* running_mean, float* running_var, float* mean, float* invstd,

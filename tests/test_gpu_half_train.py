@@ -289,3 +289,47 @@ def test_half_training_loss_curve_follows_fp32(monkeypatch):
     print('half', ['%.3f' % v for v in a[::3]], 'fp32', ['%.3f' % v for v in b[::3]], 'apart (max, mean, last five)', got, 'yardstick', yard)
     assert np.all(np.isfinite(a)) and a[-1] < 0.1 * a[0] and b[-1] < 0.1 * b[0]
     assert all(g <= 2.0 * y for g, y in zip(got, yard)), (got, yard)
+
+
+def test_half_images_of_a_step_are_packed_in_one_launch(monkeypatch):
+    """half_train._HalfImages: the first half training pass packs every image on first use (and registers it); from the second pass
+    on ONE b2m_weight_pack_h_run launch (on the side stream, beside the stem) repacks all of them from the weights the optimizer
+    has just changed -- a fused Adam bumps no version counter, so the repack is unconditional -- and every image holds exactly the
+    bits b2m_weight_pack_h / b2m_weight_pack_h_t make of the current weights."""
+    from box2mask_amd import synth, _lib, half_train as HT
+    from box2mask_amd.config import scannet_config
+    from box2mask_amd.model import Model
+    torch.manual_seed(5)
+    model = Model(scannet_config(half_training=True), *synth.scannet_tables())
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+    batch = synth.make_batch(4, seed0=11, target_voxels=3000, pts_per_m2=6000.0)
+    HT.images.__init__()
+    calls = []
+    _lib.set_hook(lambda name, a, meta=None: calls.append(name))
+    try:
+        for step in range(2):
+            del calls[:]
+            opt.zero_grad()
+            model.compute_loss(batch, 150)['optimization_loss'].backward()
+            opt.step()
+            packs = [c for c in calls if c.startswith('b2m_weight_pack_h')]
+            if step == 0:
+                first = len(packs)
+                assert first > 60 and 'b2m_weight_pack_h_run' not in packs, packs[:5]
+            else:
+                assert packs == ['b2m_weight_pack_h_run'], packs
+    finally:
+        _lib.set_hook(None)
+    assert len(HT.images.entries) == first
+    # a third pass opens: every image against the single-image entries on the weights of now
+    HT.images.begin_pass()
+    torch.cuda.synchronize()
+    for key, e in HT.images.entries.items():
+        w = e[0]()
+        w3 = w.detach() if w.dim() == 3 else w.detach().unsqueeze(0)
+        ref = torch.empty_like(e[2])
+        HT._HalfImages._pack_one(w3, e[1], ref)
+        torch.cuda.synchronize()
+        assert torch.equal(ref.view(torch.int16), e[2].view(torch.int16)), key[1:]
+    HT.images.__init__()
