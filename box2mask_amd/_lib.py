@@ -38,6 +38,7 @@ PROTOTYPES = {
     'b2m_conv_fwd': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P],
     'b2m_conv_fwd_affine': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, I64, P, I64, I32, P, P, P, I64, I32, P, P],
     'b2m_conv_fwd_h': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, I64, P, I64, I32, P, P, P, I64, I32, P],
+    'b2m_conv_fwd_h_stats': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, I64, P, I64, I32, P, P],
     'b2m_weight_pack_h': [P, I64, I32, I32, I32, I32, P, P],
     'b2m_conv_fwd_stats': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, I64, P, I64, I32, I32, P, P, P],
     'b2m_conv_wgrad_h': [P, I64, I32, I64, P, I64, I32, P, P, P, I64, I32, P, I64, I64, I32, F32, P],

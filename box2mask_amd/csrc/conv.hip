@@ -1355,10 +1355,31 @@ extern "C" int b2m_weight_pack_h_run(const void* plan_dev, int32_t n, int64_t to
 // Y(half) = [relu]( conv(X1 | X2)(half) * scale + shift [+ res(half)] ) through conv_fwd_flow_kernel<.., F16>: real rulebooks
 // only (a 1x1 layer comes with the identity rulebook of its map: b2m_rulebook of K = 1), input channels of both sources in
 // multiples of 16, output channels in multiples of 16, 16-byte aligned rows.  scale / shift may be NULL (plain convolution).
+static int conv_fwd_h_impl(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int64_t ldx2, int32_t c2, int64_t n_in,
+                           const void* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                           int64_t n_out, void* y, int64_t ldy, int32_t cout, const float* scale, const float* shift,
+                           const void* res, int64_t ld_res, int32_t relu, double* tile_stats, void* stream);
 extern "C" int b2m_conv_fwd_h(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int64_t ldx2, int32_t c2, int64_t n_in,
                               const void* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                               int64_t n_out, void* y, int64_t ldy, int32_t cout, const float* scale, const float* shift,
                               const void* res, int64_t ld_res, int32_t relu, void* stream) {
+    return conv_fwd_h_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, scale, shift, res, ld_res,
+                           relu, nullptr, stream);
+}
+// The plain half convolution that also leaves the per-tile column sums of its output AS STORED (each value rounded to binary16
+// first): tile_stats[tile][0 / 1][cout] = sum / sum of squares over the tile's 64 rows, fp64 -- what the training-mode BatchNorm
+// behind the layer would otherwise read the whole output for (b2m_bn_tilestats / b2m_bn_tilestats_finalize take them).
+extern "C" int b2m_conv_fwd_h_stats(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int64_t ldx2, int32_t c2, int64_t n_in,
+                                    const void* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                                    int64_t n_out, void* y, int64_t ldy, int32_t cout, double* tile_stats, void* stream) {
+    B2M_CHECK_ARG(tile_stats != nullptr, "tile_stats is NULL");
+    return conv_fwd_h_impl(x1, ldx1, c1, x2, ldx2, c2, n_in, wp, K, rb_in, rb_out, rb_cnt, n_out, y, ldy, cout, nullptr, nullptr, nullptr, 0,
+                           0, tile_stats, stream);
+}
+static int conv_fwd_h_impl(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int64_t ldx2, int32_t c2, int64_t n_in,
+                           const void* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                           int64_t n_out, void* y, int64_t ldy, int32_t cout, const float* scale, const float* shift,
+                           const void* res, int64_t ld_res, int32_t relu, double* tile_stats, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     B2M_CHECK_ARG(x1 && wp && y && rb_in && rb_out && rb_cnt && c1 > 0 && c2 >= 0 && cout > 0 && K >= 1 && K <= 128, "bad pointers/sizes (K<=128)");
     B2M_CHECK_ARG(c2 == 0 || x2 != nullptr, "x2 is NULL");
@@ -1376,7 +1397,7 @@ extern "C" int b2m_conv_fwd_h(const void* x1, int64_t ldx1, int32_t c1, const vo
     a.wp = (const float*)wp; a.K = K; a.bias = nullptr;
     a.rb_in = rb_in; a.rb_out = rb_out; a.rb_cnt = rb_cnt;
     a.n_out = n_out; a.ntiles = cdiv64(n_out, B2M_TILE);
-    a.y = (float*)y; a.ldy = ldy; a.cout = cout; a.accumulate = 0; a.stats = nullptr; a.vec_store = 1; a.fast32 = 1;
+    a.y = (float*)y; a.ldy = ldy; a.cout = cout; a.accumulate = 0; a.stats = tile_stats; a.vec_store = 1; a.fast32 = 1;
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = (const float*)res; a.ld_res = ld_res; a.ep_relu = relu;
     a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr; a.zeros = nullptr;
     const int TW = conv_tw(cout, K);

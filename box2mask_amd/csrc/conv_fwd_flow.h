@@ -31,7 +31,9 @@
 // Column sums of a finished output strip (64 rows x SW columns in LDS, row pitch SW + 4): lane c adds up column c over
 // the tile's valid rows and stores sum / sum of squares to stats[tile][0 / 1][col0 + c] -- what bn_stats_kernel would
 // read the whole of Y again for.
-template <int SW>
+// R16 (the F16 kernels in half-precision training): the sums are those of the values as STORED -- each fp32 accumulator rounded to
+// binary16 first -- so that they are the statistics of the tensor the BatchNorm behind the layer reads.
+template <int SW, bool R16 = false>
 __device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float* strip, int64_t tile, int64_t row0, int col0, int lane) {
     constexpr int PITCH = SW + 4;
     const int64_t rem = a.n_out - row0;
@@ -44,19 +46,21 @@ __device__ __forceinline__ void strip_column_sums(const ConvArgs& a, const float
         for (; r + 3 < rows; r += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const double v = (double)strip[(r + u) * PITCH + lane];
+                const float f = strip[(r + u) * PITCH + lane];
+                const double v = R16 ? (double)(float)(_Float16)f : (double)f;
                 s[u] += v; s2[u] = fma(v, v, s2[u]);
             }
         }
         for (; r < rows; ++r) {
-            const double v = (double)strip[r * PITCH + lane];
+            const float f = strip[r * PITCH + lane];
+            const double v = R16 ? (double)(float)(_Float16)f : (double)f;
             s[0] += v; s2[0] = fma(v, v, s2[0]);
         }
         double* o = a.stats + tile * 2 * a.cout + col0 + lane;
         o[0] = (s[0] + s[1]) + (s[2] + s[3]); o[a.cout] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
     }
 }
-#define tile_column_sums(a, strip, tile, row0, col0, lane) strip_column_sums<SW>(a, strip, tile, row0, col0, lane)
+#define tile_column_sums(a, strip, tile, row0, col0, lane) strip_column_sums<SW, (F16 != 0)>(a, strip, tile, row0, col0, lane)
 
 // Half output (F16 kernels): four consecutive columns of output row `grow` -- the inference epilogue in fp32 (scale / shift,
 // residual read as half, ReLU), one rounding to half, one 8-byte store.  ConvArgs::y / ep_res hold half data here.
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
             f32x4 v = *(const f32x4*)&smem[row * PITCH + c4];
 #pragma unroll
             for (int w = 1; w < WPB; ++w) v += *(const f32x4*)&smem[w * STRIP + row * PITCH + c4];
-            if (!F16 && a.stats) *(f32x4*)&smem[row * PITCH + c4] = v;  // keep the combined strip for the column sums below
+            if (a.stats) *(f32x4*)&smem[row * PITCH + c4] = v;  // keep the combined strip for the column sums below
             const int col = col0 + c4;
             if constexpr (F16) {
                 if (col + 3 < a.cout) store_half4(a, v, grow, col);
@@ -630,14 +634,14 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
                 }
             }
         }
-        if (!F16 && a.stats) {
+        if (a.stats) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             tile_column_sums(a, smem, tile, row0, col0, lane);
         }
         B2M_RES_END((int64_t)blockIdx.x * WPB, 0);
         return;
     }
-    if (!F16 && a.stats) tile_column_sums(a, Cs, tile, row0, col0, lane);
+    if (a.stats) tile_column_sums(a, Cs, tile, row0, col0, lane);
 #ifdef B2M_STAMPS
             if constexpr (WPB == 1 && !F16 && HL == 1 && DBG == 0) {
     B2M_STAMP(fs_stat);

@@ -21,6 +21,7 @@ Turned on by `SelectionNet.half_training = True` (or `cfg.half_training`); under
 / `functional._BatchNorm` (/root/reference/models/resnet.py:61-83, detection_net.py:37-135)."""
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -145,11 +146,26 @@ def weight_pack_ht(weight, mirror: bool, s0: int, sc: int):
     return images.get(weight, 0, True, mirror, s0, sc)
 
 
-def _conv_h(x1, x2, image, K, rb, n_out, cout):
+def conv_tile_stats() -> bool:
+    """B2M_CONV_STATS_H=0: the half BatchNorm reads the convolution's output for its statistics (b2m_bn_stats_h) instead of taking the
+    per-tile column sums the convolution kernel leaves behind (b2m_conv_fwd_h_stats)."""
+    return os.environ.get('B2M_CONV_STATS_H', '1') == '1' and F_.conv_tile_stats()
+
+
+def _conv_h(x1, x2, image, K, rb, n_out, cout, tile_stats=None):
+    """tile_stats: a list that receives (tensor [ntiles, 2, cout] fp64, ntiles) -- the per-tile column sums of the output as stored."""
     c1 = x1.shape[1]
     c2 = x2.shape[1] if x2 is not None else 0
     out = torch.empty((n_out, cout), dtype=torch.float16, device=x1.device)
     if n_out == 0:
+        return out
+    if tile_stats is not None:
+        ntiles = (n_out + 63) // 64
+        ts = torch.empty((ntiles, 2, cout), dtype=torch.float64, device=x1.device)
+        _call('b2m_conv_fwd_h_stats', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2, x1.shape[0],
+              image.data_ptr(), K, rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr(), n_out, out.data_ptr(), out.stride(0),
+              cout, ts.data_ptr(), meta={'half': True})
+        tile_stats.append((ts, ntiles))
         return out
     _call('b2m_conv_fwd_h', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2, x1.shape[0],
           image.data_ptr(), K, rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr(), n_out, out.data_ptr(), out.stride(0),
@@ -177,7 +193,7 @@ class _ConvH(torch.autograd.Function):
     """Y = sum_k [x1|x2][in_k] W[k], half in / out (functional._SparseConv without bias, pass-through and tile statistics)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, rb_f, rb_b, mirror, n_out):
+    def forward(ctx, x1, x2, weight, rb_f, rb_b, mirror, n_out, holder=None):
         x1 = _hc(x1)
         x2 = _hc(x2) if x2 is not None else None
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
@@ -185,7 +201,7 @@ class _ConvH(torch.autograd.Function):
         c1 = x1.shape[1]
         c2 = x2.shape[1] if x2 is not None else 0
         assert c1 + c2 == cin and rb_f.K == K and rb_f.n_out == n_out
-        y = _conv_h(x1, x2, images.get(weight, c1), K, rb_f, n_out, cout)
+        y = _conv_h(x1, x2, images.get(weight, c1), K, rb_f, n_out, cout, tile_stats=holder)
         ctx.save_for_backward(x1, x2, weight)
         ctx.rb_f, ctx.rb_b, ctx.mirror = rb_f, rb_b, mirror
         return y
@@ -226,11 +242,17 @@ class _ConvH(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(F_.join_side_streams)
             else:
                 run()
-        return dx1, dx2, dw, None, None, None, None
+        return dx1, dx2, dw, None, None, None, None, None
 
 
-def conv(x1, x2, weight, rb_f, rb_b, mirror, n_out):
-    return _ConvH.apply(x1, x2, weight, rb_f, rb_b, mirror, n_out)
+def conv(x1, x2, weight, rb_f, rb_b, mirror, n_out, collect_stats=False):
+    """collect_stats: the caller batch-normalises the result in training mode; the per-tile column sums then ride along on the
+    returned tensor (attribute `_b2m_tile_stats`, read by batch_norm), as functional.sparse_conv does for the fp32 layers."""
+    holder = [] if (collect_stats and conv_tile_stats()) else None
+    y = _ConvH.apply(x1, x2, weight, rb_f, rb_b, mirror, n_out, holder)
+    if holder:
+        y._b2m_tile_stats = holder[0]
+    return y
 
 
 _ws = {}
@@ -254,9 +276,11 @@ class _BatchNormH(torch.autograd.Function):
     rank's own sums (the gradient all-reduce averages them)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, sync=False):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, sync=False, tile_stats=None):
         x = _hc(x)
         n, c = x.shape
+        if tile_stats is not None and (tile_stats[0].shape[2] != c or tile_stats[1] != (n + 63) // 64):
+            tile_stats = None                  # not this tensor's sums
         dev = x.device
         group = F_._sync_group() if sync else None
         if n <= 1 and group is None:
@@ -266,11 +290,19 @@ class _BatchNormH(torch.autograd.Function):
         mean, invstd, scale, shift = f32(), f32(), f32(), f32()
         count_dev = None
         if group is None:
-            _call('b2m_bn_stats_finalize_h', x.data_ptr(), x.stride(0), n, c, _workspace(c, dev).data_ptr(), _ptr(gamma), _ptr(beta), eps,
-                  momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+            if tile_stats is not None:         # the producing convolution left the per-tile column sums: no pass over x
+                _call('b2m_bn_tilestats_finalize', tile_stats[0].data_ptr(), tile_stats[1], n, c, _workspace(c, dev).data_ptr(), None,
+                      _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
+                      scale.data_ptr(), shift.data_ptr())
+            else:
+                _call('b2m_bn_stats_finalize_h', x.data_ptr(), x.stride(0), n, c, _workspace(c, dev).data_ptr(), _ptr(gamma), _ptr(beta),
+                      eps, momentum, _ptr(running_mean), _ptr(running_var), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                      shift.data_ptr())
         else:
             stats = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-            if n > 0:
+            if n > 0 and tile_stats is not None:
+                _call('b2m_bn_tilestats', tile_stats[0].data_ptr(), tile_stats[1], c, _workspace(c, dev).data_ptr(), stats.data_ptr())
+            elif n > 0:
                 _call('b2m_bn_stats_h', x.data_ptr(), x.stride(0), n, c, _workspace(c, dev).data_ptr(), stats.data_ptr())
             else:
                 stats.zero_()
@@ -316,11 +348,12 @@ class _BatchNormH(torch.autograd.Function):
                   _ptr(ctx.count_dev) if group is not None else None, relu,
                   dx.data_ptr(), dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, None, None, None,
-                None, dres, None, None)
+                None, dres, None, None, None)
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=False, sync=False):
-    return _BatchNormH.apply(x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, sync)
+    tile_stats = getattr(x, '_b2m_tile_stats', None)       # left by conv(collect_stats=True)
+    return _BatchNormH.apply(x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, sync, tile_stats)
 
 
 class _ToHalf(torch.autograd.Function):

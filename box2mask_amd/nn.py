@@ -126,7 +126,7 @@ class MinkowskiConvolution(_ConvBase):
                 rb_f = rb_b = m.rulebook_same(l, self.kernel_size); mirror, level = True, None
             else:
                 rb_f, rb_b, mirror, level = m.rulebook_down(l), m.rulebook_up(l), False, l + 1
-            y = HT.conv(x1, x2, self.kernel, rb_f, rb_b, mirror, rb_f.n_out)
+            y = HT.conv(x1, x2, self.kernel, rb_f, rb_b, mirror, rb_f.n_out, collect_stats=self.training)
             return result((y, x1, x2) if passthrough else y, level)
         if self.kernel_volume == 1:
             assert self.stride == 1
@@ -164,7 +164,7 @@ class MinkowskiConvolutionTranspose(_ConvBase):
         if x1.dtype == torch.float16:          # half-precision training (half_train.py)
             from . import half_train as HT
             assert self.bias is None
-            return x.new(HT.conv(x1, x2, self.kernel, rb_f, rb_b, False, rb_f.n_out), level=l)
+            return x.new(HT.conv(x1, x2, self.kernel, rb_f, rb_b, False, rb_f.n_out, collect_stats=self.training), level=l)
         y = F_.sparse_conv(x1, x2, self.kernel, self.bias, rb_f, rb_b, False, rb_f.n_out,
                            collect_stats=self.training and self.bias is None)
         return x.new(y, level=l)

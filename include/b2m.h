@@ -235,6 +235,13 @@ int b2m_conv_fwd_h(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int
                    const void* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
                    int64_t n_out, void* y, int64_t ldy, int32_t cout, const float* scale, const float* shift,
                    const void* res, int64_t ld_res, int32_t relu, void* stream);
+/* ... the plain half convolution (no epilogue) that also leaves the per-tile column sums of its output as stored -- every value
+ * rounded to binary16 first --: tile_stats[ceil(n_out / 64)][2][cout] doubles (sum, sum of squares per tile of 64 rows), the input
+ * of b2m_bn_tilestats / b2m_bn_tilestats_finalize.  Half-precision training: the training-mode BatchNorm behind the layer
+ * (resnet.py:61-66) then needs no pass over the layer's output for its statistics. */
+int b2m_conv_fwd_h_stats(const void* x1, int64_t ldx1, int32_t c1, const void* x2, int64_t ldx2, int32_t c2, int64_t n_in,
+                         const void* wp, int32_t K, const int32_t* rb_in, const uint8_t* rb_out, const int32_t* rb_cnt,
+                         int64_t n_out, void* y, int64_t ldy, int32_t cout, double* tile_stats, void* stream);
 
 /* Transposed k2s2 convolution / data gradient of the strided one, in SCATTER form: Y[fine] (+)= W[koff(fine)] . X[parent(fine)]
  * walked over the map's DOWN rulebook (b2m_stride_tables -> b2m_rulebook: tiled over the n_coarse INPUT rows, rb_in = fine row,
