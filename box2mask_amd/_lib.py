@@ -46,8 +46,8 @@ PROTOTYPES = {
     'b2m_bn_stats_finalize_h': [P, I64, I64, I32, P, P, P, F32, F32, P, P, P, P, P, P, P],
     'b2m_bn_stats_h': [P, I64, I64, I32, P, P, P],
     'b2m_bn_apply_h': [P, I64, I64, I32, P, P, P, I64, I32, P, I64, P],
-    'b2m_bn_bwd_reduce_h': [P, I64, P, I64, P, I64, I64, I32, P, P, I32, P, P, P, P, F32, P],
-    'b2m_bn_bwd_apply_h': [P, I64, P, I64, P, I64, I64, I32, P, P, P, P, F64, P, I32, P, I64, P, I64, P],
+    'b2m_bn_bwd_reduce_h': [P, I64, P, I64, P, I64, I64, I32, P, P, I32, P, P, P, P, P, P, F32, P],
+    'b2m_bn_bwd_apply_h': [P, I64, P, I64, P, I64, I64, I32, P, P, P, P, F64, P, I32, P, P, P, I64, P, I64, P],
     'b2m_clock_probe': [P, I32, P],
     'b2m_xchg_allreduce': [P, I32, P, I32, I32, C.c_uint64, P, P, P],
     'b2m_conv_up': [P, I64, I32, P, I64, I32, I64, P, I32, P, P, P, P, P, I64, I32, I64, I32, P, P, P, I64, I32, P, P],

@@ -597,43 +597,58 @@ extern "C" int b2m_bn_apply_h(const void* x, int64_t ldx, int64_t n, int32_t c, 
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
-template <bool RELU>
+// HASY = false (ReLU without a fused residual): the mask is the sign of the forward's fmaf(x, scale, shift), recomputed from the x
+// the kernel reads anyway -- one tensor read less, and the forward need not keep y (as the fp32 kernels do since round 2; a value that
+// underflowed to zero in binary16, |v| < 3e-8, counts as positive here: the derivative of the unrounded function).
+template <bool RELU, bool HASY>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_h_kernel(const _Float16* __restrict__ dy, int64_t lddy,
                                                               const _Float16* __restrict__ y, int64_t ldy,
                                                               const _Float16* __restrict__ x, int64_t ldx, int64_t n, int c,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ mscale, const float* __restrict__ mshift,
                                                               double* __restrict__ partial) {
     const int c4 = c >> 2, mycg = (threadIdx.x % c4) * 4;
     const f32x4 m = *(const f32x4*)(mean + mycg), is = *(const f32x4*)(invstd + mycg);
-    constexpr int NIN = RELU ? 3 : 2;
+    f32x4 ms = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
+    if (RELU && !HASY) { ms = *(const f32x4*)(mscale + mycg); mb = *(const f32x4*)(mshift + mycg); }
+    constexpr int NIN = (RELU && HASY) ? 3 : 2;
     column_reduce_staged<NIN>(n, c, partial,
         [&](int64_t r, int cg, f32x4 (&in)[NIN]) {
             in[0] = ldh4(dy + r * lddy + cg * 4);
             in[1] = ldh4(x + r * ldx + cg * 4);
-            if constexpr (RELU) in[2] = ldh4(y + r * ldy + cg * 4);
+            if constexpr (RELU && HASY) in[2] = ldh4(y + r * ldy + cg * 4);
         },
         [&](const f32x4 (&in)[NIN], f32x4& a, f32x4& b) {
             f32x4 g = in[0];
             if constexpr (RELU) {
+                f32x4 yy;
+                if constexpr (HASY) yy = in[NIN - 1];
+                else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) g[u] = in[2][u] > 0.f ? g[u] : 0.f;
+                    for (int u = 0; u < 4; ++u) yy[u] = __builtin_fmaf(in[1][u], ms[u], mb[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
             }
             a = g; b = g * ((in[1] - m) * is);
         });
 }
 extern "C" int b2m_bn_bwd_reduce_h(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx,
-                                   int64_t n, int32_t c, const float* mean, const float* invstd, int32_t relu, double* partial,
+                                   int64_t n, int32_t c, const float* mean, const float* invstd, int32_t relu,
+                                   const float* mask_scale, const float* mask_shift, double* partial,
                                    double* sums, float* dbeta_f32, float* dgamma_f32, float param_grad_scale, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(dy && x && mean && invstd && partial && sums && (!relu || y), "NULL argument (relu needs y)");
-    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && (!relu || ldy % 4 == 0) && n >= 1,
+    B2M_CHECK_ARG(dy && x && mean && invstd && partial && sums && (!relu || y || (mask_scale && mask_shift)),
+                  "NULL argument (relu needs y, or mask_scale and mask_shift)");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && (!relu || !y || ldy % 4 == 0) && n >= 1,
                   "c and leading dimensions must be multiples of 4");
     B2M_CHECK_ARG(((uintptr_t)dy % 8) == 0 && ((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0, "8-byte aligned rows");
     const int nblk = reduce_blocks(n);
     const int c4 = c / 4, nslots = 256 / c4;
     const size_t lds = (size_t)nslots * c4 * 8 * sizeof(float);
-    if (relu) bn_bwd_reduce_h_kernel<true><<<nblk, 256, lds, st>>>((const _Float16*)dy, lddy, (const _Float16*)y, ldy, (const _Float16*)x, ldx, n, c, mean, invstd, partial);
-    else bn_bwd_reduce_h_kernel<false><<<nblk, 256, lds, st>>>((const _Float16*)dy, lddy, nullptr, 0, (const _Float16*)x, ldx, n, c, mean, invstd, partial);
+    if (relu && y) bn_bwd_reduce_h_kernel<true, true><<<nblk, 256, lds, st>>>((const _Float16*)dy, lddy, (const _Float16*)y, ldy, (const _Float16*)x, ldx, n, c, mean, invstd, nullptr, nullptr, partial);
+    else if (relu) bn_bwd_reduce_h_kernel<true, false><<<nblk, 256, lds, st>>>((const _Float16*)dy, lddy, nullptr, 0, (const _Float16*)x, ldx, n, c, mean, invstd, mask_scale, mask_shift, partial);
+    else bn_bwd_reduce_h_kernel<false, false><<<nblk, 256, lds, st>>>((const _Float16*)dy, lddy, nullptr, 0, (const _Float16*)x, ldx, n, c, mean, invstd, nullptr, nullptr, partial);
     reduce_final_kernel<<<2 * c, 64, 0, st>>>(partial, nblk, 2 * c, sums, dbeta_f32, dgamma_f32, param_grad_scale);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
@@ -644,6 +659,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const _Float16* __r
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const double* __restrict__ sums,
                                                              double count_host, const double* __restrict__ count_dev, int relu,
+                                                             const float* __restrict__ mscale, const float* __restrict__ mshift,
                                                              _Float16* __restrict__ dx, int64_t lddx,
                                                              _Float16* __restrict__ dres, int64_t lddres) {
     const int c4 = c >> 2;
@@ -653,6 +669,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const _Float16* __r
     if (rs >= nslots) return;
     const f32x4 m = *(const f32x4*)(mean + cg * 4), is = *(const f32x4*)(invstd + cg * 4);
     f32x4 sg, sgx, ga;
+    f32x4 msc = {0.f, 0.f, 0.f, 0.f}, msh = {0.f, 0.f, 0.f, 0.f};
+    if (relu && !y) { msc = *(const f32x4*)(mscale + cg * 4); msh = *(const f32x4*)(mshift + cg * 4); }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         sg[u] = (float)sums[cg * 4 + u] * inv_n; sgx[u] = (float)sums[c + cg * 4 + u] * inv_n;
@@ -662,7 +680,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const _Float16* __r
         f32x4 g = ldh4(dy + r * lddy + cg * 4);
         const f32x4 xx = ldh4(x + r * ldx + cg * 4);
         if (relu) {
-            const f32x4 yy = ldh4(y + r * ldy + cg * 4);
+            f32x4 yy;
+            if (y) yy = ldh4(y + r * ldy + cg * 4);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yy[u] = __builtin_fmaf(xx[u], msc[u], msh[u]);
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) g[u] = yy[u] > 0.f ? g[u] : 0.f;
         }
@@ -678,18 +701,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h_kernel(const _Float16* __r
 }
 extern "C" int b2m_bn_bwd_apply_h(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx, int64_t n,
                                   int32_t c, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                                  double count, const double* count_dev, int32_t relu, void* dx, int64_t lddx, void* dres,
-                                  int64_t lddres, void* stream) {
+                                  double count, const double* count_dev, int32_t relu, const float* mask_scale,
+                                  const float* mask_shift, void* dx, int64_t lddx, void* dres, int64_t lddres, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    B2M_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y), "NULL argument (relu needs y)");
-    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || ldy % 4 == 0) &&
+    B2M_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y || (mask_scale && mask_shift)),
+                  "NULL argument (relu needs y, or mask_scale and mask_shift)");
+    B2M_CHECK_ARG(c > 0 && c % 4 == 0 && c <= 1024 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!relu || !y || ldy % 4 == 0) &&
                       (!dres || lddres % 4 == 0) && (count_dev || count >= 1), "c and leading dimensions must be multiples of 4");
     B2M_CHECK_ARG(((uintptr_t)dy % 8) == 0 && ((uintptr_t)x % 8) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)dx % 8) == 0 &&
                       ((uintptr_t)dres % 8) == 0, "8-byte aligned rows");
     if (n == 0) return B2M_OK;
     bn_bwd_apply_h_kernel<<<row_grid(n, c / 4), 256, 0, st>>>((const _Float16*)dy, lddy, (const _Float16*)y, ldy, (const _Float16*)x, ldx,
                                                               n, c, mean, invstd, gamma, sums, count, count_dev, relu,
-                                                              (_Float16*)dx, lddx, (_Float16*)dres, lddres);
+                                                              mask_scale, mask_shift, (_Float16*)dx, lddx, (_Float16*)dres, lddres);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }

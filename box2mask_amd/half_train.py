@@ -315,13 +315,17 @@ class _BatchNormH(torch.autograd.Function):
         if n > 0:
             _call('b2m_bn_apply_h', x.data_ptr(), x.stride(0), n, c, scale.data_ptr(), shift.data_ptr(), _ptr(residual),
                   residual.stride(0) if residual is not None else 0, 1 if relu else 0, y.data_ptr(), y.stride(0))
-        ctx.save_for_backward(x, y if relu else None, gamma, beta, mean, invstd)
+        # without a fused residual the ReLU mask is the sign of fmaf(x, scale, shift): the backward recomputes it from x (which it
+        # reads anyway) instead of reading y, and y is not kept (functional._BatchNorm does the same)
+        ctx.mask_from_x = bool(relu) and residual is None
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, beta, mean, invstd,
+                              scale if ctx.mask_from_x else None, shift if ctx.mask_from_x else None)
         ctx.relu, ctx.has_res, ctx.sync, ctx.count_dev = bool(relu), residual is not None, bool(sync), count_dev
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, y, gamma, beta, mean, invstd, mscale, mshift = ctx.saved_tensors
         dy = _hc(dy)
         n, c = x.shape
         dev = x.device
@@ -333,8 +337,8 @@ class _BatchNormH(torch.autograd.Function):
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         if n > 0:
             _call('b2m_bn_bwd_reduce_h', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
-                  x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _workspace(c, dev).data_ptr(), sums.data_ptr(),
-                  dbeta.data_ptr(), dgamma.data_ptr(), 1.0 / loss_scale[0])       # (the sums are of the SCALED gradient)
+                  x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), relu, _ptr(mscale), _ptr(mshift), _workspace(c, dev).data_ptr(),
+                  sums.data_ptr(), dbeta.data_ptr(), dgamma.data_ptr(), 1.0 / loss_scale[0])       # (the sums are of the SCALED gradient)
         else:
             sums.zero_(); dbeta.zero_(); dgamma.zero_()
         group = F_._sync_group() if ctx.sync else None
@@ -345,7 +349,7 @@ class _BatchNormH(torch.autograd.Function):
         if n > 0:
             _call('b2m_bn_bwd_apply_h', dy.data_ptr(), dy.stride(0), _ptr(y), y.stride(0) if y is not None else 0, x.data_ptr(),
                   x.stride(0), n, c, mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), sums.data_ptr(), float(n),
-                  _ptr(ctx.count_dev) if group is not None else None, relu,
+                  _ptr(ctx.count_dev) if group is not None else None, relu, _ptr(mscale), _ptr(mshift),
                   dx.data_ptr(), dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, None, None, None,
                 None, dres, None, None, None)

@@ -322,13 +322,16 @@ int b2m_bn_stats_finalize_h(const void* x, int64_t ldx, int64_t n, int32_t c, do
 int b2m_bn_stats_h(const void* x, int64_t ldx, int64_t n, int32_t c, double* partial, double* stats, void* stream);
 int b2m_bn_apply_h(const void* x, int64_t ldx, int64_t n, int32_t c, const float* scale, const float* shift,
                    const void* residual, int64_t ldr, int32_t relu, void* y, int64_t ldy, void* stream);
+/* (relu != 0 with y == NULL: the mask is the sign of fmaf(x, mask_scale, mask_shift) -- the forward's scale / shift of a layer WITHOUT
+ * a fused residual -- recomputed from the x that is read anyway; the forward then need not keep y.  As b2m_bn_bwd_reduce / _apply.) */
 int b2m_bn_bwd_reduce_h(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx, int64_t n,
-                        int32_t c, const float* mean, const float* invstd, int32_t relu, double* partial, double* sums,
+                        int32_t c, const float* mean, const float* invstd, int32_t relu, const float* mask_scale,
+                        const float* mask_shift, double* partial, double* sums,
                         float* dbeta_f32, float* dgamma_f32, float param_grad_scale, void* stream);
 int b2m_bn_bwd_apply_h(const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* x, int64_t ldx, int64_t n,
                        int32_t c, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                       double count, const double* count_dev, int32_t relu, void* dx, int64_t lddx, void* dres,
-                       int64_t lddres, void* stream);
+                       double count, const double* count_dev, int32_t relu, const float* mask_scale, const float* mask_shift,
+                       void* dx, int64_t lddx, void* dres, int64_t lddres, void* stream);
 
 /* ---------------------------------------------------------------- SyncBN statistics exchange inside one node (opt-in)
  * Device-side all-reduce (SUM) of n <= b2m_xchg_max_doubles() doubles between <= b2m_xchg_max_ranks() ranks whose MAILBOXES
