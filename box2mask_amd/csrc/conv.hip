@@ -41,6 +41,8 @@ struct ConvArgs {
     // -- the eval-mode BatchNorm (+ residual) (+ ReLU) that follows every trunk convolution, in exactly b2m_bn_apply's
     // arithmetic, without its launch and without the round trip of Y through HBM.  16-byte column groups only.
     const float* ep_scale; const float* ep_shift; const float* ep_res; int64_t ld_res; int ep_relu;
+    int img_wide;    // F16 kernels with 32-column strips reading an image packed for 64-column strips: strip s is the half s & 1 of
+                     // the image's strip s >> 1 (the strip width of the IMAGE follows the channel count, that of the LAUNCH the map's size)
 };
 
 // loads of out-of-range operands are redirected here (pointer select, no select on the loaded value)
@@ -1237,8 +1239,17 @@ static inline int conv_h_ck(int c1, int c2) {
     if (c1 % 32 == 0 && c2 % 32 == 0) { const int nc = (c1 + c2) / 32; if (nc % 2 == 0 || nc % 3 == 0) return 32; }
     return 16;
 }
+// strip width of the half IMAGES in 16-column tiles: 64-column strips where the output channels come in 64s (round 6: every strip
+// gathers the layer's input rows again -- a 128-channel layer in 32-column strips gathered them four times: level 1 128->128 180 ->
+// 259 TFLOP/s, level 2 156 -> 211, level 3 256->256 153 -> 205, level 1 64->64 142 -> 160).  The 64-column kernel holds two waves per
+// SIMD, not three or four, and halves the number of work items: on maps of a few dozen tiles it loses (level 4 256->256 111 -> 93),
+// so b2m_conv_fwd_h launches the 32-column kernel there -- on the same image (ConvArgs::img_wide).  B2M_CONV_TW4_H=0: as fp32.
+static inline int conv_tw_h(int cout, int K) {
+    if (K > 1 && cout % 64 == 0 && env_flag("B2M_CONV_TW4_H", 1)) return 4;
+    return conv_tw(cout, K);
+}
 extern "C" int64_t b2m_weight_pack_h_size(int32_t K, int32_t c1, int32_t c2, int32_t cout) {      // in halfs
-    const int TW = conv_tw(cout, K);
+    const int TW = conv_tw_h(cout, K);
     return (int64_t)K * ((cout + 16 * TW - 1) / (16 * TW)) * ((c1 + c2) / conv_h_ck(c1, c2)) * (64 * TW * (conv_h_ck(c1, c2) / 4));
 }
 // (source element of logical weight (k, ci, co): w[kk * sk + ci * sci + co * sco], kk = mirror ? K - 1 - k : k -- the plain image
@@ -1265,7 +1276,7 @@ extern "C" int b2m_weight_pack_h(const float* w, int64_t ldw, int32_t K, int32_t
     int64_t grid = (total + 255) / 256;
     if (grid > 65536) grid = 65536;
     weight_pack_h_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(w, (int64_t)(c1 + c2) * ldw, ldw, 1, 0, K, c1 + c2, cout,
-                                                                         conv_h_ck(c1, c2), conv_tw(cout, K), (_Float16*)wp, total);
+                                                                         conv_h_ck(c1, c2), conv_tw_h(cout, K), (_Float16*)wp, total);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -1280,7 +1291,7 @@ extern "C" int b2m_weight_pack_h_t(const float* w, int32_t K, int32_t cin, int32
     int64_t grid = (total + 255) / 256;
     if (grid > 65536) grid = 65536;
     weight_pack_h_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(w + (int64_t)s0 * cout, (int64_t)cin * cout, 1, cout, mirror ? 1 : 0,
-                                                                         K, cout, sc, conv_h_ck(cout, 0), conv_tw(sc, K), (_Float16*)wp, total);
+                                                                         K, cout, sc, conv_h_ck(cout, 0), conv_tw_h(sc, K), (_Float16*)wp, total);
     B2M_LAUNCH_CHECK();
     return B2M_OK;
 }
@@ -1307,12 +1318,12 @@ extern "C" int64_t b2m_weight_pack_h_plan(int32_t n, const int64_t* w, const int
             const int c2 = cin[i] - c1[i];
             B2M_CHECK_ARG(c1[i] > 0 && c2 >= 0 && c1[i] % 16 == 0 && c2 % 16 == 0, "input channels of both sources must be multiples of 16");
             e.w = (const float*)(uintptr_t)w[i]; e.sci = cout[i]; e.sco = 1; e.mirror = 0;
-            e.cin = cin[i]; e.cout = cout[i]; e.CK = conv_h_ck(c1[i], c2); e.TW = conv_tw(cout[i], K[i]);
+            e.cin = cin[i]; e.cout = cout[i]; e.CK = conv_h_ck(c1[i], c2); e.TW = conv_tw_h(cout[i], K[i]);
             e.total = b2m_weight_pack_h_size(K[i], c1[i], c2, cout[i]);
         } else {                       // b2m_weight_pack_h_t(w, K, cin, cout, mirror, s0, sc)
             B2M_CHECK_ARG(s0[i] >= 0 && sc[i] > 0 && s0[i] + sc[i] <= cin[i] && cout[i] % 16 == 0, "bad channel slice");
             e.w = (const float*)(uintptr_t)w[i] + (int64_t)s0[i] * cout[i]; e.sci = 1; e.sco = cout[i]; e.mirror = mirror[i] ? 1 : 0;
-            e.cin = cout[i]; e.cout = sc[i]; e.CK = conv_h_ck(cout[i], 0); e.TW = conv_tw(sc[i], K[i]);
+            e.cin = cout[i]; e.cout = sc[i]; e.CK = conv_h_ck(cout[i], 0); e.TW = conv_tw_h(sc[i], K[i]);
             e.total = b2m_weight_pack_h_size(K[i], cout[i], 0, sc[i]);
         }
         e.first_block = blocks;
@@ -1400,7 +1411,11 @@ static int conv_fwd_h_impl(const void* x1, int64_t ldx1, int32_t c1, const void*
     a.y = (float*)y; a.ldy = ldy; a.cout = cout; a.accumulate = 0; a.stats = tile_stats; a.vec_store = 1; a.fast32 = 1;
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = (const float*)res; a.ld_res = ld_res; a.ep_relu = relu;
     a.xcd_start = nullptr; a.wg_per_tile = 0; a.tile_order = nullptr; a.zeros = nullptr;
-    const int TW = conv_tw(cout, K);
+    // the image is packed for 64-column strips wherever the output channels come in 64s; a map of fewer than 256 tiles runs its
+    // 32-column kernel on that image (two waves per SIMD and half the work items cost more there than the second gather)
+    const int TW_img = conv_tw_h(cout, K);
+    const int TW = (TW_img == 4 && a.ntiles < env_flag("B2M_CONV_TW4_H_MIN_TILES", 256)) ? 2 : TW_img;
+    a.img_wide = (TW_img == 4 && TW == 2) ? 1 : 0;
     a.nstrips = (cout + 16 * TW - 1) / (16 * TW);
     const int CK = conv_h_ck(c1, c2), nc = (c1 + c2) / CK;
     int depth = nc % 2 == 0 ? 2 : 3;
@@ -1423,14 +1438,14 @@ static int conv_fwd_h_impl(const void* x1, int64_t ldx1, int32_t c1, const void*
     }
 #define B2M_FLOW_H(D_, TW_, WPB_, F_) conv_fwd_flow_kernel<D_, TW_, 0, WPB_, 1, F_><<<fo.grid, 64 * WPB_, 0, st>>>(a)
     if (CK == 16) {
-        if (wpb == 4) { if (TW == 3) B2M_FLOW_H(2, 3, 4, 2); else B2M_FLOW_H(2, 2, 4, 2); }
-        else { if (TW == 3) B2M_FLOW_H(2, 3, 1, 2); else B2M_FLOW_H(2, 2, 1, 2); }
+        if (wpb == 4) { if (TW == 4) B2M_FLOW_H(2, 4, 4, 2); else if (TW == 3) B2M_FLOW_H(2, 3, 4, 2); else B2M_FLOW_H(2, 2, 4, 2); }
+        else { if (TW == 4) B2M_FLOW_H(2, 4, 1, 2); else if (TW == 3) B2M_FLOW_H(2, 3, 1, 2); else B2M_FLOW_H(2, 2, 1, 2); }
     } else if (depth == 2) {
-        if (wpb == 4) { if (TW == 3) B2M_FLOW_H(2, 3, 4, 1); else B2M_FLOW_H(2, 2, 4, 1); }
-        else { if (TW == 3) B2M_FLOW_H(2, 3, 1, 1); else B2M_FLOW_H(2, 2, 1, 1); }
+        if (wpb == 4) { if (TW == 4) B2M_FLOW_H(2, 4, 4, 1); else if (TW == 3) B2M_FLOW_H(2, 3, 4, 1); else B2M_FLOW_H(2, 2, 4, 1); }
+        else { if (TW == 4) B2M_FLOW_H(2, 4, 1, 1); else if (TW == 3) B2M_FLOW_H(2, 3, 1, 1); else B2M_FLOW_H(2, 2, 1, 1); }
     } else {
-        if (wpb == 4) { if (TW == 3) B2M_FLOW_H(3, 3, 4, 1); else B2M_FLOW_H(3, 2, 4, 1); }
-        else { if (TW == 3) B2M_FLOW_H(3, 3, 1, 1); else B2M_FLOW_H(3, 2, 1, 1); }
+        if (wpb == 4) { if (TW == 4) B2M_FLOW_H(3, 4, 4, 1); else if (TW == 3) B2M_FLOW_H(3, 3, 4, 1); else B2M_FLOW_H(3, 2, 4, 1); }
+        else { if (TW == 4) B2M_FLOW_H(3, 4, 1, 1); else if (TW == 3) B2M_FLOW_H(3, 3, 1, 1); else B2M_FLOW_H(3, 2, 1, 1); }
     }
 #undef B2M_FLOW_H
     B2M_LAUNCH_CHECK();

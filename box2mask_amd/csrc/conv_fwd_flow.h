@@ -118,8 +118,9 @@ __device__ __forceinline__ void store_half4(const ConvArgs& a, f32x4 v, int64_t 
 // LDS strip, no flush, no write-out; accumulate = a plain read-modify-write of the gradient already there: the row has one
 // writer).
 template <int D, int TW, int DBG = 0, int WPB = 1, int HL = 0, int F16 = 0, int UP = 0>
-__global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WPB, TW == 4 ? 2 : (TW == 2 && D == 2 && !UP) ? 4 : 3) void conv_fwd_flow_kernel(ConvArgs a) {
     static_assert(!F16 || HL, "the half variant exists with hand-issued loads only");
+    static_assert(TW <= 3 || F16, "64-column strips: the half variants only");
     static_assert(!UP || (HL && WPB == 1 && !F16), "the scatter form: fp32, un-split, hand-issued loads");
     constexpr int KS = 4;                     // k-steps per 16-channel chunk == floats per lane per gathered row
     constexpr int ESZ = F16 ? 2 : 4;          // bytes per activation element
@@ -294,8 +295,11 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
         const uint32_t wlo = (uint32_t)lane * (F16 == 2 ? 8u : 16u);         // packed block layout [u][lane][4 floats]: pack_pos()
         const uint32_t q16 = (uint32_t)q * (F16 == 2 ? 8u : 16u);       // the lane's bytes inside the row piece
         const uint32_t ld1 = (uint32_t)a.ldx1 * (uint32_t)ESZ, ld2 = (uint32_t)a.ldx2 * (uint32_t)ESZ;     // row pitch in bytes
-        const uint32_t wstrip = (uint32_t)strip * (uint32_t)NC;
-        const uint32_t wkstride = (uint32_t)a.nstrips * (uint32_t)NC;
+        // (F16, 32-column strips on an image packed for 64-column strips: the image's strip s >> 1, its pieces 2 (s & 1), 2 (s & 1) + 1)
+        const bool wide = F16 && TW == 2 && a.img_wide;
+        const uint32_t wstrip = (uint32_t)(wide ? strip >> 1 : strip) * (uint32_t)NC;
+        const uint32_t wkstride = (uint32_t)(wide ? a.nstrips >> 1 : a.nstrips) * (uint32_t)NC;
+        const uint32_t wsub = wide ? (uint32_t)(strip & 1) * (F16 == 2 ? 1024u : 2048u) : 0u;
         // operand registers: buffer j holds row group g's four k-steps (one 16-byte gather) and the TW weight pieces; MFMA operand
         // (k-step s, column tile t) of the weights is float TW * s + t of the buffer's TW pieces.  With hand-issued loads every
         // load statement takes its destination as an IN/OUT operand: the previous content stays alive, in that very register, up
@@ -336,17 +340,19 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
         };
         auto weights = [&](int j, int e, int c) {
             const uint32_t blk = (uint32_t)(e & 127) * wkstride + wstrip + (uint32_t)c;     // wave-uniform
-            const char* wsrc = (const char*)a.wp + (size_t)blk * (size_t)(F16 == 2 ? LW * 2 : LW * 4);
+            const char* wsrc = (const char*)a.wp + (size_t)blk * ((size_t)(F16 == 2 ? LW * 2 : LW * 4) << (wide ? 1 : 0)) + wsub;
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
                 if constexpr (F16 == 2) {
                     if (u == 0) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
                     else if (u == 1) asm volatile("global_load_dwordx2 %0, %1, %2 offset:512" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
-                    else asm volatile("global_load_dwordx2 %0, %1, %2 offset:1024" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                    else if (u == 2) asm volatile("global_load_dwordx2 %0, %1, %2 offset:1024" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                    else asm volatile("global_load_dwordx2 %0, %1, %2 offset:1536" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
                 } else if constexpr (HL) {
                     if (u == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
                     else if (u == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
-                    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                    else if (u == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
+                    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "+v"(bw[j][u]) : "v"(wlo), "s"(wsrc) : "memory");
                 } else {
                     bw[j][u] = *(const opv*)(wsrc + (wlo + 1024u * u));
                 }
@@ -392,7 +398,12 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
         // software-visible hazard, a non-MFMA read of a fresh result, is covered by the s_nop in front of the flush.
         auto mfma_group = [&](int j, int g) {
             if constexpr (F16 == 2) {
-                if constexpr (TW == 3) {
+                if constexpr (TW == 4) {
+                    asm volatile("v_mfma_f32_16x16x16_f16 %0, %5, %4, %0\n\tv_mfma_f32_16x16x16_f16 %1, %6, %4, %1\n\t"
+                                 "v_mfma_f32_16x16x16_f16 %2, %7, %4, %2\n\tv_mfma_f32_16x16x16_f16 %3, %8, %4, %3"
+                                 : "+v"(acc[g][0]), "+v"(acc[g][1]), "+v"(acc[g][2]), "+v"(acc[g][3])
+                                 : "v"(av[j][g]), "v"(bw[j][0]), "v"(bw[j][1]), "v"(bw[j][2]), "v"(bw[j][3]) : "memory");
+                } else if constexpr (TW == 3) {
                     asm volatile("v_mfma_f32_16x16x16_f16 %0, %4, %3, %0\n\tv_mfma_f32_16x16x16_f16 %1, %5, %3, %1\n\t"
                                  "v_mfma_f32_16x16x16_f16 %2, %6, %3, %2"
                                  : "+v"(acc[g][0]), "+v"(acc[g][1]), "+v"(acc[g][2])
@@ -405,7 +416,12 @@ __global__ __launch_bounds__(64 * WPB, (TW == 2 && D == 2 && !UP) ? 4 : 3) void 
             } else if constexpr (F16) {
                 // weights = A (lane (i, q): input channels 8q .. 8q + 7 of output channel 16t + i), gathered rows = B (lane (i, q):
                 // the same eight channels of pair i): D[channel][pair] as in the fp32 form
-                if constexpr (TW == 3) {
+                if constexpr (TW == 4) {          // (round 6: 64-column strips for the layers whose output channels come in 64s)
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %5, %4, %0\n\tv_mfma_f32_16x16x32_f16 %1, %6, %4, %1\n\t"
+                                 "v_mfma_f32_16x16x32_f16 %2, %7, %4, %2\n\tv_mfma_f32_16x16x32_f16 %3, %8, %4, %3"
+                                 : "+v"(acc[g][0]), "+v"(acc[g][1]), "+v"(acc[g][2]), "+v"(acc[g][3])
+                                 : "v"(av[j][g]), "v"(bw[j][0]), "v"(bw[j][1]), "v"(bw[j][2]), "v"(bw[j][3]) : "memory");
+                } else if constexpr (TW == 3) {
                     asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %3, %0\n\tv_mfma_f32_16x16x32_f16 %1, %5, %3, %1\n\t"
                                  "v_mfma_f32_16x16x32_f16 %2, %6, %3, %2"
                                  : "+v"(acc[g][0]), "+v"(acc[g][1]), "+v"(acc[g][2])

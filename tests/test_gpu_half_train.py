@@ -370,3 +370,53 @@ def test_half_batchnorm_statistics_from_the_convolution_tiles(maps, monkeypatch,
     d = (out['1'][1].float() - out['0'][1].float()).abs()
     assert float(d.max()) <= 2e-3 * float(out['0'][1].float().abs().max())          # a half ulp apart at most
     assert float((d > 0).float().mean()) < 1e-3
+
+
+STRIP_REGIMES = {
+    # 64-column strips (images and kernels) on every map, un-split and in four slices per item
+    'wide_unsplit': {'B2M_CONV_TW4_H_MIN_TILES': '0', 'B2M_CONV_TARGET': '0'},
+    'wide_sliced': {'B2M_CONV_TW4_H_MIN_TILES': '0', 'B2M_CONV_TARGET': '1000000'},
+    # the 32-column kernels on the 64-column image (what a map of fewer than 256 tiles gets)
+    'narrow_on_wide_image_unsplit': {'B2M_CONV_TW4_H_MIN_TILES': '1000000', 'B2M_CONV_TARGET': '0'},
+    'narrow_on_wide_image_sliced': {'B2M_CONV_TW4_H_MIN_TILES': '1000000', 'B2M_CONV_TARGET': '1000000'},
+    # 32-column images (rounds 4 - 5)
+    'narrow_image': {'B2M_CONV_TW4_H': '0'},
+}
+
+
+@pytest.mark.parametrize('regime', sorted(STRIP_REGIMES))
+@pytest.mark.parametrize('level,cin,cout', [(0, 64, 64), (0, 96, 128), (1, 128, 128), (1, 32, 64), (1, 128, 256), (1, 256, 128)])
+def test_half_convolution_strip_widths(maps, monkeypatch, level, cin, cout, regime):
+    """The F16 convolution in 64-column strips (round 6: output channels in multiples of 64; conv_fwd_flow_kernel<.., TW = 4, .., F16>,
+    one gather of the input rows per 64 output channels instead of per 32) and its 32-column kernel reading the 64-column image on small
+    maps: forward and data gradient of a 3x3x3 layer against the fp32 kernels on the same half-rounded numbers, every combination of
+    image width, kernel width and slicing (32 input channels: the 16-channel-chunk variants, F16 = 2)."""
+    from box2mask_amd import functional as F_, half_train as HT, _lib
+    monkeypatch.setenv('B2M_WGRAD_STREAM', '0')
+    for k_, v_ in STRIP_REGIMES[regime].items():
+        monkeypatch.setenv(k_, v_)
+    _lib.reload_env()
+    HT.images.__init__()
+    monkeypatch.setattr(HT, 'loss_scale', [1.0])
+    m = maps
+    rb = m.rulebook_same(level, 3)
+    n = m.n(level)
+    torch.manual_seed(level * 1000 + cin + cout)
+    x = torch.randn(n, cin, device='cuda').half()
+    w = (torch.randn(27, cin, cout, device='cuda') * (2.0 / (cin * 10) ** 0.5)).half().float().contiguous()
+    gy = torch.randn(n, cout, device='cuda').half()
+    xh = x.clone().requires_grad_(True); wh = w.clone().requires_grad_(True)
+    yh = HT.conv(xh, None, wh, rb, rb, True, n)
+    yh.backward(gy)
+    xf = x.float().requires_grad_(True); wf = w.clone().requires_grad_(True)
+    yf = F_.sparse_conv(xf, None, wf, None, rb, rb, True, n)
+    yf.backward(gy.float())
+    torch.cuda.synchronize()
+    try:
+        _half_close(yh.detach(), yf.detach(), 'forward')
+        _half_close(xh.grad, xf.grad, 'data gradient')
+        assert _rel(wh.grad, wf.grad) < 1e-4
+    finally:
+        monkeypatch.undo()
+        _lib.reload_env()
+        HT.images.__init__()

@@ -39,6 +39,11 @@ PINNED = {
     '_Z20conv_fwd_flow_kernelILi3ELi2ELi0ELi4ELi1ELi1ELi0EEv8ConvArgs': (168, 3, True),
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi1ELi2ELi0EEv8ConvArgs': (128, 4, True),
     '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi4ELi1ELi2ELi0EEv8ConvArgs': (168, 3, True),
+    # ... in 64-column strips (round 6: output channels in multiples of 64 on maps of 256 tiles and more): two waves per SIMD
+    '_Z20conv_fwd_flow_kernelILi2ELi4ELi0ELi1ELi1ELi1ELi0EEv8ConvArgs': (184, 2, True),
+    '_Z20conv_fwd_flow_kernelILi2ELi4ELi0ELi4ELi1ELi1ELi0EEv8ConvArgs': (184, 2, True),
+    '_Z20conv_fwd_flow_kernelILi3ELi4ELi0ELi1ELi1ELi1ELi0EEv8ConvArgs': (216, 2, True),
+    '_Z20conv_fwd_flow_kernelILi2ELi4ELi0ELi1ELi1ELi2ELi0EEv8ConvArgs': (152, 2, True),
     # the transposed k2s2 maps in scatter form (b2m_conv_up, round 5): no LDS strip, three waves per SIMD by registers
     '_Z20conv_fwd_flow_kernelILi2ELi3ELi0ELi1ELi1ELi0ELi1EEv8ConvArgs': (168, 3, True),
     '_Z20conv_fwd_flow_kernelILi2ELi2ELi0ELi1ELi1ELi0ELi1EEv8ConvArgs': (168, 3, True),
@@ -128,7 +133,7 @@ def test_nothing_touches_a_register_of_a_load_in_flight(kernels, name):
     in the source -- the statement that waits is the only reader -- and this is the check that it stays cured; the trace also
     proves the counts themselves: an MFMA reading an operand whose load is still among the N youngest is reported.)"""
     import isa_check
-    assert len(HAND_ISSUED) == 32, HAND_ISSUED      # 14 forward variants (round 6: + the two-slice form) + 9 weight-gradient block shapes x {plain, exchanged row roles}
+    assert len(HAND_ISSUED) == 36, HAND_ISSUED      # 18 forward variants (round 6: + the two-slice form, + four 64-column half variants) + 9 weight-gradient block shapes x {plain, exchanged row roles}
     body = isa_check.kernel_body(isa_check.device_asm(), name)
     assert sum(1 for i, l in enumerate(body) if 'global_load' in l and 'ASMSTART' in body[i - 1] + body[i - 2] + body[i - 3]) >= 8
     assert isa_check.inflight_violations(body) == []

@@ -90,6 +90,11 @@ for name, rb, K, c1, c2, co in cases:
         f_h = lambda: F_.conv_affine_h(x1h, x2h, wh, rbh, n_out)
         f_h(); torch.cuda.synchronize()
         line += ' | half fwd %6.2f TF' % (fl / min(timeit(f_h) for _ in range(4)) / 1e9)
+        if co % 64 == 0 and K > 1:      # ... and in 32-column strips (B2M_CONV_TW4_H=0: the strip width of the fp32 kernels)
+            os.environ['B2M_CONV_TW4_H'] = '0'; _lib.reload_env(); F_.invalidate_half_images()
+            f_h(); torch.cuda.synchronize()
+            line += ' (32-col strips %6.2f)' % (fl / min(timeit(f_h) for _ in range(4)) / 1e9)
+            os.environ.pop('B2M_CONV_TW4_H'); _lib.reload_env(); F_.invalidate_half_images()
         if rb is not None and c2 == 0:
             # ... and the half weight gradient (b2m_conv_wgrad_h): f16 MFMA through the transposing LDS read | operands converted on
             # load, fp32 MFMA, flat pipeline | the same, plain kernel
