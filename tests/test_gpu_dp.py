@@ -161,6 +161,14 @@ def test_half_training_under_syncbn_two_ranks():
     _two_rank_check('gloo', half=True, tol=5e-2)
 
 
+@pytest.mark.timeout(600)
+def test_half_training_under_syncbn_two_ranks_rccl():
+    """The same over RCCL, one rank per GPU (skipped on the single-GPU test box; tools/first_multigpu_lease.sh runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs')
+    _two_rank_check('nccl', half=True, tol=5e-2)
+
+
 @pytest.mark.timeout(900)
 def test_syncbn_statistics_through_ipc_mailboxes_two_ranks():
     """B2M_SYNCBN_IPC=1: every SyncBN statistics exchange of the step (forward and backward, single layers, pairs, the small-map
