@@ -152,8 +152,9 @@ def conv_tile_stats() -> bool:
     return os.environ.get('B2M_CONV_STATS_H', '1') == '1' and F_.conv_tile_stats()
 
 
-def _conv_h(x1, x2, image, K, rb, n_out, cout, tile_stats=None):
-    """tile_stats: a list that receives (tensor [ntiles, 2, cout] fp64, ntiles) -- the per-tile column sums of the output as stored."""
+def _conv_h(x1, x2, image, K, rb, n_out, cout, tile_stats=None, res=None):
+    """tile_stats: a list that receives (tensor [ntiles, 2, cout] fp64, ntiles) -- the per-tile column sums of the output as stored.
+    res: a half (n_out, cout) tensor added to the result in the kernel's epilogue (fp32 sum, one rounding)."""
     c1 = x1.shape[1]
     c2 = x2.shape[1] if x2 is not None else 0
     out = torch.empty((n_out, cout), dtype=torch.float16, device=x1.device)
@@ -169,7 +170,7 @@ def _conv_h(x1, x2, image, K, rb, n_out, cout, tile_stats=None):
         return out
     _call('b2m_conv_fwd_h', x1.data_ptr(), x1.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0, c2, x1.shape[0],
           image.data_ptr(), K, rb.rb_in.data_ptr(), rb.rb_out.data_ptr(), rb.rb_cnt.data_ptr(), n_out, out.data_ptr(), out.stride(0),
-          cout, None, None, None, 0, 0, meta={'half': True})
+          cout, None, None, _ptr(res), res.stride(0) if res is not None else 0, 0, meta={'half': True})
     return out
 
 
@@ -193,7 +194,8 @@ class _ConvH(torch.autograd.Function):
     """Y = sum_k [x1|x2][in_k] W[k], half in / out (functional._SparseConv without bias, pass-through and tile statistics)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, rb_f, rb_b, mirror, n_out, holder=None):
+    def forward(ctx, x1, x2, weight, rb_f, rb_b, mirror, n_out, holder=None, passthrough=False):
+        in1, in2 = x1, x2
         x1 = _hc(x1)
         x2 = _hc(x2) if x2 is not None else None
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
@@ -204,21 +206,44 @@ class _ConvH(torch.autograd.Function):
         y = _conv_h(x1, x2, images.get(weight, c1), K, rb_f, n_out, cout, tile_stats=holder)
         ctx.save_for_backward(x1, x2, weight)
         ctx.rb_f, ctx.rb_b, ctx.mirror = rb_f, rb_b, mirror
+        if passthrough:
+            # The inputs come back as further outputs, as in functional._SparseConv: whoever else consumes them (the residual
+            # branch of a BasicBlock) takes THESE, so their gradient arrives here in one call with dy and the data gradient takes
+            # it as the residual of its epilogue (fp32 sum, one rounding, a new tensor: nothing is modified in place) -- instead
+            # of an add kernel of autograd's behind the convolution (22 per step).
+            ctx.set_materialize_grads(False)
+            return (y, in1) if in2 is None else (y, in1, in2)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, p1=None, p2=None):
         x1, x2, weight = ctx.saved_tensors
+        if dy is None:                         # only the passed-through inputs were used downstream
+            return p1, p2, None, None, None, None, None, None, None
         dy = _hc(dy)
         w3 = weight if weight.dim() == 3 else weight.unsqueeze(0)
         K, cin, cout = w3.shape
         c1 = x1.shape[1]
         inv = 1.0 / loss_scale[0]
         dx1 = dx2 = dw = None
+        def fusable(p, n, c):
+            return (p is not None and p.dtype == torch.float16 and tuple(p.shape) == (n, c) and p.stride(1) == 1 and
+                    p.stride(0) % 4 == 0 and p.data_ptr() % 8 == 0 and n > 0)
         if ctx.needs_input_grad[0]:
-            dx1 = _conv_h(dy, None, weight_pack_ht(weight, ctx.mirror, 0, c1), K, ctx.rb_b, x1.shape[0], c1)
+            f = fusable(p1, x1.shape[0], c1)
+            dx1 = _conv_h(dy, None, weight_pack_ht(weight, ctx.mirror, 0, c1), K, ctx.rb_b, x1.shape[0], c1, res=p1 if f else None)
+            if p1 is not None and not f:
+                dx1 = dx1 + p1
+        elif p1 is not None:
+            dx1 = p1
         if x2 is not None and ctx.needs_input_grad[1]:
-            dx2 = _conv_h(dy, None, weight_pack_ht(weight, ctx.mirror, c1, x2.shape[1]), K, ctx.rb_b, x2.shape[0], x2.shape[1])
+            f = fusable(p2, x2.shape[0], x2.shape[1])
+            dx2 = _conv_h(dy, None, weight_pack_ht(weight, ctx.mirror, c1, x2.shape[1]), K, ctx.rb_b, x2.shape[0], x2.shape[1],
+                          res=p2 if f else None)
+            if p2 is not None and not f:
+                dx2 = dx2 + p2
+        elif p2 is not None:
+            dx2 = p2
         if ctx.needs_input_grad[2]:
             dw = grad_slot(weight)
             if dw is None:
@@ -242,17 +267,26 @@ class _ConvH(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(F_.join_side_streams)
             else:
                 run()
-        return dx1, dx2, dw, None, None, None, None, None
+        return dx1, dx2, dw, None, None, None, None, None, None
 
 
-def conv(x1, x2, weight, rb_f, rb_b, mirror, n_out, collect_stats=False):
+def conv(x1, x2, weight, rb_f, rb_b, mirror, n_out, collect_stats=False, passthrough=False):
     """collect_stats: the caller batch-normalises the result in training mode; the per-tile column sums then ride along on the
-    returned tensor (attribute `_b2m_tile_stats`, read by batch_norm), as functional.sparse_conv does for the fp32 layers."""
+    returned tensor (attribute `_b2m_tile_stats`, read by batch_norm), as functional.sparse_conv does for the fp32 layers.
+    passthrough: returns (y, x1, x2) with x1 / x2 aliases of the inputs for every OTHER consumer of them (functional.sparse_conv);
+    the inputs themselves when no gradient is being recorded."""
     holder = [] if (collect_stats and conv_tile_stats()) else None
-    y = _ConvH.apply(x1, x2, weight, rb_f, rb_b, mirror, n_out, holder)
+    alias = bool(passthrough) and torch.is_grad_enabled() and F_.conv_passthrough() and \
+        (x1.requires_grad or (x2 is not None and x2.requires_grad))
+    out = _ConvH.apply(x1, x2, weight, rb_f, rb_b, mirror, n_out, holder, alias)
+    y = out[0] if alias else out
     if holder:
         y._b2m_tile_stats = holder[0]
-    return y
+    if not passthrough:
+        return y
+    if not alias:
+        return y, x1, x2
+    return (y, out[1], out[2] if x2 is not None else None)
 
 
 _ws = {}

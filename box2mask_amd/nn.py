@@ -116,8 +116,8 @@ class MinkowskiConvolution(_ConvBase):
             y, a1, a2 = out
             return x.new(y, level=level), _like(x, a1, a2)
         if x1.dtype == torch.float16:
-            # half-precision training (half_train.py): the same layer on binary16 activations.  No pass-through form: the
-            # other consumers of x take x itself and autograd sums the two half gradients
+            # half-precision training (half_train.py): the same layer on binary16 activations; the passed-through gradient is the
+            # residual of the data gradient's epilogue
             from . import half_train as HT
             assert self.bias is None, 'the half trunk has no biased convolutions'
             if self.kernel_volume == 1:
@@ -126,8 +126,8 @@ class MinkowskiConvolution(_ConvBase):
                 rb_f = rb_b = m.rulebook_same(l, self.kernel_size); mirror, level = True, None
             else:
                 rb_f, rb_b, mirror, level = m.rulebook_down(l), m.rulebook_up(l), False, l + 1
-            y = HT.conv(x1, x2, self.kernel, rb_f, rb_b, mirror, rb_f.n_out, collect_stats=self.training)
-            return result((y, x1, x2) if passthrough else y, level)
+            return result(HT.conv(x1, x2, self.kernel, rb_f, rb_b, mirror, rb_f.n_out, collect_stats=self.training,
+                                  passthrough=passthrough), level)
         if self.kernel_volume == 1:
             assert self.stride == 1
             return result(F_.sparse_conv(x1, x2, self.kernel, self.bias, None, None, False, x1.shape[0],

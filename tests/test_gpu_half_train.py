@@ -420,3 +420,55 @@ def test_half_convolution_strip_widths(maps, monkeypatch, level, cin, cout, regi
         monkeypatch.undo()
         _lib.reload_env()
         HT.images.__init__()
+
+
+@pytest.mark.parametrize('level,c1,c2,cout', [(0, 96, 0, 96), (1, 96, 32, 128), (1, 64, 0, 64)])
+def test_half_convolution_passes_the_other_consumers_gradient_through(maps, monkeypatch, level, c1, c2, cout):
+    """HT.conv(passthrough=True) hands the inputs back as aliases for their other consumers (a BasicBlock's residual branch): their
+    gradient then arrives at the convolution's backward together with dy and is the RESIDUAL of the data gradient's epilogue -- one
+    launch, fp32 sum, one rounding -- instead of an add kernel of autograd's behind it.  Against B2M_CONV_PASSTHROUGH=0 (the plain
+    form + autograd's add: two roundings) and against the fp32 kernels."""
+    from box2mask_amd import functional as F_, half_train as HT, _lib
+    monkeypatch.setenv('B2M_WGRAD_STREAM', '0')
+    monkeypatch.setattr(HT, 'loss_scale', [1.0])
+    m = maps
+    rb = m.rulebook_same(level, 3)
+    n = m.n(level)
+    torch.manual_seed(11 + level + c1 + cout)
+    x = torch.randn(n, c1 + c2, device='cuda').half()
+    w = (torch.randn(27, c1 + c2, cout, device='cuda') * (2.0 / ((c1 + c2) * 10) ** 0.5)).half().float().contiguous()
+    gy = torch.randn(n, cout, device='cuda').half()
+    g_other = torch.randn(n, c1 + c2, device='cuda').half()
+    grads = {}
+    for pt in ('1', '0'):
+        monkeypatch.setenv('B2M_CONV_PASSTHROUGH', pt)
+        calls = []
+        _lib.set_hook(lambda name, a, meta=None: calls.append(name))
+        try:
+            xh = x.clone().requires_grad_(True)
+            wh = w.clone().requires_grad_(True)
+            x1 = xh[:, :c1].contiguous() if c2 else xh
+            x2 = xh[:, c1:].contiguous() if c2 else None
+            y, a1, a2 = HT.conv(x1, x2, wh, rb, rb, True, n, passthrough=True)
+            assert (a1 is not x1) == (pt == '1')
+            other = a1 if a2 is None else torch.cat([a1, a2], 1)
+            ((y.float() * gy.float()).sum() + (other.float() * g_other.float()).sum()).backward()
+        finally:
+            _lib.set_hook(None)
+        torch.cuda.synchronize()
+        grads[pt] = (xh.grad.clone(), wh.grad.clone(), y.detach().clone())
+    xf = x.float().requires_grad_(True)
+    wf = w.clone().requires_grad_(True)
+    f1 = xf[:, :c1].contiguous() if c2 else xf
+    f2 = xf[:, c1:].contiguous() if c2 else None
+    yf = F_.sparse_conv(f1, f2, wf, None, rb, rb, True, n)
+    ((yf * gy.float()).sum() + (xf * g_other.float()).sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(grads['1'][2], grads['0'][2])
+    _half_close(grads['1'][0], xf.grad, 'data gradient + the other consumer\'s gradient in one rounding')
+    assert _rel(grads['0'][0].float(), xf.grad) < 2e-3            # (two roundings: the element bound of one does not hold)
+    for pt in ('1', '0'):
+        assert _rel(grads[pt][1], wf.grad) < 1e-4
+    # one rounding instead of two: the fused form is at least as close to the fp32 sum
+    e1 = float((grads['1'][0].float() - xf.grad).abs().mean()); e0 = float((grads['0'][0].float() - xf.grad).abs().mean())
+    assert e1 <= e0 * 1.001, (e1, e0)

@@ -1,6 +1,6 @@
 """Which torch (aten) operators does one training step issue, and from where?
 
-    python tools/torch_ops.py            (BS=8 TV=150000 PREFETCH=1)
+    python tools/torch_ops.py            (BS=8 TV=150000 PREFETCH=1 HALF=0|1)
 
 A TorchDispatchMode sees every aten operator of the step -- forward, the autograd engine's backward thread, the optimizer --
 and books it under the innermost frame of this repository that issued it.  Operators that only make views or allocate are
@@ -52,7 +52,7 @@ class Log(TorchDispatchMode):
 
 
 def main():
-    cfg = scannet_config()
+    cfg = scannet_config(half_training=os.environ.get('HALF', '0') == '1')
     torch.manual_seed(0)
     model = Model(cfg, *synth.scannet_tables())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
