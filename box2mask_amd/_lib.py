@@ -207,9 +207,14 @@ def call_ret(name, *args):
     return rc
 
 
+env_epoch = [0]      # advanced by reload_env: whatever was built under the old switches (packed weight images: their strip width is a
+                     # switch) is rebuilt on its next use
+
+
 def reload_env():
     """The library caches the B2M_* switches per process: call this after changing one in os.environ."""
     load().b2m_reload_env()
+    env_epoch[0] += 1
 
 
 def require_gpu():

@@ -85,6 +85,7 @@ class _PackedWeights:
         self.pending = {}
         self.dirty = True
         self.pass_id = 0
+        self.env_epoch = _lib.env_epoch[0]
 
     @staticmethod
     def _w3(weight):
@@ -93,6 +94,8 @@ class _PackedWeights:
         return w3
 
     def get(self, weight, transpose=False, mirror=False, slice_begin=0, slice_count=None):
+        if self.env_epoch != _lib.env_epoch[0]:          # the library's switches changed (the images' strip width is one): start over
+            self.__init__()
         w3 = self._w3(weight.detach())
         K, cin, cout = w3.shape
         sc = cin if slice_count is None else slice_count
@@ -166,6 +169,8 @@ class _PackedWeights:
         since they were packed (training_epoch) and no image was registered since -- 0.37 ms per pass that a batch-size-1
         forward pass of 5-7 ms would otherwise spend on weights that cannot have changed; a parameter changed through torch
         (load_state_dict, in-place ops) is still caught by its version counter at lookup (`get`)."""
+        if self.env_epoch != _lib.env_epoch[0]:
+            self.__init__()
         if inference and not self.dirty and self.plan is not None and getattr(self, '_epoch', None) == training_epoch():
             return
         self._epoch = training_epoch()
@@ -353,7 +358,7 @@ def weight_pack_h(weight, c1: int, c2: int):
     assert cin == c1 + c2
     e = _half_images.get(id(weight))
     if (e is not None and e[0]() is weight and e[1] == (c1, c2) and e[3] == weight._version and e[4] == weight.data_ptr()
-            and e[5] == _half_epoch[0]):
+            and e[5] == (_half_epoch[0], _lib.env_epoch[0])):       # (env_epoch: the image's strip width is a library switch)
         return e[2]
     n = _lib.load().b2m_weight_pack_h_size(K, c1, c2, cout)
     image = torch.empty(n, dtype=torch.float16, device=w3.device)
@@ -361,7 +366,7 @@ def weight_pack_h(weight, c1: int, c2: int):
     if e is None:                                   # a new parameter: drop the images of parameters that no longer exist
         for k in [k for k, v in _half_images.items() if v[0]() is None]:
             del _half_images[k]
-    _half_images[id(weight)] = [weakref.ref(weight), (c1, c2), image, weight._version, weight.data_ptr(), _half_epoch[0]]
+    _half_images[id(weight)] = [weakref.ref(weight), (c1, c2), image, weight._version, weight.data_ptr(), (_half_epoch[0], _lib.env_epoch[0])]
     return image
 
 

@@ -57,6 +57,7 @@ class _HalfImages:
         self.dirty = True
         self.pass_id = 0
         self.pending = None        # event of the side-stream launch of this pass
+        self.env_epoch = _lib.env_epoch[0]
 
     @staticmethod
     def _pack_one(w3, d, image):
@@ -67,6 +68,8 @@ class _HalfImages:
             _call('b2m_weight_pack_h', w3.data_ptr(), cout, K, c1, cin - c1, cout, image.data_ptr())
 
     def get(self, weight, c1=0, transposed=False, mirror=False, s0=0, sc=0):
+        if self.env_epoch != _lib.env_epoch[0]:          # the library's switches changed (the images' strip width is one): start over
+            self.__init__()
         w3 = weight.detach()
         w3 = w3 if w3.dim() == 3 else w3.unsqueeze(0)
         assert w3.dtype == torch.float32 and w3.is_contiguous()
@@ -113,6 +116,8 @@ class _HalfImages:
         self.plan = (torch.from_numpy(host).to(es[0][2].device), len(keys), int(blocks), keys)
 
     def begin_pass(self):
+        if self.env_epoch != _lib.env_epoch[0]:
+            self.__init__()
         self.pass_id += 1
         self.pending = None
         if not self.entries:
