@@ -17,4 +17,12 @@ if os.environ.get('HALF'):          # ... and the half-precision inference kerne
     xh = x.half()
     for _ in range(3):
         F_.conv_affine_h(xh, None, w, rb, rb.n_out)
+    # ... the half weight gradient on the f16 MFMA (conv_wgrad_trh_kernel) and the 64-column F16 convolution (128 -> 128)
+    from box2mask_amd import half_train as HT
+    dyh = dy.half(); dwh = torch.zeros_like(w)
+    for _ in range(2):
+        HT._wgrad_h(xh, dyh, rb, 27, dwh, 0, 1.0)
+    x128 = torch.randn(rb.n_in, 128, device='cuda').half(); w128 = torch.randn(27, 128, 128, device='cuda') * 0.05
+    for _ in range(2):
+        F_.conv_affine_h(x128, None, w128, rb, rb.n_out)
 torch.cuda.synchronize()
