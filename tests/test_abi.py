@@ -81,3 +81,45 @@ def test_product_does_not_import_oracle():
         if f.endswith('.py'):
             txt = open(os.path.join(pkg, f)).read()
             assert 'import oracle' not in txt and 'from oracle' not in txt, f
+
+
+def test_round6_entries_check_their_arguments_on_the_host():
+    """The entries added in round 6 validate their arguments before anything touches a device (negative return + b2m_last_error, the
+    convention of include/b2m.h) -- and b2m_weight_pack_h_plan, which is host code altogether, lays a plan out as documented."""
+    import ctypes as C
+    import numpy as np
+    lib = _lib.load()
+    err = lambda: lib.b2m_last_error().decode()
+    # the plan of two images of a (27, 96, 128) layer: forward image (96 | 0 input channels) and the transposed image of channels 32..95
+    n = 2
+    i64 = lambda v: np.ascontiguousarray(v, dtype=np.int64)
+    i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    cols = [i64([4096, 4096]), i64([8192, 16384]), i32([27, 27]), i32([96, 96]), i32([128, 128]), i32([96, 0]), i32([0, 1]), i32([0, 1]),
+            i32([0, 32]), i32([0, 64])]
+    size = lib.b2m_weight_pack_h_plan_size()
+    assert 64 <= size <= 128
+    host = np.zeros(n * size, np.uint8)
+    blocks = lib.b2m_weight_pack_h_plan(n, *[p(c) for c in cols], p(host))
+    total0 = lib.b2m_weight_pack_h_size(27, 96, 0, 128)
+    total1 = lib.b2m_weight_pack_h_size(27, 128, 0, 64)
+    assert total0 == 27 * 96 * 128 and total1 == 27 * 128 * 64            # (complete strips and chunks: no padding)
+    assert blocks == -(-total0 // 2048) + -(-total1 // 2048)
+    bad = [c.copy() for c in cols]
+    bad[8][1] = 64                                                          # slice 64 .. 127 of 96 input channels
+    assert lib.b2m_weight_pack_h_plan(n, *[p(c) for c in bad], p(host)) < 0 and 'slice' in err()
+    bad = [c.copy() for c in cols]
+    bad[5][0] = 40                                                          # 40 | 56 input channels: not multiples of 16
+    assert lib.b2m_weight_pack_h_plan(n, *[p(c) for c in bad], p(host)) < 0 and '16' in err()
+    assert lib.b2m_weight_pack_h_run(None, 0, 0, None) == 0                 # nothing to do: no launch, no device needed
+    # half weight gradient: 2-byte aligned operands
+    a = [4097, 96, 96, 1000, 8192, 96, 96, 64, 64, 64, 1000, 27, 4096, 96, 96 * 96, 0, 1.0, None]
+    assert lib.b2m_conv_wgrad_h(*a) < 0 and 'aligned' in err()
+    # F16 convolution with tile sums: the sums' buffer is not optional
+    a = [4096, 96, 96, None, 0, 0, 1000, 8192, 27, 64, 64, 64, 1000, 16384, 96, 96, None, None]
+    assert lib.b2m_conv_fwd_h_stats(*a) < 0 and 'tile_stats' in err()
+    # half BatchNorm backward: ReLU needs the stored output or the forward's scale / shift
+    a = [4096, 96, None, 0, 8192, 96, 1000, 96, 64, 64, 1, None, None, 64, 64, None, None, 1.0, None]
+    assert lib.b2m_bn_bwd_reduce_h(*a) < 0 and 'relu' in err()
+    a = [4096, 96, None, 0, 8192, 96, 1000, 96, 64, 64, None, 64, 1000.0, None, 1, None, None, 16384, 96, None, 0, None]
+    assert lib.b2m_bn_bwd_apply_h(*a) < 0 and 'relu' in err()
