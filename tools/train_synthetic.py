@@ -3,7 +3,7 @@ batch (prepare.voxelize_scene / box_supervision / collate) -> training steps as 
 -> a checkpoint in the reference's format -> predictions -> instance masks -> ScanNet AP against the scenes' own
 instances (eval_metric.compute_eval).
 
-    python tools/train_synthetic.py --scenes 4 --voxels 20000 --steps 200
+    python tools/train_synthetic.py --scenes 4 --voxels 20000 --steps 200 [--half 1]
 """
 import argparse
 import os
@@ -62,9 +62,10 @@ def main(argv=None):
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--eval-every', type=int, default=50)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--half', type=int, default=0, help='1: cfg.half_training (half activations / gradients in the trunk, half_train.py)')
     args = ap.parse_args(argv)
     torch.manual_seed(args.seed)
-    cfg = scannet_config(lr=args.lr, mlp_bb_scores_start_epoch=0)       # score head trained from the first step
+    cfg = scannet_config(lr=args.lr, mlp_bb_scores_start_epoch=0, half_training=bool(args.half))       # score head trained from the first step
     cfg.checkpoint_path = tempfile.mkdtemp(prefix='b2m_ckpt_') + '/'
     sup = SimpleNamespace(smallest_bb_heuristic=True)
     batch, raws = build_batch(range(args.scenes), args.voxels, 'train', sup)
