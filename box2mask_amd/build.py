@@ -40,12 +40,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = None
     for s, p in procs:
         out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode()))
-        if verbose and out.strip():
+        if p.returncode != 0 and failed is None:
+            failed = (s, out.decode())
+        elif verbose and out.strip():
             print(out.decode())
+    if failed is not None:
+        # the library of an OLDER source must not survive a failed build: whatever runs next would run it in silence (round 6:
+        # two hours of GPU leases measured a library one edit behind its source)
+        if os.path.exists(LIB):
+            os.remove(LIB)
+        raise RuntimeError('hipcc failed on %s (the stale %s was removed):\n%s' % (failed[0], os.path.basename(LIB), failed[1]))
     cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
     if verbose:
         print(' '.join(cmd), flush=True)

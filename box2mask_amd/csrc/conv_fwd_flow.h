@@ -340,7 +340,15 @@ __global__ __launch_bounds__(64 * WPB, TW == 4 ? 2 : (TW == 2 && D == 2 && !UP) 
         };
         auto weights = [&](int j, int e, int c) {
             const uint32_t blk = (uint32_t)(e & 127) * wkstride + wstrip + (uint32_t)c;     // wave-uniform
-            const char* wsrc = (const char*)a.wp + (size_t)blk * ((size_t)(F16 == 2 ? LW * 2 : LW * 4) << (wide ? 1 : 0)) + wsub;
+            size_t woff = (size_t)blk * ((size_t)(F16 == 2 ? LW * 2 : LW * 4) << (wide ? 1 : 0)) + wsub;
+            if constexpr (F16 == 2) {
+                // Wave-uniform, and told so: in the 16-channel-chunk variants hipcc computes this offset on the vector ALU and then
+                // hands the asm statements below a VGPR pair for their "s" operand -- which `-S` prints without complaint and only
+                // the assembler (`-c`) rejects ("invalid operand for instruction").
+                woff = ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(woff >> 32)) << 32) |
+                       (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)woff);
+            }
+            const char* wsrc = (const char*)a.wp + woff;
 #pragma unroll
             for (int u = 0; u < TW; ++u) {
                 if constexpr (F16 == 2) {

@@ -90,6 +90,11 @@ for name, rb, K, c1, c2, co in cases:
         f_h = lambda: F_.conv_affine_h(x1h, x2h, wh, rbh, n_out)
         f_h(); torch.cuda.synchronize()
         line += ' | half fwd %6.2f TF' % (fl / min(timeit(f_h) for _ in range(4)) / 1e9)
+        if K > 1:                       # ... one wave per workgroup (B2M_CONV_GROUP_H=0: rounds 4 - 5) instead of four items per workgroup
+            os.environ['B2M_CONV_GROUP_H'] = '0'; _lib.reload_env()
+            f_h(); torch.cuda.synchronize()
+            line += ' (ungrouped %6.2f)' % (fl / min(timeit(f_h) for _ in range(4)) / 1e9)
+            os.environ.pop('B2M_CONV_GROUP_H'); _lib.reload_env()
         if co % 64 == 0 and K > 1:      # ... and in 32-column strips (B2M_CONV_TW4_H=0: the strip width of the fp32 kernels)
             os.environ['B2M_CONV_TW4_H'] = '0'; _lib.reload_env(); F_.invalidate_half_images()
             f_h(); torch.cuda.synchronize()
